@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- driver contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.
+
+Workload `roi_align_rotated` (default this round): one step = one rotated RoIAlign FORWARD pass of
+the north-star point of BASELINE.json -- 1024x1024 tile -> stride-4 FPN level = 1x256x256x256 fp32
+feature map, 2000 random OBB RoIs, 7x7 output, sampling 2.  Inputs are resident in
+HBM before the timed region.  `value` = algorithmic GB/s over all ranks (each rank runs the same
+per-GPU workload on its own map + RoIs: image-parallel, no data-path collective -> "weak").
+
+ALGORITHMIC bytes per launch: 4*N*C*H*W (map read once) + 4*R*C*PH*PW (output written
+once) + 24*R  = 67.11 MB + 100.35 MB + 0.05 MB = 167.5 MB at R = 2000.
+
+Other workloads (`--workload`): roi_align_rotated_bwd, box_iou_rotated, nms_rotated (reported with the
+same JSON shape; used for profiles/, not for the driver's default line).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--workload", default="roi_align_rotated")
+    p.add_argument("--rois", type=int, default=2000)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def make_inputs(workload, R, seed, dev):
+    from tests import inputs as I
+    rng = np.random.default_rng(seed)
+    d = {}
+    if workload.startswith("roi_align"):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        feat = torch.randn((1, 256, 256, 256), generator=g)
+        d["feat_np"] = None
+        d["feat"] = feat.to(dev).contiguous(memory_format=torch.channels_last)
+        rois = I.rois_from_obbs(I.random_obbs(rng, R), np.zeros(R))
+        d["rois_np"] = rois
+        d["rois"] = torch.from_numpy(rois).to(dev)
+        d["grad"] = torch.randn((R, 256, 7, 7), device=dev) if workload.endswith("bwd") else None
+        d["feat_cpu"] = feat
+    elif workload == "box_iou_rotated":
+        b1, b2 = I.random_obbs(rng, 64, wh=(16.0, 256.0)), I.random_obbs(rng, 21824)
+        d["b1_np"], d["b2_np"] = b1, b2
+        d["b1"], d["b2"] = torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev)
+    elif workload == "nms_rotated":
+        n = R
+        dets = np.concatenate([I.random_obbs(rng, n // 2), I.clustered_obbs(rng, n - n // 2, 64, 1024.0)], 0)
+        scores = (rng.uniform(0, 1, n) + np.arange(n) * 1e-7).astype(np.float32)
+        d["dets_np"], d["scores_np"] = dets, scores
+        d["dets"], d["scores"] = torch.from_numpy(dets).to(dev), torch.from_numpy(scores).to(dev)
+        d["order"] = torch.argsort(d["scores"], descending=True, stable=True)
+    else:
+        raise SystemExit("unknown workload " + workload)
+    return d
+
+
+def make_step(workload, d):
+    """returns (step_fn, units_per_step, unit_name, algorithmic_bytes_per_launch, kernel_name, dtype)"""
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    if workload == "roi_align_rotated":
+        feat, rois = d["feat"], d["rois"]
+        R = rois.shape[0]
+        out = torch.empty((R, 256, 7, 7), device=feat.device)
+        fp, rp, op = feat.data_ptr(), rois.data_ptr(), out.data_ptr()
+
+        def step():
+            L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op,
+                                               L.stream_ptr(feat)), "fwd")
+        d["out"] = out
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        return step, nbytes / 1e9, "GB", nbytes, "roi_align_fwd_kernel<ROTATED,vec4>", "f32"
+    if workload == "roi_align_rotated_bwd":
+        feat, rois, grad = d["feat"], d["rois"], d["grad"]
+        R = rois.shape[0]
+        gin = torch.empty_like(feat)
+        gp, rp, ip = grad.data_ptr(), rois.data_ptr(), gin.data_ptr()
+
+        def step():
+            L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, ip,
+                                                L.stream_ptr(feat)), "bwd")
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        return step, nbytes / 1e9, "GB", nbytes, "roi_align_bwd_kernel<ROTATED>", "f32"
+    if workload == "box_iou_rotated":
+        from jdet_amd.ops import box_iou_rotated
+        b1, b2 = d["b1"], d["b2"]
+
+        def step():
+            d["out"] = box_iou_rotated(b1, b2)
+        n = b1.shape[0] * b2.shape[0]
+        return step, n / 1e6, "Mpair", 20 * (b1.shape[0] + b2.shape[0]) + 4 * n, "box_iou_kernel", "f32"
+    if workload == "nms_rotated":
+        from jdet_amd.ops.nms_rotated import nms_rotated_keep_mask
+        dets, order = d["dets"], d["order"]
+
+        def step():
+            d["out"] = nms_rotated_keep_mask(dets, order, 0.1)
+        n = dets.shape[0]
+        return step, n * (n - 1) / 2 / 1e6, "Mpair", 20 * n + 8 * n * ((n + 63) // 64) + n, "nms_mask_kernel", "f32"
+    raise SystemExit("unknown workload")
+
+
+def cpu_baseline(workload, d, R):
+    """Oracle (kind=port: our CPU restatement, parity-pinned against the reference kernel text) on a
+    bounded sample of the same workload, all host cores (OpenMP over RoIs / rows)."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    O.lib()
+    if workload.startswith("roi_align"):
+        feat = d["feat_cpu"].numpy()
+        # size the sample from a 16-RoI probe so that it costs ~10-20 s
+        t0 = time.perf_counter()
+        O.roi_align_forward(O.V_ROT, feat, d["rois_np"][:16], (7, 7), 0.25, 2)
+        per = (time.perf_counter() - t0) / 16
+        rs = int(min(R, max(32, 12.0 / max(per, 1e-6))))
+        t0 = time.perf_counter()
+        if workload.endswith("bwd"):
+            g = np.ones((rs, 256, 7, 7), np.float32)
+            O.roi_align_backward(O.V_ROT, g, d["rois_np"][:rs], feat.shape, 0.25, 2)
+            cores_used = 1  # serial accumulation
+        else:
+            O.roi_align_forward(O.V_ROT, feat, d["rois_np"][:rs], (7, 7), 0.25, 2)
+            cores_used = cores
+        t = time.perf_counter() - t0
+        full = t * R / rs
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        return {"value": nbytes / 1e9 / full, "unit": "GB/s", "cores": cores_used, "kind": "port",
+                "sample": "first %d of %d RoIs of the same map (%.1f s), extrapolated linearly in RoIs; "
+                          "algorithmic bytes of the full workload / extrapolated time" % (rs, R, t)}
+    if workload == "box_iou_rotated":
+        b1, b2 = d["b1_np"][:16], d["b2_np"]
+        t0 = time.perf_counter()
+        O.box_iou_rotated(b1, b2)
+        t = time.perf_counter() - t0
+        return {"value": b1.shape[0] * b2.shape[0] / 1e6 / t, "unit": "Mpair/s", "cores": min(cores, 16),
+                "kind": "port", "sample": "16 of 64 gt rows x 21824 anchors (%.1f s)" % t}
+    if workload == "nms_rotated":
+        dets, scores = d["dets_np"], d["scores_np"]
+        order = np.argsort(-scores, kind="stable").astype(np.int32)
+        t0 = time.perf_counter()
+        O.nms_rotated_keep(dets, order, 0.1)
+        t = time.perf_counter() - t0
+        n = dets.shape[0]
+        return {"value": n * (n - 1) / 2 / 1e6 / t, "unit": "Mpair/s", "cores": 1, "kind": "port",
+                "sample": "full n=%d greedy NMS, single thread as in the reference (%.1f s); upper-triangle "
+                          "pairs / time (the greedy loop skips suppressed rows)" % (n, t)}
+    return None
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    d = make_inputs(a.workload, a.rois, 1000 + rank, dev)
+    step, units, unit_name, nbytes, kname, dtype = make_step(a.workload, d)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / a.steps  # HIP events on the launch stream (torch's current stream)
+    if dist is not None:
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+
+    if rank == 0:
+        value = units * a.steps * world / t
+        line = {
+            "metric": ("rotated RoIAlign forward algorithmic GB/s (1024x1024 tile, %d RoIs)" % a.rois
+                       if a.workload == "roi_align_rotated" else a.workload + " " + unit_name + "/s"),
+            "value": value, "unit": unit_name + "/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": a.workload, "fmap": "1x256x256x256 fp32 NHWC", "rois": a.rois,
+                       "pooled": "7x7", "sampling_ratio": 2, "spatial_scale": 0.25,
+                       "parallelism": "image-parallel x%d (no collective)" % world},
+        }
+        ach = nbytes / 1e9 / (dev_ms / 1e3)
+        line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                            "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

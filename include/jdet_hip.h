@@ -1,0 +1,122 @@
+/* jdet_hip.h -- C ABI of libjdet_hip.so: the MI355X (gfx950) implementation of the
+ * rotated-box hot path of Jittor/JDet (reference snapshot 2025-03-10).
+ *
+ * The reference has no C ABI: every operator below is a `jt.code(...)` call whose C++/CUDA
+ * body lives in a Python string (python/jdet/ops/<op>.py).  Each entry point here replaces
+ * one such `jt.code` site; the citation on each declaration is the reference call site a
+ * maintainer would rebind (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; no framework types.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the legacy default stream).
+ *   - return 0 on success, a positive hipError_t value if a launch failed, or a negative
+ *     JDET_E_* code for argument errors.  Nothing is launched on error.
+ *   - asynchronous: no entry point synchronises the device or allocates memory; scratch
+ *     comes from the caller (see the *_workspace queries).
+ *   - all floating-point tensors are fp32 (the reference is fp32 everywhere); boxes are
+ *     [xc, yc, w, h, theta(rad)]; RoIs are [batch, xc, yc, w, h, theta] (rotated) or
+ *     [batch, x1, y1, x2, y2] (horizontal).
+ *   - inputs are never written; outputs are fully overwritten (backward kernels zero-fill
+ *     their accumulation target themselves, as the reference's cudaMemsetAsync does).
+ */
+#ifndef JDET_HIP_H_
+#define JDET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* jdet_stream_t; /* hipStream_t */
+
+#define JDET_OK 0
+#define JDET_E_BADARG (-1)   /* null pointer, negative size, unknown enum value        */
+#define JDET_E_UNSUPPORTED (-2) /* shape outside what the kernels handle (documented below) */
+#define JDET_E_WORKSPACE (-3) /* workspace too small                                     */
+
+/* RoIAlign dialects */
+#define JDET_ROI_ROTATED 0    /* ROIAlignRotated     ops/roi_align_rotated.py:L61-127,L165-255    */
+#define JDET_ROI_ROTATED_V1 1 /* ROIAlignRotated_v1  ops/roi_align_rotated_v1.py:L71-145,L193-298 */
+#define JDET_ROI_RIROI 2      /* RiRoIAlign          ops/riroi_align.py:L70-163,L228-358          */
+#define JDET_ROI_HBB_V0 3     /* ROIAlign version=0  ops/roi_align.py:L93-204                     */
+#define JDET_ROI_HBB_V1 4     /* ROIAlign version=1  (same file, ROI_ALIGN_VERSION 1)             */
+
+/* Feature-map memory layouts.  NHWC ("channels last") is the native layout of the kernels:
+ * one bilinear tap is a contiguous C-vector.  NCHW inputs go through jdet_nchw_to_nhwc. */
+#define JDET_LAYOUT_NCHW 0
+#define JDET_LAYOUT_NHWC 1
+
+int jdet_version(void);
+
+/* Layout conversion helpers (tiled transposes), x: (N,C,H,W) <-> y: (N,H,W,C). */
+int jdet_nchw_to_nhwc(const float* x, int N, int C, int H, int W, float* y, jdet_stream_t stream);
+int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, jdet_stream_t stream);
+
+/* RoIAlign forward.  Replaces the jt.code sites roi_align_rotated.py:L265-283,
+ * roi_align_rotated_v1.py:L308-326, riroi_align.py:L425-427, roi_align.py:L217-237.
+ *   feat    : (N, C, H, W) values stored NHWC, i.e. feat[((n*H+y)*W+x)*C + c]   [layout NHWC]
+ *             C is the TOTAL plane count (RiRoIAlign: C = channels * n_orient).
+ *   rois    : (R, 6) rotated dialects, (R, 5) horizontal dialects
+ *   out     : (R, C, PH, PW) contiguous (the reference's output layout)
+ *   sample_num : >0 fixed grid, <=0 adaptive ceil(roi_size / pooled_size)
+ *   n_orient   : RiRoIAlign only (C % n_orient == 0); pass 1 otherwise
+ * Limits: PH*PW <= 256; any C >= 1 (C % 4 == 0 takes the vector path). */
+int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                           const float* rois, int R, int PH, int PW, float spatial_scale,
+                           int sample_num, int n_orient, float* out, jdet_stream_t stream);
+
+/* RoIAlign backward w.r.t. the feature map.  Replaces roi_align_rotated.py:L286-307 (and the
+ * _v1 / riroi / hbb twins).  grad_in_nhwc (N,H,W,C) is zero-filled then accumulated with
+ * hardware fp32 atomics (order-nondeterministic in the last bits, as in the reference). */
+int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,
+                            int C, int H, int W, int PH, int PW, float spatial_scale,
+                            int sample_num, int n_orient, float* grad_in_nhwc,
+                            jdet_stream_t stream);
+
+/* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and
+ * box_iou_rotated_v1.py:L512 (the python-side "too small" zeroing L515-523 stays in the
+ * host wrapper).  version 0/1 selects the vertex convention; sort_mode 0 reproduces the
+ * reference CPU path (std::sort, L316-325), 1 the reference CUDA exchange sort (L338-351).
+ * stride = floats per box row (>= 5). */
+int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, int stride,
+                         int version, int sort_mode, float* ious, jdet_stream_t stream);
+
+/* Rotated NMS.  Replaces nms_rotated.py:L497-503 (nms_rotated_cpu) / L506-513 (cuda).
+ *   dets (n, box_len) box_len 5, or 6 with a label in column 5 (cross-label IoU := 0, L283-286)
+ *   order: int32 indices by descending score (the caller's argsort, nms_rotated.py:L519,L532)
+ *   cmp_ge 1: suppress when iou >= thr (reference CPU rule L444); 0: iou > thr (CUDA rule L403)
+ *   keep : n bytes, 1 = kept, indexed by ORIGINAL detection index
+ * Entirely on device: tile bitmask kernel + single-wave scan, no host synchronisation. */
+size_t jdet_nms_rotated_workspace(int n);
+int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
+                     float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,
+                     void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
+/* Deformable-conv v1 sampling.  Replace dcn_v1.py:L309-338 (im2col), L374-410 (col2im),
+ * L340-372 (col2im_coord).  im (B,C,H,W) NCHW; offset (B, dg*2*kh*kw, Ho, Wo) ordered
+ * (dy,dx) per tap; col (C*kh*kw, B, Ho, Wo). */
+int jdet_deform_im2col(const float* im, const float* offset, int B, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                       int dil_w, int deform_groups, float* col, jdet_stream_t stream);
+int jdet_deform_col2im(const float* col, const float* offset, int B, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                       int dil_w, int deform_groups, float* grad_im, jdet_stream_t stream);
+int jdet_deform_col2im_coord(const float* col, const float* im, const float* offset, int B, int C,
+                             int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
+                             int stride_w, int dil_h, int dil_w, int deform_groups,
+                             float* grad_offset, jdet_stream_t stream);
+
+/* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
+ * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
+ * out (nOut*nRot, nIn*nOri, kH, kW). */
+int jdet_arf_forward(const float* weight, const uint8_t* indices, int nOut, int nIn, int nOri,
+                     int kH, int kW, int nRot, float* out, jdet_stream_t stream);
+int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
+                      int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JDET_HIP_H_ */

@@ -1,0 +1,109 @@
+"""ctypes loader for libjdet_hip.so (the C ABI declared in include/jdet_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a tensor is not on a HIP
+device, the ops raise.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)  PyTorch is used only for device memory and the current stream.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libjdet_hip.so")
+
+_i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/jdet_hip.h one to one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "jdet_version": (_i, []),
+    "jdet_nchw_to_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "jdet_nhwc_to_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p]),
+    "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p]),
+    "jdet_box_iou_rotated": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "jdet_nms_rotated_workspace": (_sz, [_i]),
+    "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),
+    "jdet_deform_im2col": (_i, [_p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_deform_col2im": (_i, [_p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_deform_col2im_coord": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
+    "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
+}
+
+_lib = None
+
+# Hull-point ordering inside the rotated IoU: 0 = the reference's CPU path (std::sort,
+# box_iou_rotated.py:L316-325), 1 = its CUDA exchange sort (L338-351).  They differ only on
+# degenerate hulls; 0 is "the Jittor CPU reference" BASELINE.json asks parity against.
+REFERENCE_SORT = 0
+
+
+def build(force=False, verbose=False):
+    """Compile every .hip under csrc/ for gfx950 and link libjdet_hip.so in-tree."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libjdet_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "jdet_amd: %s not found.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C jdet_amd/csrc` (needs hipcc).  There is no CPU fallback." % LIB_PATH)
+        # torch is imported above, so its libamdhip64 (SONAME libamdhip64.so.7) is already in the
+        # process and our DT_NEEDED entry resolves to that same runtime: one HIP context, shared
+        # streams and allocations.
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError here == ABI drift: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class JDetHipError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "bad argument", -2: "unsupported shape", -3: "workspace too small"}
+
+
+def check(status, what):
+    if status != 0:
+        msg = _ERR.get(status, "hipError_t %d" % status)
+        raise JDetHipError("%s failed: %s" % (what, msg))
+
+
+def stream_ptr(t=None):
+    return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
+
+
+def need_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise JDetHipError(
+                "jdet_amd ops run only on a HIP device (got a %s tensor); there is no CPU fallback "
+                "in the product path" % t.device)
+
+
+def f32c(t):
+    """contiguous fp32 view/copy (the reference asserts dtypes instead; fp32 is its only dtype)"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None and t.numel() > 0 else None

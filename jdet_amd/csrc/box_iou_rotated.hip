@@ -1,0 +1,419 @@
+// Rotated-box IoU and rotated NMS for gfx950 (MI355X).
+//
+// Reference semantics:
+//   python/jdet/ops/box_iou_rotated.py:L13-310   (vertices, 16 edge intersections + 8 containment
+//                                                  tests, Graham hull, shoelace area, IoU)
+//   python/jdet/ops/box_iou_rotated_v1.py:L69-76 (opposite vertex convention)
+//   python/jdet/ops/nms_rotated.py:L281-310      (label column -> IoU 0 across labels)
+//   python/jdet/ops/nms_rotated.py:L414-449      (CPU greedy rule, `>=`), L352-411 + L450-493
+//                                                (CUDA 64x64 bitmask kernel, `>`, host scan)
+//
+// MI355X design (not a translation):
+//   * IoU is ALU/latency bound (20 B per box, ~400-3000 flop per overlapping pair).  The
+//     intersection-point array (<= 24 points) is the only dynamically indexed state; it lives
+//     in LDS as [slot][lane] (bank = lane -> conflict-free for any per-lane slot), everything
+//     else is fully unrolled into VGPRs -> no scratch memory.
+//   * a conservative circumscribed-circle test returns the exact 0 the reference would compute
+//     for clearly disjoint pairs (the overwhelming majority) before any heavy work.
+//   * float/double mix, comparison constants and operation order follow the reference's CPU
+//     path literally and the file is compiled with -ffp-contract=off, so IoU values -- and
+//     therefore NMS keep masks and assigner labels -- are bit-identical to the CPU oracle.
+//     The hull sort replays libstdc++'s insertion sort (what std::sort runs for <= 16 elements).
+//   * NMS: wave64 == 64-bit suppression word.  One wave per 64x64 tile of score-sorted boxes:
+//     lanes are the 64 column boxes, the row box is wave-uniform, __ballot() yields the mask
+//     word directly; only upper-triangle tiles run.  The greedy scan stays on the device (one
+//     workgroup: diagonal tile resolved by v_readlane chain, remaining words OR-ed in parallel
+//     into LDS) -- no cudaDeviceSynchronize + host loop as in the reference.
+#include "common.h"
+
+namespace {
+
+struct P2 {
+  float x, y;
+};
+__device__ __forceinline__ P2 mk(float x, float y) { P2 p; p.x = x; p.y = y; return p; }
+__device__ __forceinline__ P2 sub(P2 a, P2 b) { return mk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float dot_2d(P2 a, P2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float cross_2d(P2 a, P2 b) { return a.x * b.y - b.x * a.y; }
+
+struct RBox {
+  float x_ctr, y_ctr, w, h, a;
+};
+
+template <int V1>
+__device__ __forceinline__ void rotated_vertices(const RBox& box, P2 (&pts)[4]) {
+  const double theta = box.a;
+  const float cosTheta2 = (float)cos(theta) * 0.5f;
+  const float sinTheta2 = (float)sin(theta) * 0.5f;
+  if (!V1) {
+    pts[0].x = box.x_ctr - sinTheta2 * box.h - cosTheta2 * box.w;
+    pts[0].y = box.y_ctr + cosTheta2 * box.h - sinTheta2 * box.w;
+    pts[1].x = box.x_ctr + sinTheta2 * box.h - cosTheta2 * box.w;
+    pts[1].y = box.y_ctr - cosTheta2 * box.h - sinTheta2 * box.w;
+  } else {
+    pts[0].x = box.x_ctr + sinTheta2 * box.h + cosTheta2 * box.w;
+    pts[0].y = box.y_ctr + cosTheta2 * box.h - sinTheta2 * box.w;
+    pts[1].x = box.x_ctr - sinTheta2 * box.h + cosTheta2 * box.w;
+    pts[1].y = box.y_ctr - cosTheta2 * box.h - sinTheta2 * box.w;
+  }
+  pts[2].x = 2 * box.x_ctr - pts[0].x;
+  pts[2].y = 2 * box.y_ctr - pts[0].y;
+  pts[3].x = 2 * box.x_ctr - pts[1].x;
+  pts[3].y = 2 * box.y_ctr - pts[1].y;
+}
+
+// hull-sort predicate of the reference CPU path (box_iou_rotated.py:L318-325)
+__device__ __forceinline__ bool cpu_less(P2 A, P2 B) {
+  const float temp = cross_2d(A, B);
+  if ((double)fabsf(temp) < 1e-6) return dot_2d(A, A) < dot_2d(B, B);
+  return temp > 0;
+}
+
+// Per-lane point stack in LDS: element i of this lane is at base[i * NT].
+template <int NT>
+struct LanePts {
+  float* x;
+  float* y;
+  __device__ __forceinline__ P2 get(int i) const { return mk(x[i * NT], y[i * NT]); }
+  __device__ __forceinline__ void set(int i, P2 p) const {
+    x[i * NT] = p.x;
+    y[i * NT] = p.y;
+  }
+};
+
+// IoU of two boxes given as 5 floats each (raw, un-shifted), reference single_box_iou_rotated
+// (box_iou_rotated.py:L281-310).  SORT 0 = CPU std::sort replay, 1 = CUDA exchange sort.
+template <int V1, int NT>
+__device__ float single_box_iou(const float* b1, const float* b2, int sort_mode, LanePts<NT> q) {
+  RBox box1, box2;
+  const double center_shift_x = (double)(b1[0] + b2[0]) / 2.0;
+  const double center_shift_y = (double)(b1[1] + b2[1]) / 2.0;
+  box1.x_ctr = (float)((double)b1[0] - center_shift_x);
+  box1.y_ctr = (float)((double)b1[1] - center_shift_y);
+  box1.w = b1[2]; box1.h = b1[3]; box1.a = b1[4];
+  box2.x_ctr = (float)((double)b2[0] - center_shift_x);
+  box2.y_ctr = (float)((double)b2[1] - center_shift_y);
+  box2.w = b2[2]; box2.h = b2[3]; box2.a = b2[4];
+  const float area1 = box1.w * box1.h;
+  const float area2 = box2.w * box2.h;
+  if ((double)area1 < 1e-14 || (double)area2 < 1e-14) return 0.f;
+
+  P2 pts1[4], pts2[4], vec1[4], vec2[4];
+  rotated_vertices<V1>(box1, pts1);
+  rotated_vertices<V1>(box2, pts2);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    vec1[i] = sub(pts1[(i + 1) & 3], pts1[i]);
+    vec2[i] = sub(pts2[(i + 1) & 3], pts2[i]);
+  }
+  // --- get_intersection_points (L74-153)
+  int num = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float det = cross_2d(vec2[j], vec1[i]);
+      if ((double)fabsf(det) <= 1e-14) continue;
+      const P2 vec12 = sub(pts2[j], pts1[i]);
+      const float t1 = cross_2d(vec2[j], vec12) / det;
+      const float t2 = cross_2d(vec1[i], vec12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f) {
+        q.set(num++, mk(pts1[i].x + vec1[i].x * t1, pts1[i].y + vec1[i].y * t1));
+      }
+    }
+  }
+  {
+    const P2 AB = vec2[0], DA = vec2[3];
+    const float ABdotAB = dot_2d(AB, AB), ADdotAD = dot_2d(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const P2 AP = sub(pts1[i], pts2[0]);
+      const float APdotAB = dot_2d(AP, AB);
+      const float APdotAD = -dot_2d(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        q.set(num++, pts1[i]);
+    }
+  }
+  {
+    const P2 AB = vec1[0], DA = vec1[3];
+    const float ABdotAB = dot_2d(AB, AB), ADdotAD = dot_2d(DA, DA);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const P2 AP = sub(pts2[i], pts1[0]);
+      const float APdotAB = dot_2d(AP, AB);
+      const float APdotAD = -dot_2d(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        q.set(num++, pts2[i]);
+    }
+  }
+  if (num <= 2) return 0.f;
+
+  // --- convex_hull_graham (L155-238), in place: q[i] <- p[i] - start
+  int t = 0;
+  {
+    P2 best = q.get(0);
+    for (int i = 1; i < num; i++) {
+      const P2 p = q.get(i);
+      if (p.y < best.y || (p.y == best.y && p.x < best.x)) {
+        t = i;
+        best = p;
+      }
+    }
+    for (int i = 0; i < num; i++) q.set(i, sub(q.get(i), best));
+    const P2 tmp = q.get(0);
+    q.set(0, q.get(t));
+    q.set(t, tmp);
+  }
+  int k;
+  if (sort_mode == 0) {
+    // The reference fills dist[] BEFORE std::sort and never permutes it (L190-193, L316-325),
+    // so Step 4's scan sees pre-sort distances: find k on the unsorted array.
+    for (k = 1; k < num; k++) {
+      const P2 p = q.get(k);
+      if ((double)dot_2d(p, p) > 1e-8) break;
+    }
+    // libstdc++ std::__insertion_sort over q[1..num)
+    for (int i = 2; i < num; i++) {
+      const P2 val = q.get(i);
+      if (cpu_less(val, q.get(1))) {
+        for (int m = i; m > 1; m--) q.set(m, q.get(m - 1));
+        q.set(1, val);
+      } else {
+        int nx = i - 1;
+        P2 pv = q.get(nx);
+        while (cpu_less(val, pv)) {
+          q.set(nx + 1, pv);
+          nx--;
+          pv = q.get(nx);
+        }
+        q.set(nx + 1, val);
+      }
+    }
+  } else {
+    // reference CUDA exchange sort (L338-351); dist[] is swapped with q there, i.e. always
+    // equals dot(q[i],q[i])
+    for (int i = 1; i < num - 1; i++) {
+      for (int j = i + 1; j < num; j++) {
+        const P2 qi = q.get(i), qj = q.get(j);
+        const float crossProduct = cross_2d(qi, qj);
+        if (((double)crossProduct < -1e-6) ||
+            ((double)fabsf(crossProduct) < 1e-6 && dot_2d(qi, qi) > dot_2d(qj, qj))) {
+          q.set(i, qj);
+          q.set(j, qi);
+        }
+      }
+    }
+    for (k = 1; k < num; k++) {
+      const P2 p = q.get(k);
+      if ((double)dot_2d(p, p) > 1e-8) break;
+    }
+  }
+  if (k == num) return 0.f / (area1 + area2 - 0.f);  // hull is one point: area 0
+  q.set(1, q.get(k));
+  int m = 2;
+  for (int i = k + 1; i < num; i++) {
+    const P2 qi = q.get(i);
+    while (m > 1) {
+      const P2 a = q.get(m - 2);
+      if (cross_2d(sub(qi, a), sub(q.get(m - 1), a)) >= 0) m--; else break;
+    }
+    q.set(m++, qi);
+  }
+  // --- polygon_area (L240-252)
+  float area = 0;
+  if (m > 2) {
+    const P2 q0 = q.get(0);
+    for (int i = 1; i < m - 1; i++)
+      area += fabsf(cross_2d(sub(q.get(i), q0), sub(q.get(i + 1), q0)));
+    area = area / 2.0f;
+  }
+  const float intersection = area;
+  return intersection / (area1 + area2 - intersection);
+}
+
+// Conservative disjointness test on the circumscribed circles.  True only when the boxes are
+// separated by a margin far above fp32 rounding, in which case the reference finds no
+// intersection point and returns exactly 0.  NaN/inf fall through to the full path.
+__device__ __forceinline__ bool surely_disjoint(const float* b1, const float* b2) {
+  const float dx = b1[0] - b2[0], dy = b1[1] - b2[1];
+  const float d2 = dx * dx + dy * dy;
+  const float r1 = 0.5f * sqrtf(b1[2] * b1[2] + b1[3] * b1[3]);
+  const float r2 = 0.5f * sqrtf(b2[2] * b2[2] + b2[3] * b2[3]);
+  const float rr = r1 + r2;
+  return d2 > rr * rr * 1.001f + 1e-3f;
+}
+
+template <int NT>
+__device__ __forceinline__ float iou_dispatch(const float* b1, const float* b2, int version,
+                                              int sort_mode, LanePts<NT> q) {
+  if (surely_disjoint(b1, b2)) return 0.f;
+  return version ? single_box_iou<1, NT>(b1, b2, sort_mode, q)
+                 : single_box_iou<0, NT>(b1, b2, sort_mode, q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pairwise IoU: one lane per (i, j), j fastest (coalesced stores)
+// ---------------------------------------------------------------------------------------------
+constexpr int kIouBlock = 128;
+
+__global__ __launch_bounds__(kIouBlock) void box_iou_kernel(const float* __restrict__ boxes1, int n1,
+                                                            const float* __restrict__ boxes2, int n2,
+                                                            int stride, int version, int sort_mode,
+                                                            float* __restrict__ ious) {
+  __shared__ float s_x[24 * kIouBlock];
+  __shared__ float s_y[24 * kIouBlock];
+  LanePts<kIouBlock> q;
+  q.x = s_x + threadIdx.x;
+  q.y = s_y + threadIdx.x;
+  const long total = (long)n1 * n2;
+  for (long p = (long)blockIdx.x * kIouBlock + threadIdx.x; p < total; p += (long)gridDim.x * kIouBlock) {
+    const int i = (int)(p / n2), j = (int)(p % n2);
+    float a[5], b[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      a[k] = boxes1[(size_t)i * stride + k];
+      b[k] = boxes2[(size_t)j * stride + k];
+    }
+    ious[p] = iou_dispatch<kIouBlock>(a, b, version, sort_mode, q);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS: tile mask kernel (one wave per 64x64 tile) + on-device greedy scan
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ dets, int n, int box_len,
+                                                      const int32_t* __restrict__ order, float thr,
+                                                      int cmp_ge, int sort_mode,
+                                                      unsigned long long* __restrict__ mask) {
+  const int row_blk = blockIdx.y, col_blk = blockIdx.x;
+  if (col_blk < row_blk) return;  // only the upper triangle is ever read by the scan
+  __shared__ float s_x[24 * 64];
+  __shared__ float s_y[24 * 64];
+  LanePts<64> q;
+  const int lane = threadIdx.x;
+  q.x = s_x + lane;
+  q.y = s_y + lane;
+  const int col_blocks = (n + 63) >> 6;
+  const int col = col_blk * 64 + lane;  // position in score order
+  const bool col_ok = col < n;
+  float cb[6] = {0, 0, 0, 0, 0, 0};
+  if (col_ok) {
+    const float* p = dets + (size_t)order[col] * box_len;
+#pragma unroll
+    for (int k = 0; k < 5; k++) cb[k] = p[k];
+    if (box_len == 6) cb[5] = p[5];
+  }
+  const int rows = min(64, n - row_blk * 64);
+  for (int i = 0; i < rows; i++) {
+    const int row = row_blk * 64 + i;
+    const float* p = dets + (size_t)order[row] * box_len;  // wave-uniform -> scalar loads
+    float rb[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) rb[k] = p[k];
+    rb[5] = box_len == 6 ? p[5] : 0.f;
+    bool hit = false;
+    if (col_ok && col > row) {
+      // ml_nms: different labels -> IoU 0 (nms_rotated.py:L283-286); argument order is
+      // (higher score, lower score) as in the CPU loop L443
+      float ovr = 0.f;
+      if (!(box_len == 6 && rb[5] != cb[5])) ovr = iou_dispatch<64>(rb, cb, 0, sort_mode, q);
+      hit = cmp_ge ? (ovr >= thr) : (ovr > thr);
+    }
+    const unsigned long long word = __ballot(hit);
+    if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = word;
+  }
+}
+
+constexpr int kScanBlock = 256;
+constexpr int kScanMaxWords = 8192;  // n <= 524288
+
+__global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                              int n, const int32_t* __restrict__ order,
+                                                              uint8_t* __restrict__ keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // col_blocks (+1)
+  const int col_blocks = (n + 63) >> 6;
+  unsigned long long* s_keepbits = s_remv + col_blocks;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j = threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
+  __syncthreads();
+  for (int c = 0; c < col_blocks; c++) {
+    const int rows = min(64, n - c * 64);
+    if (wave == 0) {
+      // diagonal tile: lane = row; resolve the within-tile greedy dependency with readlanes
+      const int row = c * 64 + lane;
+      unsigned long long d = 0ull;
+      if (lane < rows) d = mask[(size_t)row * col_blocks + c];
+      unsigned long long removed = s_remv[c];
+      unsigned long long keepbits = 0ull;
+      const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
+      for (int i = 0; i < rows; i++) {
+        if (!((removed >> i) & 1ull)) {
+          keepbits |= 1ull << i;
+          const unsigned long long di =
+              ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
+          removed |= di;
+        }
+      }
+      if (lane < rows) keep[order[row]] = (uint8_t)((keepbits >> lane) & 1ull);
+      if (lane == 0) *s_keepbits = keepbits;
+    }
+    __syncthreads();
+    const unsigned long long kb = *s_keepbits;
+    // OR the rows of kept boxes into the remaining column words; waves split the kept rows
+    int idx = 0;
+    for (unsigned long long bits = kb; bits; bits &= bits - 1ull, idx++) {
+      if ((idx & 3) != wave) continue;
+      const int i = __builtin_ctzll(bits);
+      const unsigned long long* rowp = mask + (size_t)(c * 64 + i) * col_blocks;
+      for (int j = c + 1 + lane; j < col_blocks; j += 64) {
+        const unsigned long long w = rowp[j];
+        if (w) atomicOr(&s_remv[j], w);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+JDET_API int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, int stride,
+                                  int version, int sort_mode, float* ious, jdet_stream_t stream) {
+  if (n1 < 0 || n2 < 0 || stride < 5 || (version != 0 && version != 1) ||
+      (sort_mode != 0 && sort_mode != 1))
+    return JDET_E_BADARG;
+  if (n1 == 0 || n2 == 0) return JDET_OK;
+  if (!boxes1 || !boxes2 || !ious) return JDET_E_BADARG;
+  const long total = (long)n1 * n2;
+  const int grid = (int)((total + kIouBlock - 1) / kIouBlock > 1048576 ? 1048576
+                                                                       : (total + kIouBlock - 1) / kIouBlock);
+  hipLaunchKernelGGL(box_iou_kernel, dim3(grid), dim3(kIouBlock), 0, (hipStream_t)stream, boxes1, n1,
+                     boxes2, n2, stride, version, sort_mode, ious);
+  return jdet_launch_status();
+}
+
+JDET_API size_t jdet_nms_rotated_workspace(int n) {
+  if (n <= 0) return 0;
+  const size_t col_blocks = ((size_t)n + 63) >> 6;
+  return (size_t)n * col_blocks * sizeof(unsigned long long);
+}
+
+JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
+                              float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,
+                              void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
+  if (n < 0 || (box_len != 5 && box_len != 6) || (sort_mode != 0 && sort_mode != 1)) return JDET_E_BADARG;
+  if (n == 0) return JDET_OK;
+  if (!dets || !order || !keep || !workspace) return JDET_E_BADARG;
+  if (workspace_bytes < jdet_nms_rotated_workspace(n)) return JDET_E_WORKSPACE;
+  const int col_blocks = (n + 63) >> 6;
+  if (col_blocks > kScanMaxWords) return JDET_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* mask = (unsigned long long*)workspace;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
+                     order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask);
+  int e = jdet_launch_status();
+  if (e) return e;
+  const size_t lds = ((size_t)col_blocks + 1) * sizeof(unsigned long long);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanBlock), lds, st, mask, n, order, keep);
+  return jdet_launch_status();
+}

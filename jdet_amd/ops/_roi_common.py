@@ -1,0 +1,68 @@
+"""Shared autograd plumbing of the RoIAlign dialects (device work happens in csrc/roi_align.hip)."""
+import torch
+
+from .. import _lib as L
+
+V_ROT, V_ROT_V1, V_RI, V_HBB0, V_HBB1 = 0, 1, 2, 3, 4
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def to_nhwc(x):
+    """Return a (N,C,H,W)-shaped fp32 tensor whose memory is NHWC (torch.channels_last).
+
+    The kernels read one bilinear tap as one contiguous C-vector, so NHWC is their native layout
+    (DESIGN.md).  A channels_last input (what the conv stack produces) is used as is; an NCHW
+    input is transposed once by jdet_nchw_to_nhwc.
+    """
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.is_contiguous(memory_format=torch.channels_last):
+        return x
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device,
+                    memory_format=torch.channels_last)
+    L.check(L.lib().jdet_nchw_to_nhwc(L.ptr(x), N, C, H, W, L.ptr(y), L.stream_ptr(x)), "jdet_nchw_to_nhwc")
+    return y
+
+
+class RoIAlignFunction(torch.autograd.Function):
+    """forward(input (N,C,H,W), rois (R,6|5)) -> (R,C,PH,PW); grad only w.r.t. input
+    (reference: `return input_grad, None`, roi_align_rotated.py:L308)."""
+
+    @staticmethod
+    def forward(ctx, input, rois, variant, output_size, spatial_scale, sample_num, n_orient):
+        L.need_device(input, rois)
+        cols = 5 if variant in (V_HBB0, V_HBB1) else 6
+        assert rois.dim() == 2 and rois.shape[1] == cols, "rois must be (R,%d)" % cols
+        assert input.dim() == 4
+        PH, PW = output_size
+        feat = to_nhwc(input)
+        rois_c = L.f32c(rois)
+        N, C, H, W = feat.shape
+        R = rois_c.shape[0]
+        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
+        L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                               float(spatial_scale), int(sample_num), int(n_orient),
+                                               L.ptr(out), L.stream_ptr(feat)),
+                "jdet_roi_align_forward")
+        ctx.save_for_backward(rois_c)
+        ctx.cfg = (variant, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (rois_c,) = ctx.saved_tensors
+        variant, (N, C, H, W), PH, PW, scale, sample_num, n_orient = ctx.cfg
+        g = L.f32c(grad_output)
+        R = rois_c.shape[0]
+        grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
+                              memory_format=torch.channels_last)
+        L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
+                                                scale, sample_num, n_orient, L.ptr(grad_in),
+                                                L.stream_ptr(g)),
+                "jdet_roi_align_backward")
+        return grad_in, None, None, None, None, None, None

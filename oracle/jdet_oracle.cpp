@@ -1,0 +1,727 @@
+// jdet_oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference's rotated-box hot path (Jittor/JDet,
+// snapshot 2025-03-10).  It is the *checker* for the HIP kernels in
+// jdet_amd/csrc/: only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load it.  The product path (jdet_amd) never links,
+// imports or falls back to anything in this file.
+//
+// Language: C++ (g++), not plain C, because the reference's CPU IoU path
+// orders hull points with std::sort (python/jdet/ops/box_iou_rotated.py:L316-325)
+// and the libstdc++ ordering is part of what "the Jittor CPU reference" means.
+//
+// Every function follows the float/double mix of the cited reference lines
+// literally (e.g. `1. - ly` is a double subtraction rounded to float), so that
+// it agrees bit-for-bit with the reference kernel text when that text is
+// host-compiled (oracle/build_ref.py -> oracle/_ref/, used by
+// tests/golden/gen_golden.py).  Compile with -ffp-contract=off.
+//
+// Pinning status: pinned against (a) the reference's known-answer literals
+// (box_iou_rotated.py:L513-514, nms_rotated.py:L599-603) and (b) golden vectors
+// produced by the host-compiled reference kernel text (tests/golden/*.npz).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#define JO_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+// RoIAlign family
+//   variant 0: ROIAlignRotated      ops/roi_align_rotated.py:L61-127 / L165-255
+//   variant 1: ROIAlignRotated_v1   ops/roi_align_rotated_v1.py:L71-145 / L193-298
+//   variant 2: RiRoIAlign           ops/riroi_align.py:L70-163 / L228-358
+//   variant 3: ROIAlign (hbb) v0    ops/roi_align.py:L93-204, ROI_ALIGN_VERSION 0
+//   variant 4: ROIAlign (hbb) v1    same, ROI_ALIGN_VERSION 1
+// Feature map NCHW fp32, rois (R,6)=[b,xc,yc,w,h,theta] or (R,5)=[b,x1,y1,x2,y2].
+// ---------------------------------------------------------------------------
+namespace {
+
+enum { V_ROT = 0, V_ROT_V1 = 1, V_RI = 2, V_HBB0 = 3, V_HBB1 = 4 };
+
+// bilinear_interpolate_gradient: roi_align_rotated.py:L128-163 (v1: `<` clamps,
+// roi_align_rotated_v1.py:L161-164).  Returns false when the sample is out of
+// the map (weights 0, indices -1 in the reference).
+inline bool bilinear_setup(int variant, int height, int width, float y, float x,
+                           float& w1, float& w2, float& w3, float& w4,
+                           int& x_low, int& x_high, int& y_low, int& y_high) {
+  if (y < -1.0 || y > height || x < -1.0 || x > width) {
+    w1 = w2 = w3 = w4 = 0.f;
+    x_low = x_high = y_low = y_high = -1;
+    return false;
+  }
+  if (variant == V_ROT_V1) {
+    if (y < 0) y = 0;
+    if (x < 0) x = 0;
+  } else {
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+  }
+  y_low = (int)y;
+  x_low = (int)x;
+  if (y_low >= height - 1) {
+    y_high = y_low = height - 1;
+    y = (float)y_low;
+  } else {
+    y_high = y_low + 1;
+  }
+  if (x_low >= width - 1) {
+    x_high = x_low = width - 1;
+    x = (float)x_low;
+  } else {
+    x_high = x_low + 1;
+  }
+  float ly = y - y_low;
+  float lx = x - x_low;
+  float hy = 1. - ly;  // double subtraction, rounded to float (L49)
+  float hx = 1. - lx;
+  w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  return true;
+}
+
+// bilinear_interpolate: roi_align_rotated.py:L21-59
+inline float bilinear_interp(int variant, const float* data, int height, int width,
+                             float y, float x) {
+  float w1, w2, w3, w4;
+  int xl, xh, yl, yh;
+  if (!bilinear_setup(variant, height, width, y, x, w1, w2, w3, w4, xl, xh, yl, yh)) return 0.f;
+  float lt = data[yl * width + xl];
+  float rt = data[yl * width + xh];
+  float lb = data[yh * width + xl];
+  float rb = data[yh * width + xh];
+  float val = (w1 * lt + w2 * rt + w3 * lb + w4 * rb);
+  return val;
+}
+
+struct RoiGeom {
+  int batch;
+  float center_w, center_h;   // rotated variants
+  float start_w, start_h;     // offset of bin (0,0): -w/2 (rotated) or x1*s (hbb)
+  float bin_h, bin_w;
+  int grid_h, grid_w;
+  float cosT, sinT;
+  float count;
+  // RiRoIAlign
+  float l_var, r_var;
+  int ind;
+};
+
+// Per-RoI scalar prologue shared by forward and backward.  `sample_num` is the
+// int the kernel receives (the python wrapper passes a float literal that C++
+// truncates: roi_align_rotated.py:L271,L280).
+inline RoiGeom roi_geom(int variant, const float* roi, float spatial_scale, int sample_num,
+                        int pooled_h, int pooled_w, int nOrientation, bool backward) {
+  RoiGeom g;
+  g.batch = (int)roi[0];
+  g.l_var = 0.f; g.r_var = 1.f; g.ind = 0;
+  float roi_width, roi_height;
+  if (variant == V_HBB0 || variant == V_HBB1) {
+    // roi_align.py:L105-117
+    float roi_start_w = roi[1] * spatial_scale;
+    float roi_start_h = roi[2] * spatial_scale;
+    if (variant == V_HBB1) {
+      float roi_end_w = (roi[3] + 1) * spatial_scale;
+      float roi_end_h = (roi[4] + 1) * spatial_scale;
+      roi_width = fmaxf(roi_end_w - roi_start_w, 0.);
+      roi_height = fmaxf(roi_end_h - roi_start_h, 0.);
+    } else {
+      float roi_end_w = roi[3] * spatial_scale;
+      float roi_end_h = roi[4] * spatial_scale;
+      roi_width = fmaxf(roi_end_w - roi_start_w, 1.);
+      roi_height = fmaxf(roi_end_h - roi_start_h, 1.);
+    }
+    g.start_w = roi_start_w;
+    g.start_h = roi_start_h;
+    g.center_w = g.center_h = 0.f;
+    g.cosT = 1.f; g.sinT = 0.f;
+  } else {
+    // roi_align_rotated.py:L77-85 ; v1 L89-90 subtracts 0.5
+    g.center_w = roi[1] * spatial_scale;
+    g.center_h = roi[2] * spatial_scale;
+    if (variant == V_ROT_V1) {
+      g.center_w = roi[1] * spatial_scale - (float)0.5;
+      g.center_h = roi[2] * spatial_scale - (float)0.5;
+    }
+    roi_width = roi[3] * spatial_scale;
+    roi_height = roi[4] * spatial_scale;
+    float theta = roi[5];
+    roi_width = std::max(roi_width, (float)1.);
+    roi_height = std::max(roi_height, (float)1.);
+    g.start_h = -roi_height / 2.0;  // L99-100
+    g.start_w = -roi_width / 2.0;
+    // host-compiled `cos(theta)` on a float resolves to the double overload
+    // (global ::cos), the CUDA build to cosf; both round to float here.
+    g.cosT = (float)cos((double)theta);
+    g.sinT = (float)sin((double)theta);
+    if (variant == V_RI) {
+      // riroi_align.py:L105-113 ; PI literal L8
+      float ind_float = theta * nOrientation / (2 * 3.141592653);
+      int ind = (int)floor(ind_float);
+      g.l_var = ind_float - (float)ind;
+      g.r_var = 1.0 - g.l_var;
+      g.ind = (ind + nOrientation) % nOrientation;
+    }
+  }
+  g.bin_h = (float)roi_height / (float)pooled_h;
+  g.bin_w = (float)roi_width / (float)pooled_w;
+  g.grid_h = (sample_num > 0) ? sample_num : (int)ceil(roi_height / pooled_h);
+  g.grid_w = (sample_num > 0) ? sample_num : (int)ceil(roi_width / pooled_w);
+  int cnt = g.grid_h * g.grid_w;
+  // v1 forward clamps count to >= 1 (v1 L120); v1 backward does not (v1 L246)
+  if (variant == V_ROT_V1 && !backward) cnt = std::max(cnt, 1);
+  g.count = (float)cnt;
+  return g;
+}
+
+// sample position for (ph,pw,iy,ix): roi_align_rotated.py:L106-118 (v1 L133-134;
+// hbb roi_align.py:L129-132)
+inline void sample_xy(int variant, const RoiGeom& g, int ph, int pw, int iy, int ix,
+                      float& x, float& y) {
+  const float yy = g.start_h + ph * g.bin_h +
+                   static_cast<float>(iy + .5f) * g.bin_h / static_cast<float>(g.grid_h);
+  const float xx = g.start_w + pw * g.bin_w +
+                   static_cast<float>(ix + .5f) * g.bin_w / static_cast<float>(g.grid_w);
+  if (variant == V_HBB0 || variant == V_HBB1) {
+    x = xx; y = yy;
+  } else if (variant == V_ROT_V1) {
+    x = xx * g.cosT + yy * g.sinT + g.center_w;
+    y = yy * g.cosT - xx * g.sinT + g.center_h;
+  } else {
+    x = xx * g.cosT - yy * g.sinT + g.center_w;
+    y = xx * g.sinT + yy * g.cosT + g.center_h;
+  }
+}
+
+}  // namespace
+
+// out: (R, C*nO, PH, PW).  For variants != RI pass nOrientation = 1.
+// `channels` is the per-orientation channel count (C), so the map has C*nO planes.
+JO_API void jo_roi_align_forward(int variant, const float* feat, int N, int channels, int H, int W,
+                                 const float* rois, int R, int PH, int PW, float spatial_scale,
+                                 int sample_num, int nOrientation, float* out) {
+  (void)N;
+  const int roi_cols = (variant == V_HBB0 || variant == V_HBB1) ? 5 : 6;
+  const int nO = (variant == V_RI) ? nOrientation : 1;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int n = 0; n < R; n++) {
+    const RoiGeom g = roi_geom(variant, rois + (size_t)n * roi_cols, spatial_scale, sample_num,
+                               PH, PW, nO, false);
+    for (int c = 0; c < channels; c++)
+      for (int o = 0; o < nO; o++) {
+        int ind_rot = (o - g.ind + nO) % nO;
+        int ind_rot_plus = (ind_rot + 1 + nO) % nO;
+        const float* d0 = feat + ((size_t)(g.batch * channels * nO + c * nO + ind_rot)) * H * W;
+        const float* d1 = feat + ((size_t)(g.batch * channels * nO + c * nO + ind_rot_plus)) * H * W;
+        for (int ph = 0; ph < PH; ph++)
+          for (int pw = 0; pw < PW; pw++) {
+            float output_val = 0.;
+            for (int iy = 0; iy < g.grid_h; iy++)
+              for (int ix = 0; ix < g.grid_w; ix++) {
+                float x, y;
+                sample_xy(variant, g, ph, pw, iy, ix, x, y);
+                float val = bilinear_interp(variant, d0, H, W, y, x);
+                if (variant == V_RI) {
+                  float val_plus = bilinear_interp(variant, d1, H, W, y, x);
+                  output_val += g.r_var * val + g.l_var * val_plus;  // riroi L158
+                } else {
+                  output_val += val;
+                }
+              }
+            output_val /= g.count;
+            out[(((size_t)n * channels * nO + c * nO + o) * PH + ph) * PW + pw] = output_val;
+          }
+      }
+  }
+}
+
+// grad_in: (N, C*nO, H, W), zero-filled here (reference: cudaMemsetAsync L302).
+// Serial accumulation in index order n,c,o,ph,pw,iy,ix (the reference's atomics
+// have no defined order; comparisons against this use an fp32 tolerance).
+JO_API void jo_roi_align_backward(int variant, const float* grad_out, int N, int channels, int H,
+                                  int W, const float* rois, int R, int PH, int PW,
+                                  float spatial_scale, int sample_num, int nOrientation,
+                                  float* grad_in) {
+  const int roi_cols = (variant == V_HBB0 || variant == V_HBB1) ? 5 : 6;
+  const int nO = (variant == V_RI) ? nOrientation : 1;
+  memset(grad_in, 0, sizeof(float) * (size_t)N * channels * nO * H * W);
+  for (int n = 0; n < R; n++) {
+    const RoiGeom g = roi_geom(variant, rois + (size_t)n * roi_cols, spatial_scale, sample_num,
+                               PH, PW, nO, true);
+    for (int c = 0; c < channels; c++)
+      for (int o = 0; o < nO; o++) {
+        int ind_rot = (o - g.ind + nO) % nO;
+        int ind_rot_plus = (ind_rot + 1 + nO) % nO;
+        float* d0 = grad_in + ((size_t)(g.batch * channels * nO + c * nO + ind_rot)) * H * W;
+        float* d1 = grad_in + ((size_t)(g.batch * channels * nO + c * nO + ind_rot_plus)) * H * W;
+        for (int ph = 0; ph < PH; ph++)
+          for (int pw = 0; pw < PW; pw++) {
+            const float top =
+                grad_out[(((size_t)n * channels * nO + c * nO + o) * PH + ph) * PW + pw];
+            for (int iy = 0; iy < g.grid_h; iy++)
+              for (int ix = 0; ix < g.grid_w; ix++) {
+                float x, y;
+                sample_xy(variant, g, ph, pw, iy, ix, x, y);
+                float w1, w2, w3, w4;
+                int xl, xh, yl, yh;
+                bilinear_setup(variant, H, W, y, x, w1, w2, w3, w4, xl, xh, yl, yh);
+                float g1 = top * w1 / g.count;
+                float g2 = top * w2 / g.count;
+                float g3 = top * w3 / g.count;
+                float g4 = top * w4 / g.count;
+                if (xl >= 0 && xh >= 0 && yl >= 0 && yh >= 0) {
+                  if (variant == V_RI) {  // riroi L337-353
+                    d0[yl * W + xl] += g1 * g.r_var;
+                    d0[yl * W + xh] += g2 * g.r_var;
+                    d0[yh * W + xl] += g3 * g.r_var;
+                    d0[yh * W + xh] += g4 * g.r_var;
+                    d1[yl * W + xl] += g1 * g.l_var;
+                    d1[yl * W + xh] += g2 * g.l_var;
+                    d1[yh * W + xl] += g3 * g.l_var;
+                    d1[yh * W + xh] += g4 * g.l_var;
+                  } else {
+                    d0[yl * W + xl] += g1;
+                    d0[yl * W + xh] += g2;
+                    d0[yh * W + xl] += g3;
+                    d0[yh * W + xh] += g4;
+                  }
+                }
+              }
+          }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Rotated IoU  (ops/box_iou_rotated.py:L13-310, CPU header L312-326;
+//               _v1 vertex convention ops/box_iou_rotated_v1.py:L69-76)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Pt {
+  float x, y;
+  Pt(float px = 0, float py = 0) : x(px), y(py) {}
+  Pt operator+(const Pt& p) const { return Pt(x + p.x, y + p.y); }
+  Pt& operator+=(const Pt& p) { x += p.x; y += p.y; return *this; }
+  Pt operator-(const Pt& p) const { return Pt(x - p.x, y - p.y); }
+  Pt operator*(const float c) const { return Pt(x * c, y * c); }
+};
+inline float dot_2d(const Pt& A, const Pt& B) { return A.x * B.x + A.y * B.y; }
+inline float cross_2d(const Pt& A, const Pt& B) { return A.x * B.y - B.x * A.y; }
+
+struct RBox { float x_ctr, y_ctr, w, h, a; };
+
+// L52-72 (v0) ; v1 L69-76
+inline void rotated_vertices(int v1, const RBox& box, Pt (&pts)[4]) {
+  double theta = box.a;
+  float cosTheta2 = (float)cos(theta) * 0.5f;
+  float sinTheta2 = (float)sin(theta) * 0.5f;
+  if (!v1) {
+    pts[0].x = box.x_ctr - sinTheta2 * box.h - cosTheta2 * box.w;
+    pts[0].y = box.y_ctr + cosTheta2 * box.h - sinTheta2 * box.w;
+    pts[1].x = box.x_ctr + sinTheta2 * box.h - cosTheta2 * box.w;
+    pts[1].y = box.y_ctr - cosTheta2 * box.h - sinTheta2 * box.w;
+  } else {
+    pts[0].x = box.x_ctr + sinTheta2 * box.h + cosTheta2 * box.w;
+    pts[0].y = box.y_ctr + cosTheta2 * box.h - sinTheta2 * box.w;
+    pts[1].x = box.x_ctr - sinTheta2 * box.h + cosTheta2 * box.w;
+    pts[1].y = box.y_ctr - cosTheta2 * box.h - sinTheta2 * box.w;
+  }
+  pts[2].x = 2 * box.x_ctr - pts[0].x;
+  pts[2].y = 2 * box.y_ctr - pts[0].y;
+  pts[3].x = 2 * box.x_ctr - pts[1].x;
+  pts[3].y = 2 * box.y_ctr - pts[1].y;
+}
+
+// L74-153
+inline int intersection_points(const Pt (&pts1)[4], const Pt (&pts2)[4], Pt (&inter)[24]) {
+  Pt vec1[4], vec2[4];
+  for (int i = 0; i < 4; i++) {
+    vec1[i] = pts1[(i + 1) % 4] - pts1[i];
+    vec2[i] = pts2[(i + 1) % 4] - pts2[i];
+  }
+  int num = 0;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float det = cross_2d(vec2[j], vec1[i]);
+      if (fabs(det) <= 1e-14) continue;
+      Pt vec12 = pts2[j] - pts1[i];
+      float t1 = cross_2d(vec2[j], vec12) / det;
+      float t2 = cross_2d(vec1[i], vec12) / det;
+      if (t1 >= 0.0f && t1 <= 1.0f && t2 >= 0.0f && t2 <= 1.0f)
+        inter[num++] = pts1[i] + vec1[i] * t1;
+    }
+  {
+    const Pt& AB = vec2[0];
+    const Pt& DA = vec2[3];
+    float ABdotAB = dot_2d(AB, AB), ADdotAD = dot_2d(DA, DA);
+    for (int i = 0; i < 4; i++) {
+      Pt AP = pts1[i] - pts2[0];
+      float APdotAB = dot_2d(AP, AB);
+      float APdotAD = -dot_2d(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        inter[num++] = pts1[i];
+    }
+  }
+  {
+    const Pt& AB = vec1[0];
+    const Pt& DA = vec1[3];
+    float ABdotAB = dot_2d(AB, AB), ADdotAD = dot_2d(DA, DA);
+    for (int i = 0; i < 4; i++) {
+      Pt AP = pts2[i] - pts1[0];
+      float APdotAB = dot_2d(AP, AB);
+      float APdotAD = -dot_2d(AP, DA);
+      if ((APdotAB >= 0) && (APdotAD >= 0) && (APdotAB <= ABdotAB) && (APdotAD <= ADdotAD))
+        inter[num++] = pts2[i];
+    }
+  }
+  return num;
+}
+
+// L155-238 with the CPU sort L316-325 (sort_mode 0) or the CUDA exchange sort
+// L338-351 (sort_mode 1).  shift_to_zero is always true at the single call site
+// (L275).
+inline int convex_hull_graham(const Pt (&p)[24], int num_in, Pt (&q)[24], int sort_mode) {
+  int t = 0;
+  for (int i = 1; i < num_in; i++)
+    if (p[i].y < p[t].y || (p[i].y == p[t].y && p[i].x < p[t].x)) t = i;
+  const Pt start = p[t];
+  for (int i = 0; i < num_in; i++) q[i] = p[i] - start;
+  Pt tmp = q[0];
+  q[0] = q[t];
+  q[t] = tmp;
+  float dist[24];
+  for (int i = 0; i < num_in; i++) dist[i] = dot_2d(q[i], q[i]);
+  if (sort_mode == 0) {
+    std::sort(q + 1, q + num_in, [](const Pt& A, const Pt& B) -> bool {
+      float temp = cross_2d(A, B);
+      if (fabs(temp) < 1e-6) {
+        return dot_2d(A, A) < dot_2d(B, B);
+      } else {
+        return temp > 0;
+      }
+    });
+    // NOTE (reference quirk, L190-203): `dist` is filled BEFORE the sort and is
+    // not permuted by std::sort, so Step 4 below reads pre-sort distances.
+  } else {
+    for (int i = 1; i < num_in - 1; i++)
+      for (int j = i + 1; j < num_in; j++) {
+        float crossProduct = cross_2d(q[i], q[j]);
+        if ((crossProduct < -1e-6) || (fabs(crossProduct) < 1e-6 && dist[i] > dist[j])) {
+          Pt q_tmp = q[i]; q[i] = q[j]; q[j] = q_tmp;
+          float d_tmp = dist[i]; dist[i] = dist[j]; dist[j] = d_tmp;
+        }
+      }
+  }
+  int k;
+  for (k = 1; k < num_in; k++)
+    if (dist[k] > 1e-8) break;
+  if (k == num_in) {
+    q[0] = p[t];
+    return 1;
+  }
+  q[1] = q[k];
+  int m = 2;
+  for (int i = k + 1; i < num_in; i++) {
+    while (m > 1 && cross_2d(q[i] - q[m - 2], q[m - 1] - q[m - 2]) >= 0) m--;
+    q[m++] = q[i];
+  }
+  return m;
+}
+
+// L240-252
+inline float polygon_area(const Pt (&q)[24], int m) {
+  if (m <= 2) return 0;
+  float area = 0;
+  for (int i = 1; i < m - 1; i++) area += fabs(cross_2d(q[i] - q[0], q[i + 1] - q[0]));
+  return area / 2.0;
+}
+
+// L254-310 ; nms_rotated.py:L281-310 adds the label test for BOX_LENGTH 6
+inline float single_box_iou_rotated(const float* b1, const float* b2, int v1, int sort_mode,
+                                    int box_len) {
+  if (box_len == 6 && b1[5] != b2[5]) return 0.0;
+  RBox box1, box2;
+  auto center_shift_x = (b1[0] + b2[0]) / 2.0;  // float add, double divide
+  auto center_shift_y = (b1[1] + b2[1]) / 2.0;
+  box1.x_ctr = b1[0] - center_shift_x;
+  box1.y_ctr = b1[1] - center_shift_y;
+  box1.w = b1[2]; box1.h = b1[3]; box1.a = b1[4];
+  box2.x_ctr = b2[0] - center_shift_x;
+  box2.y_ctr = b2[1] - center_shift_y;
+  box2.w = b2[2]; box2.h = b2[3]; box2.a = b2[4];
+  const float area1 = box1.w * box1.h;
+  const float area2 = box2.w * box2.h;
+  if (area1 < 1e-14 || area2 < 1e-14) return 0.f;
+  Pt inter[24], ordered[24];
+  Pt pts1[4], pts2[4];
+  rotated_vertices(v1, box1, pts1);
+  rotated_vertices(v1, box2, pts2);
+  int num = intersection_points(pts1, pts2, inter);
+  if (num <= 2) return 0.0;
+  int num_convex = convex_hull_graham(inter, num, ordered, sort_mode);
+  const float intersection = polygon_area(ordered, num_convex);
+  const float iou = intersection / (area1 + area2 - intersection);
+  return iou;
+}
+
+}  // namespace
+
+// ious (N,M) row-major.  version 0 = box_iou_rotated, 1 = box_iou_rotated_v1
+// (without the python-side too-small post-processing, v1 L515-523, which the
+// host wrapper applies).  sort_mode 0 = CPU std::sort, 1 = CUDA exchange sort.
+JO_API void jo_box_iou_rotated(const float* b1, int n1, const float* b2, int n2, int stride,
+                               int version, int sort_mode, float* ious) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n1; i++)
+    for (int j = 0; j < n2; j++)
+      ious[(size_t)i * n2 + j] =
+          single_box_iou_rotated(b1 + (size_t)i * stride, b2 + (size_t)j * stride, version,
+                                 sort_mode, 5);
+}
+
+// Greedy NMS, ops/nms_rotated.py:L414-449 (CPU source).  dets (n, box_len),
+// order = indices by descending score.  cmp_ge 1 = CPU rule `ovr >= thr` (L444),
+// 0 = CUDA rule `> thr` (L403).  keep: n bytes (bool over ORIGINAL indices).
+JO_API void jo_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
+                           float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep) {
+  std::vector<uint8_t> suppressed(n, 0);
+  memset(keep, 0, n);
+  for (int _i = 0; _i < n; _i++) {
+    int i = order[_i];
+    if (suppressed[i] == 1) continue;
+    keep[i] = 1;
+    for (int _j = _i + 1; _j < n; _j++) {
+      int j = order[_j];
+      if (suppressed[j] == 1) continue;
+      float ovr = single_box_iou_rotated(dets + (size_t)i * box_len, dets + (size_t)j * box_len, 0,
+                                         sort_mode, box_len);
+      if (cmp_ge ? (ovr >= iou_threshold) : (ovr > iou_threshold)) suppressed[j] = 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Deformable conv v1 sampling (ops/dcn_v1.py:L25-306)
+// ---------------------------------------------------------------------------
+namespace {
+
+// L25-56
+inline float dcn_bilinear(const float* data, int data_width, int height, int width, float h,
+                          float w) {
+  int h_low = (int)floor(h);
+  int w_low = (int)floor(w);
+  int h_high = h_low + 1;
+  int w_high = w_low + 1;
+  float lh = h - h_low;
+  float lw = w - w_low;
+  float hh = 1 - lh, hw = 1 - lw;
+  float v1 = 0;
+  if (h_low >= 0 && w_low >= 0) v1 = data[h_low * data_width + w_low];
+  float v2 = 0;
+  if (h_low >= 0 && w_high <= width - 1) v2 = data[h_low * data_width + w_high];
+  float v3 = 0;
+  if (h_high <= height - 1 && w_low >= 0) v3 = data[h_high * data_width + w_low];
+  float v4 = 0;
+  if (h_high <= height - 1 && w_high <= width - 1) v4 = data[h_high * data_width + w_high];
+  float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+  float val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+  return val;
+}
+
+// L58-85
+inline float dcn_gradient_weight(float argmax_h, float argmax_w, int h, int w, int height,
+                                 int width) {
+  if (argmax_h <= -1 || argmax_h >= height || argmax_w <= -1 || argmax_w >= width) return 0;
+  int argmax_h_low = (int)floor(argmax_h);
+  int argmax_w_low = (int)floor(argmax_w);
+  int argmax_h_high = argmax_h_low + 1;
+  int argmax_w_high = argmax_w_low + 1;
+  float weight = 0;
+  if (h == argmax_h_low && w == argmax_w_low) weight = (h + 1 - argmax_h) * (w + 1 - argmax_w);
+  if (h == argmax_h_low && w == argmax_w_high) weight = (h + 1 - argmax_h) * (argmax_w + 1 - w);
+  if (h == argmax_h_high && w == argmax_w_low) weight = (argmax_h + 1 - h) * (w + 1 - argmax_w);
+  if (h == argmax_h_high && w == argmax_w_high) weight = (argmax_h + 1 - h) * (argmax_w + 1 - w);
+  return weight;
+}
+
+// L87-128
+inline float dcn_coordinate_weight(float argmax_h, float argmax_w, int height, int width,
+                                   const float* im, int data_width, int bp_dir) {
+  if (argmax_h <= -1 || argmax_h >= height || argmax_w <= -1 || argmax_w >= width) return 0;
+  int hl = (int)floor(argmax_h);
+  int wl = (int)floor(argmax_w);
+  int hh = hl + 1;
+  int wh = wl + 1;
+  float weight = 0;
+  if (bp_dir == 0) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (wl + 1 - argmax_w) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += -1 * (argmax_w - wl) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += (wl + 1 - argmax_w) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_w - wl) * im[hh * data_width + wh];
+  } else if (bp_dir == 1) {
+    if (hl >= 0 && wl >= 0) weight += -1 * (hl + 1 - argmax_h) * im[hl * data_width + wl];
+    if (hl >= 0 && wh <= width - 1) weight += (hl + 1 - argmax_h) * im[hl * data_width + wh];
+    if (hh <= height - 1 && wl >= 0) weight += -1 * (argmax_h - hl) * im[hh * data_width + wl];
+    if (hh <= height - 1 && wh <= width - 1) weight += (argmax_h - hl) * im[hh * data_width + wh];
+  }
+  return weight;
+}
+
+}  // namespace
+
+// deformable_im2col_gpu_kernel L130-184.  im (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo);
+// col (C*kh*kw, B, Ho, Wo).
+JO_API void jo_deform_im2col(const float* im, const float* offset, int B, int C, int H, int W,
+                             int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                             int dil_h, int dil_w, int dg, float* col) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int cpg = C / dg;
+#pragma omp parallel for schedule(static)
+  for (int c_im = 0; c_im < C; c_im++)
+    for (int b = 0; b < B; b++)
+      for (int h_col = 0; h_col < Ho; h_col++)
+        for (int w_col = 0; w_col < Wo; w_col++) {
+          const int g = c_im / cpg;
+          const int h_in = h_col * stride_h - pad_h;
+          const int w_in = w_col * stride_w - pad_w;
+          const float* im_ptr = im + ((size_t)b * C + c_im) * H * W;
+          const float* off_ptr = offset + ((size_t)b * dg + g) * 2 * kh * kw * Ho * Wo;
+          for (int i = 0; i < kh; ++i)
+            for (int j = 0; j < kw; ++j) {
+              const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_col) * Wo + w_col];
+              const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_col) * Wo + w_col];
+              float val = 0.f;
+              const float h_im = h_in + i * dil_h + offset_h;
+              const float w_im = w_in + j * dil_w + offset_w;
+              if (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+                val = dcn_bilinear(im_ptr, W, H, W, h_im, w_im);
+              col[((((size_t)c_im * kh * kw + i * kw + j) * B + b) * Ho + h_col) * Wo + w_col] = val;
+            }
+        }
+}
+
+// deformable_col2im_gpu_kernel L185-241: grad_im (B,C,H,W) zero-filled here.
+JO_API void jo_deform_col2im(const float* col, const float* offset, int B, int C, int H, int W,
+                             int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                             int dil_h, int dil_w, int dg, float* grad_im) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int cpg = C / dg;
+  memset(grad_im, 0, sizeof(float) * (size_t)B * C * H * W);
+  const long n = (long)C * kh * kw * Ho * Wo * B;
+  for (long index = 0; index < n; index++) {
+    const int j = (index / Wo / Ho / B) % kw;
+    const int i = (index / Wo / Ho / B / kw) % kh;
+    const int c = index / Wo / Ho / B / kw / kh;
+    const int g = c / cpg;
+    int w_out = index % Wo;
+    int h_out = (index / Wo) % Ho;
+    int b = (index / Wo / Ho) % B;
+    int w_in = w_out * stride_w - pad_w;
+    int h_in = h_out * stride_h - pad_h;
+    const float* off_ptr = offset + ((size_t)b * dg + g) * 2 * kh * kw * Ho * Wo;
+    const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_out) * Wo + w_out];
+    const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_out) * Wo + w_out];
+    const float cur_inv_h = h_in + i * dil_h + offset_h;
+    const float cur_inv_w = w_in + j * dil_w + offset_w;
+    const float cur_top_grad = col[index];
+    const int cur_h = (int)cur_inv_h;
+    const int cur_w = (int)cur_inv_w;
+    for (int dy = -2; dy <= 2; dy++)
+      for (int dx = -2; dx <= 2; dx++)
+        if (cur_h + dy >= 0 && cur_h + dy < H && cur_w + dx >= 0 && cur_w + dx < W &&
+            fabsf(cur_inv_h - (cur_h + dy)) < 1 && fabsf(cur_inv_w - (cur_w + dx)) < 1) {
+          size_t pos = (((size_t)b * C + c) * H + cur_h + dy) * W + cur_w + dx;
+          float weight = dcn_gradient_weight(cur_inv_h, cur_inv_w, cur_h + dy, cur_w + dx, H, W);
+          grad_im[pos] += weight * cur_top_grad;
+        }
+  }
+}
+
+// deformable_col2im_coord_gpu_kernel L243-306: grad_offset (B, dg*2*kh*kw, Ho, Wo).
+JO_API void jo_deform_col2im_coord(const float* col, const float* im, const float* offset, int B,
+                                   int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                   int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                                   float* grad_offset) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int cpg = C * kh * kw / dg;  // channel_per_deformable_group (col channels)
+  const int offset_channels = 2 * kh * kw * dg;
+  const long n = (long)Ho * Wo * offset_channels * B;
+#pragma omp parallel for schedule(static)
+  for (long index = 0; index < n; index++) {
+    float val = 0;
+    int w = index % Wo;
+    int h = (index / Wo) % Ho;
+    int c = (index / Wo / Ho) % offset_channels;
+    int b = (index / Wo / Ho) / offset_channels;
+    const int g = c / (2 * kh * kw);
+    const int col_step = kh * kw;
+    int cnt = 0;
+    const float* col_ptr = col + (size_t)g * cpg * B * Wo * Ho;
+    const float* im_ptr = im + ((size_t)b * dg + g) * cpg / kh / kw * H * W;
+    const float* off_ptr = offset + ((size_t)b * dg + g) * 2 * kh * kw * Ho * Wo;
+    const int offset_c = c - g * 2 * kh * kw;
+    for (int col_c = (offset_c / 2); col_c < cpg; col_c += col_step) {
+      const long col_pos = ((((long)col_c * B + b) * Ho) + h) * Wo + w;
+      const int bp_dir = offset_c % 2;
+      int j = (col_pos / Wo / Ho / B) % kw;
+      int i = (col_pos / Wo / Ho / B / kw) % kh;
+      int w_out = col_pos % Wo;
+      int h_out = (col_pos / Wo) % Ho;
+      int w_in = w_out * stride_w - pad_w;
+      int h_in = h_out * stride_h - pad_h;
+      const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_out) * Wo + w_out];
+      const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_out) * Wo + w_out];
+      float inv_h = h_in + i * dil_h + offset_h;
+      float inv_w = w_in + j * dil_w + offset_w;
+      if (inv_h <= -1 || inv_w <= -1 || inv_h >= H || inv_w >= W) inv_h = inv_w = -2;
+      const float weight =
+          dcn_coordinate_weight(inv_h, inv_w, H, W, im_ptr + (size_t)cnt * H * W, W, bp_dir);
+      val += weight * col_ptr[col_pos];
+      cnt += 1;
+    }
+    grad_offset[index] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Active rotating filter (ops/orn.py:L138-211 CPU kernels)
+//   weight (nOut, nIn, nOri, kH, kW) ; indices (nOri, kH, kW, nRot) uint8, 1-based
+//   output (nOut*nRot, nIn*nOri, kH, kW)
+// ---------------------------------------------------------------------------
+JO_API void jo_arf_forward(const float* weight, const uint8_t* indices, int nOut, int nIn,
+                           int nOri, int kH, int kW, int nRot, float* out) {
+  const int nEntry = nOri * kH * kW;
+  for (int i = 0; i < nOut; i++)
+    for (int j = 0; j < nIn; j++)
+      for (int l = 0; l < nEntry; l++) {
+        float val = weight[((size_t)i * nIn + j) * nEntry + l];
+        for (int k = 0; k < nRot; k++) {
+          int index = (int)indices[l * nRot + k] - 1;
+          out[(size_t)i * (nRot * nIn * nEntry) + (size_t)k * (nIn * nEntry) + j * nEntry + index] =
+              val;
+        }
+      }
+}
+
+JO_API void jo_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn,
+                            int nOri, int kH, int kW, int nRot, float* grad_w) {
+  const int nEntry = nOri * kH * kW;
+  for (int i = 0; i < nOut; i++)
+    for (int j = 0; j < nIn; j++)
+      for (int l = 0; l < nEntry; l++) {
+        float* val = grad_w + ((size_t)i * nIn + j) * nEntry + l;
+        *val = 0;
+        for (int k = 0; k < nRot; k++) {
+          int index = (int)indices[l * nRot + k] - 1;
+          *val = *val + grad_out[(size_t)i * (nRot * nIn * nEntry) + (size_t)k * (nIn * nEntry) +
+                                 j * nEntry + index];
+        }
+      }
+}
+
+JO_API int jo_version(void) { return 1; }

@@ -1,0 +1,256 @@
+"""ctypes bindings for the CPU oracle (oracle/libjdet_oracle.so) and, when present, the
+host-compiled reference kernel text (oracle/_ref/libjdet_ref.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by jdet_amd.
+
+All functions take / return numpy arrays (float32 unless noted).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(_HERE, "libjdet_oracle.so")
+_REF_SO = os.path.join(_HERE, "_ref", "libjdet_ref.so")
+
+V_ROT, V_ROT_V1, V_RI, V_HBB0, V_HBB1 = 0, 1, 2, 3, 4
+
+_f = ctypes.c_float
+_i = ctypes.c_int
+_p = ctypes.c_void_p
+
+
+def build_oracle(force=False):
+    src = os.path.join(_HERE, "jdet_oracle.cpp")
+    if force or not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libjdet_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _ORACLE_SO
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        _lib = ctypes.CDLL(_ORACLE_SO)
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(_REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        if not have_ref():
+            raise RuntimeError("oracle/_ref/libjdet_ref.so missing: run `python oracle/build_ref.py` "
+                               "(needs /root/reference)")
+        _ref = ctypes.CDLL(_REF_SO)
+    return _ref
+
+
+def _c(a, dt=np.float32):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def set_threads(n):
+    os.environ["OMP_NUM_THREADS"] = str(n)
+
+
+# ------------------------------------------------------------------ oracle (own restatement)
+def roi_align_forward(variant, feat, rois, out_hw, spatial_scale, sample_num, n_orient=1):
+    feat, rois = _c(feat), _c(rois)
+    N, Ct, H, W = feat.shape
+    nO = n_orient if variant == V_RI else 1
+    C = Ct // nO
+    R = rois.shape[0]
+    PH, PW = out_hw
+    out = np.empty((R, Ct, PH, PW), np.float32)
+    lib().jo_roi_align_forward(_i(variant), _ptr(feat), _i(N), _i(C), _i(H), _i(W), _ptr(rois), _i(R),
+                               _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)), _i(nO), _ptr(out))
+    return out
+
+
+def roi_align_backward(variant, grad_out, rois, feat_shape, spatial_scale, sample_num, n_orient=1):
+    grad_out, rois = _c(grad_out), _c(rois)
+    N, Ct, H, W = feat_shape
+    nO = n_orient if variant == V_RI else 1
+    C = Ct // nO
+    R, _, PH, PW = grad_out.shape
+    gin = np.empty((N, Ct, H, W), np.float32)
+    lib().jo_roi_align_backward(_i(variant), _ptr(grad_out), _i(N), _i(C), _i(H), _i(W), _ptr(rois), _i(R),
+                                _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)), _i(nO), _ptr(gin))
+    return gin
+
+
+def box_iou_rotated(b1, b2, version=0, sort_mode=0):
+    b1, b2 = _c(b1), _c(b2)
+    n1, n2 = b1.shape[0], b2.shape[0]
+    out = np.zeros((n1, n2), np.float32)
+    if n1 and n2:
+        lib().jo_box_iou_rotated(_ptr(b1), _i(n1), _ptr(b2), _i(n2), _i(b1.shape[1]), _i(version),
+                                 _i(sort_mode), _ptr(out))
+    return out
+
+
+def nms_rotated_keep(dets, order, thr, cmp_ge=1, sort_mode=0):
+    """dets (n, 5|6); order int32 (descending score).  Returns bool keep mask over original indices."""
+    dets, order = _c(dets), _c(order, np.int32)
+    n, bl = dets.shape
+    keep = np.zeros((n,), np.uint8)
+    if n:
+        lib().jo_nms_rotated(_ptr(dets), _i(n), _i(bl), _ptr(order), _f(thr), _i(cmp_ge), _i(sort_mode),
+                             _ptr(keep))
+    return keep.astype(bool)
+
+
+def _dcn_out(H, W, kh, kw, pad, stride, dil):
+    Ho = (H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1
+    return Ho, Wo
+
+
+def deform_im2col(im, offset, kh, kw, pad, stride, dil, dg, _l=None, _name="jo_deform_im2col"):
+    im, offset = _c(im), _c(offset)
+    B, C, H, W = im.shape
+    Ho, Wo = _dcn_out(H, W, kh, kw, pad, stride, dil)
+    col = np.zeros((C * kh * kw, B, Ho, Wo), np.float32)
+    getattr(_l or lib(), _name)(_ptr(im), _ptr(offset), _i(B), _i(C), _i(H), _i(W), _i(kh), _i(kw),
+                                _i(pad[0]), _i(pad[1]), _i(stride[0]), _i(stride[1]), _i(dil[0]),
+                                _i(dil[1]), _i(dg), _ptr(col))
+    return col
+
+
+def deform_col2im(col, offset, im_shape, kh, kw, pad, stride, dil, dg, _l=None, _name="jo_deform_col2im"):
+    col, offset = _c(col), _c(offset)
+    B, C, H, W = im_shape
+    gim = np.zeros((B, C, H, W), np.float32)
+    getattr(_l or lib(), _name)(_ptr(col), _ptr(offset), _i(B), _i(C), _i(H), _i(W), _i(kh), _i(kw),
+                                _i(pad[0]), _i(pad[1]), _i(stride[0]), _i(stride[1]), _i(dil[0]),
+                                _i(dil[1]), _i(dg), _ptr(gim))
+    return gim
+
+
+def deform_col2im_coord(col, im, offset, kh, kw, pad, stride, dil, dg, _l=None,
+                        _name="jo_deform_col2im_coord"):
+    col, im, offset = _c(col), _c(im), _c(offset)
+    B, C, H, W = im.shape
+    goff = np.zeros(offset.shape, np.float32)
+    getattr(_l or lib(), _name)(_ptr(col), _ptr(im), _ptr(offset), _i(B), _i(C), _i(H), _i(W), _i(kh),
+                                _i(kw), _i(pad[0]), _i(pad[1]), _i(stride[0]), _i(stride[1]), _i(dil[0]),
+                                _i(dil[1]), _i(dg), _ptr(goff))
+    return goff
+
+
+def arf_forward(weight, indices, _l=None, _name="jo_arf_forward"):
+    weight, indices = _c(weight), _c(indices, np.uint8)
+    nOut, nIn, nOri, kH, kW = weight.shape
+    nRot = indices.shape[3]
+    out = np.zeros((nOut * nRot, nIn * nOri, kH, kW), np.float32)
+    getattr(_l or lib(), _name)(_ptr(weight), _ptr(indices), _i(nOut), _i(nIn), _i(nOri), _i(kH), _i(kW),
+                                _i(nRot), _ptr(out))
+    return out
+
+
+def arf_backward(indices, grad_out, _l=None, _name="jo_arf_backward"):
+    indices, grad_out = _c(indices, np.uint8), _c(grad_out)
+    nOri, kH, kW, nRot = indices.shape
+    nOut = grad_out.shape[0] // nRot
+    nIn = grad_out.shape[1] // nOri
+    gw = np.zeros((nOut, nIn, nOri, kH, kW), np.float32)
+    getattr(_l or lib(), _name)(_ptr(indices), _ptr(grad_out), _i(nOut), _i(nIn), _i(nOri), _i(kH), _i(kW),
+                                _i(nRot), _ptr(gw))
+    return gw
+
+
+# ------------------------------------------------------------------ reference kernel text (_ref)
+_REF_ROI = {V_ROT: "ref_roi_align_rotated", V_ROT_V1: "ref_roi_align_rotated_v1",
+            V_HBB0: "ref_roi_align_v0", V_HBB1: "ref_roi_align_v1"}
+
+
+def ref_roi_align_forward(variant, feat, rois, out_hw, spatial_scale, sample_num, n_orient=1):
+    feat, rois = _c(feat), _c(rois)
+    N, Ct, H, W = feat.shape
+    R = rois.shape[0]
+    PH, PW = out_hw
+    out = np.zeros((R, Ct, PH, PW), np.float32)
+    if variant == V_RI:
+        ref().ref_riroi_align_fwd(_ptr(feat), _ptr(rois), _i(R), _i(Ct // n_orient), _i(H), _i(W), _i(PH),
+                                  _i(PW), _f(spatial_scale), _i(int(sample_num)), _i(n_orient), _ptr(out))
+    elif variant in (V_HBB0, V_HBB1):
+        getattr(ref(), _REF_ROI[variant] + "_fwd")(_ptr(feat), _ptr(rois), _i(R), _i(Ct), _i(H), _i(W),
+                                                   _i(PH), _i(PW), _f(spatial_scale), _f(sample_num),
+                                                   _ptr(out))
+    else:
+        getattr(ref(), _REF_ROI[variant] + "_fwd")(_ptr(feat), _ptr(rois), _i(R), _i(Ct), _i(H), _i(W),
+                                                   _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)),
+                                                   _ptr(out))
+    return out
+
+
+def ref_roi_align_backward(variant, grad_out, rois, feat_shape, spatial_scale, sample_num, n_orient=1):
+    grad_out, rois = _c(grad_out), _c(rois)
+    N, Ct, H, W = feat_shape
+    R, _, PH, PW = grad_out.shape
+    gin = np.zeros((N, Ct, H, W), np.float32)
+    if variant == V_RI:
+        ref().ref_riroi_align_bwd(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct // n_orient), _i(H),
+                                  _i(W), _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)),
+                                  _i(n_orient), _ptr(gin))
+    elif variant in (V_HBB0, V_HBB1):
+        getattr(ref(), _REF_ROI[variant] + "_bwd")(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct), _i(H),
+                                                   _i(W), _i(PH), _i(PW), _f(spatial_scale), _f(sample_num),
+                                                   _ptr(gin))
+    else:
+        getattr(ref(), _REF_ROI[variant] + "_bwd")(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct), _i(H),
+                                                   _i(W), _i(PH), _i(PW), _f(spatial_scale),
+                                                   _i(int(sample_num)), _ptr(gin))
+    return gin
+
+
+def ref_box_iou_rotated(b1, b2, version=0, cudasort=False):
+    b1, b2 = _c(b1), _c(b2)
+    n1, n2 = b1.shape[0], b2.shape[0]
+    out = np.zeros((n1, n2), np.float32)
+    name = "ref_box_iou_rotated_cudasort" if cudasort else (
+        "ref_box_iou_rotated_v1" if version == 1 else "ref_box_iou_rotated")
+    getattr(ref(), name)(_ptr(b1), _i(n1), _ptr(b2), _i(n2), _i(b1.shape[1]), _ptr(out))
+    return out
+
+
+def ref_nms_rotated_keep(dets, order, thr):
+    dets, order = _c(dets), _c(order, np.int32)
+    n, bl = dets.shape
+    keep = np.zeros((n,), np.uint8)
+    getattr(ref(), "ref_nms_rotated%d" % bl)(_ptr(dets), _i(n), _ptr(order), _f(thr), _ptr(keep))
+    return keep.astype(bool)
+
+
+def ref_deform_im2col(*a, **k):
+    return deform_im2col(*a, _l=ref(), _name="ref_deform_im2col", **k)
+
+
+def ref_deform_col2im(*a, **k):
+    return deform_col2im(*a, _l=ref(), _name="ref_deform_col2im", **k)
+
+
+def ref_deform_col2im_coord(*a, **k):
+    return deform_col2im_coord(*a, _l=ref(), _name="ref_deform_col2im_coord", **k)
+
+
+def ref_arf_forward(*a, **k):
+    return arf_forward(*a, _l=ref(), _name="ref_arf_forward", **k)
+
+
+def ref_arf_backward(*a, **k):
+    return arf_backward(*a, _l=ref(), _name="ref_arf_backward", **k)

@@ -1,0 +1,87 @@
+"""GPU parity: deformable-conv sampling kernels, DeformConv autograd, ARF / ORConv2d."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_dcn_kernels_vs_golden(golden, dev):
+    from jdet_amd.ops import dcn_v1 as D
+    g = golden("deform_conv")
+    for nm in "abc":
+        k, pad, stride, dil, dg = [int(v) for v in g["cfg_" + nm]]
+        a = (k, k, (pad, pad), (stride, stride), (dil, dil), dg)
+        im, off, gcol = _t(g["im_" + nm], dev), _t(g["off_" + nm], dev), _t(g["gcol_" + nm], dev)
+        np.testing.assert_array_equal(D.deformable_im2col(im, off, *a).cpu().numpy(), g["col_" + nm])
+        np.testing.assert_allclose(D.deformable_col2im(gcol, off, im.shape, *a).cpu().numpy(), g["gim_" + nm], atol=2e-5)
+        np.testing.assert_array_equal(D.deformable_col2im_coord(gcol, im, off, *a).cpu().numpy(), g["goff_" + nm])
+
+
+def test_deform_conv_module_vs_oracle(dev):
+    """S2ANet AlignConv shape family (3x3, pad 1, dg 1), small: forward = W . im2col, backward through
+    the three kernels; GEMMs are rocBLAS fp32 so tolerance 1e-4 relative."""
+    from jdet_amd.ops.dcn_v1 import DeformConv
+    rng = np.random.default_rng(3)
+    B, Cin, Cout, H, W = 2, 16, 12, 13, 17
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    off = (rng.standard_normal((B, 18, H, W)) * 1.5).astype(np.float32)
+    conv = DeformConv(Cin, Cout, 3, padding=1).to(dev)
+    w = conv.weight.detach().cpu().numpy()
+    xt, ot = _t(x, dev).requires_grad_(True), _t(off, dev).requires_grad_(True)
+    y = conv(xt, ot)
+    a = (3, 3, (1, 1), (1, 1), (1, 1), 1)
+    col = O.deform_im2col(x, off, *a)
+    ref = (w.reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64)).reshape(Cout, B, H, W).transpose(1, 0, 2, 3)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    gcol = (w.reshape(Cout, -1).T.astype(np.float64) @ gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64)).astype(np.float32).reshape(col.shape)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), O.deform_col2im(gcol, off, x.shape, *a), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ot.grad.cpu().numpy(), O.deform_col2im_coord(gcol, x, off, *a), rtol=1e-4, atol=2e-4)
+    gw = gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64).T
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Cout, -1), gw, rtol=1e-4, atol=2e-4)
+
+
+def test_deform_conv_zero_offset_equals_conv2d(dev):
+    from jdet_amd.ops.dcn_v1 import DeformConv
+    torch.manual_seed(0)
+    conv = DeformConv(8, 6, 3, padding=1).to(dev)
+    x = torch.randn(3, 8, 20, 24, device=dev)
+    y = conv(x, torch.zeros(3, 18, 20, 24, device=dev))
+    ref = torch.nn.functional.conv2d(x, conv.weight, padding=1)
+    assert torch.allclose(y, ref, atol=1e-4, rtol=1e-4)
+    with pytest.raises(ValueError):
+        conv(torch.randn(8, 20, 24, device=dev), torch.zeros(3, 18, 20, 24, device=dev))
+
+
+def test_arf_vs_golden_and_orconv(golden, dev):
+    from jdet_amd.ops.orn import ORConv2d, RotationInvariantPooling, arf_backward, arf_forward, arf_indices
+    g = golden("arf")
+    np.testing.assert_array_equal(arf_indices(8, 8, (3, 3)).numpy(), g["idx"])
+    np.testing.assert_array_equal(arf_indices(8, 8, (1, 1)).numpy(), g["idx1"])
+    np.testing.assert_array_equal(arf_forward(_t(g["w"], dev), _t(g["idx"], dev)).cpu().numpy(), g["y"])
+    np.testing.assert_array_equal(arf_backward(_t(g["idx"], dev), _t(g["g"], dev)).cpu().numpy(), g["gw"])
+    np.testing.assert_array_equal(arf_forward(_t(g["w1"], dev), _t(g["idx1"], dev)).cpu().numpy(), g["y1"])
+    # S2ANet's or_conv: ORConv2d(256, 32, 3, padding=1, arf_config=(1, 8)) -- scaled down
+    conv = ORConv2d(16, 4, kernel_size=3, padding=1, arf_config=(1, 8)).to(dev)
+    x = torch.randn(2, 16, 9, 9, device=dev, requires_grad=True)
+    y = conv(x)
+    assert y.shape == (2, 32, 9, 9)
+    y.square().sum().backward()
+    w = conv.weight.detach().cpu().numpy()
+    wr = O.arf_forward(w, arf_indices(1, 8, (3, 3)).numpy())
+    ref = torch.nn.functional.conv2d(x.detach(), _t(wr, dev), conv.bias, padding=1)
+    assert torch.allclose(y, ref, atol=1e-5)
+    assert conv.weight.grad is not None and conv.weight.grad.shape == conv.weight.shape
+    rip = RotationInvariantPooling(32, 8).to(dev)
+    p = rip(y)
+    assert p.shape == (2, 4, 9, 9)
+    assert torch.equal(p, y.view(2, 4, 8, 9, 9).max(2).values)
+    assert any(k.startswith("conv.") for k in rip.state_dict())  # checkpoint-compatible unused submodule

@@ -1,0 +1,139 @@
+"""GPU parity: HIP RoIAlign family (through the C ABI / jdet_amd.ops) vs golden fixtures and the
+CPU oracle.  Forward is bit-exact by construction (same operation order, contraction off) so the
+stated tolerance is 0 ulp on finite values for forward, 2e-5 abs for the atomics-ordered backward."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+FWD_ATOL = 0.0
+BWD_ATOL = 2e-5
+
+
+def _layer(variant, hw, scale, s, nO=8):
+    from jdet_amd.ops.riroi_align import RiRoIAlign
+    from jdet_amd.ops.roi_align import ROIAlign
+    from jdet_amd.ops.roi_align_rotated import ROIAlignRotated
+    from jdet_amd.ops.roi_align_rotated_v1 import ROIAlignRotated_v1
+    if variant == O.V_ROT:
+        return ROIAlignRotated(hw, scale, s)
+    if variant == O.V_ROT_V1:
+        return ROIAlignRotated_v1(hw, scale, s)
+    if variant == O.V_RI:
+        return RiRoIAlign(hw, scale, s, nO)
+    return ROIAlign(hw, scale, s, version=1 if variant == O.V_HBB1 else 0)
+
+
+def _run(variant, feat, rois, hw, scale, s, grad, dev, channels_last, nO=8):
+    x = torch.from_numpy(feat).to(dev)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    y = _layer(variant, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
+    y.backward(torch.from_numpy(grad).to(dev))
+    torch.cuda.synchronize()
+    return y.detach().cpu().numpy(), x.grad.detach().cpu().contiguous().numpy()
+
+
+@pytest.mark.parametrize("variant,nm", [(O.V_ROT, "rot"), (O.V_ROT_V1, "rot_v1"), (O.V_HBB0, "hbb0"), (O.V_HBB1, "hbb1")])
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 0), ((2, 2), 3)])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_roi_align_vs_golden(golden, dev, variant, nm, hw, s, channels_last):
+    g = golden("roi_align")
+    rois = g["hrois"] if variant in (O.V_HBB0, O.V_HBB1) else g["rois"]
+    key = "%s_%dx%d_s%d" % (nm, hw[0], hw[1], s)
+    y, gi = _run(variant, g["feat"], rois, hw, float(g["scale"]), s, g["g_" + key], dev, channels_last)
+    np.testing.assert_allclose(y, g["y_" + key], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(gi, g["gi_" + key], rtol=0, atol=BWD_ATOL)
+
+
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 0)])
+def test_riroi_align_vs_golden(golden, dev, hw, s):
+    g = golden("riroi_align")
+    key = "ri_%dx%d_s%d" % (hw[0], hw[1], s)
+    y, gi = _run(O.V_RI, g["feat"], g["rois"], hw, float(g["scale"]), s, g["g_" + key], dev, True, int(g["nO"]))
+    np.testing.assert_allclose(y, g["y_" + key], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(gi, g["gi_" + key], rtol=0, atol=BWD_ATOL)
+
+
+@pytest.mark.parametrize("variant", [O.V_ROT, O.V_ROT_V1])
+@pytest.mark.parametrize("C", [256, 260, 5, 512])
+def test_rotated_vs_oracle_random(dev, variant, C):
+    """seeded random maps incl. channel counts off the 4-vector / 256-chunk fast path"""
+    rng = np.random.default_rng(7 + C)
+    N, H, W, scale = 2, 40, 48, 0.25
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    obbs = I.random_obbs(rng, 40, extent=W / scale, wh=(4.0, 160.0))
+    rois = np.concatenate([I.rois_from_obbs(obbs, rng.integers(0, N, 40)), I.edge_rois(H, W, scale)], 0)
+    for hw, s in (((7, 7), 2), ((7, 7), 0)):
+        grad = rng.standard_normal((rois.shape[0], C) + hw).astype(np.float32)
+        y, gi = _run(variant, feat, rois, hw, scale, s, grad, dev, True)
+        np.testing.assert_allclose(y, O.roi_align_forward(variant, feat, rois, hw, scale, s), rtol=0, atol=FWD_ATOL)
+        ref = O.roi_align_backward(variant, grad, rois, feat.shape, scale, s)
+        np.testing.assert_allclose(gi, ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
+
+
+def test_cfg0_micro_vs_oracle(dev):
+    """BASELINE configs[0]: 1x256x256x256 fmap, 512 random OBBs, 7x7, sampling 2, scale 0.25."""
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((1, 256, 256, 256)).astype(np.float32)
+    rois = I.rois_from_obbs(I.random_obbs(rng, 512), np.zeros(512))
+    grad = rng.standard_normal((512, 256, 7, 7)).astype(np.float32)
+    y, gi = _run(O.V_ROT, feat, rois, (7, 7), 0.25, 2, grad, dev, True)
+    O.set_threads(8)
+    np.testing.assert_allclose(y, O.roi_align_forward(O.V_ROT, feat, rois, (7, 7), 0.25, 2), rtol=0, atol=FWD_ATOL)
+    ref = O.roi_align_backward(O.V_ROT, grad, rois, feat.shape, 0.25, 2)
+    np.testing.assert_allclose(gi, ref, rtol=0, atol=1e-4)
+
+
+def test_full_size_properties(dev):
+    """north-star size (1024x1024 tile -> 256x256x256 map, 2000 RoIs): size-independent properties.
+    (a) linearity in the feature map, (b) a constant map pools to the constant for RoIs whose samples
+    are all inside, (c) backward of ones conserves mass: sum(grad_in) == #valid-sample-weight."""
+    from jdet_amd.ops.roi_align_rotated import ROIAlignRotated
+    rng = np.random.default_rng(1)
+    R = 2000
+    rois_np = I.rois_from_obbs(I.random_obbs(rng, R), np.zeros(R))
+    rois = torch.from_numpy(rois_np).to(dev)
+    layer = ROIAlignRotated(7, 0.25, 2)
+    a = torch.randn(1, 256, 256, 256, device=dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(1, 256, 256, 256, device=dev).contiguous(memory_format=torch.channels_last)
+    ya, yb, yab = layer(a, rois), layer(b, rois), layer(2.0 * a - 0.5 * b, rois)
+    assert torch.allclose(yab, 2.0 * ya - 0.5 * yb, atol=2e-5)
+    ones = torch.ones(1, 8, 256, 256, device=dev).contiguous(memory_format=torch.channels_last)
+    ones.requires_grad_(True)
+    yo = layer(ones, rois)
+    # RoIs fully inside the map (centre +- half diagonal) must pool to exactly ~1
+    half = 0.5 * np.hypot(rois_np[:, 3], rois_np[:, 4])
+    inside = (rois_np[:, 1] - half > 4) & (rois_np[:, 1] + half < 1016) & (rois_np[:, 2] - half > 4) & (rois_np[:, 2] + half < 1016)
+    assert inside.sum() > 100
+    assert torch.allclose(yo[torch.from_numpy(inside).to(dev)], torch.ones((), device=dev), atol=1e-5)
+    yo.sum().backward()
+    # bilinear weights of a valid sample sum to 1, so sum(grad_in) == sum(forward(ones))
+    assert abs(ones.grad.sum().item() - yo.sum().item()) < 1e-3 * yo.sum().item()
+
+
+def test_empty_and_errors(dev):
+    from jdet_amd.ops.roi_align_rotated import ROIAlignRotated
+    x = torch.randn(1, 8, 16, 16, device=dev, requires_grad=True)
+    y = ROIAlignRotated(7, 0.25, 2)(x, torch.zeros((0, 6), device=dev))
+    assert y.shape == (0, 8, 7, 7)
+    y.sum().backward()
+    assert x.grad.abs().sum().item() == 0
+    with pytest.raises(AssertionError):
+        ROIAlignRotated(7, 0.25, 2)(x, torch.zeros((3, 5), device=dev))
+
+
+def test_layout_helpers(dev):
+    from jdet_amd import _lib as L
+    x = torch.randn(3, 37, 19, 23, device=dev)
+    y = torch.empty(3, 19, 23, 37, device=dev)
+    L.check(L.lib().jdet_nchw_to_nhwc(x.data_ptr(), 3, 37, 19, 23, y.data_ptr(), L.stream_ptr(x)), "t")
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    z = torch.empty_like(x)
+    L.check(L.lib().jdet_nhwc_to_nchw(y.data_ptr(), 3, 37, 19, 23, z.data_ptr(), L.stream_ptr(x)), "t")
+    assert torch.equal(z, x)
