@@ -77,14 +77,21 @@ def make_step(workload, d):
         feat, rois = d["feat"], d["rois"]
         R = rois.shape[0]
         out = torch.empty((R, 256, 7, 7), device=feat.device)
+        obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)
         fp, rp, op = feat.data_ptr(), rois.data_ptr(), out.data_ptr()
+        o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
+        use_order = os.environ.get("JDET_BENCH_NO_ORDER", "0") != "1"
 
         def step():
-            L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op,
-                                               L.stream_ptr(feat)), "fwd")
+            # the XCD-aware schedule is recomputed every step: RoIs arrive in arbitrary order
+            st = L.stream_ptr(feat)
+            if use_order:
+                L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
+            L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
+                                               o0 if use_order else None, op, st), "fwd")
         d["out"] = out
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
-        return step, nbytes / 1e9, "GB", nbytes, "roi_align_fwd_kernel<ROTATED,vec4>", "f32"
+        return step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_kernel<ROTATED,vec4>", "f32"
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]
@@ -92,7 +99,7 @@ def make_step(workload, d):
         gp, rp, ip = grad.data_ptr(), rois.data_ptr(), gin.data_ptr()
 
         def step():
-            L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, ip,
+            L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, None, ip,
                                                 L.stream_ptr(feat)), "bwd")
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         return step, nbytes / 1e9, "GB", nbytes, "roi_align_bwd_kernel<ROTATED>", "f32"
@@ -124,25 +131,31 @@ def cpu_baseline(workload, d, R):
     O.lib()
     if workload.startswith("roi_align"):
         feat = d["feat_cpu"].numpy()
-        # size the sample from a 16-RoI probe so that it costs ~10-20 s
+        # size the sample from a 16-RoI probe so that it costs ~10 s (many-core hosts finish the
+        # whole workload in well under a second: then repeat it and keep the mean)
         t0 = time.perf_counter()
         O.roi_align_forward(O.V_ROT, feat, d["rois_np"][:16], (7, 7), 0.25, 2)
         per = (time.perf_counter() - t0) / 16
-        rs = int(min(R, max(32, 12.0 / max(per, 1e-6))))
-        t0 = time.perf_counter()
-        if workload.endswith("bwd"):
-            g = np.ones((rs, 256, 7, 7), np.float32)
-            O.roi_align_backward(O.V_ROT, g, d["rois_np"][:rs], feat.shape, 0.25, 2)
-            cores_used = 1  # serial accumulation
-        else:
-            O.roi_align_forward(O.V_ROT, feat, d["rois_np"][:rs], (7, 7), 0.25, 2)
-            cores_used = cores
-        t = time.perf_counter() - t0
+        rs = int(min(R, max(32, 10.0 / max(per, 1e-6))))
+        bwd = workload.endswith("bwd")
+        g = np.ones((rs, 256, 7, 7), np.float32) if bwd else None
+        cores_used = 1 if bwd else cores  # backward accumulates serially (as the oracle defines it)
+        reps, t = 0, 0.0
+        while reps < 1 or (t < 5.0 and reps < 50):
+            t0 = time.perf_counter()
+            if bwd:
+                O.roi_align_backward(O.V_ROT, g, d["rois_np"][:rs], feat.shape, 0.25, 2)
+            else:
+                O.roi_align_forward(O.V_ROT, feat, d["rois_np"][:rs], (7, 7), 0.25, 2)
+            t += time.perf_counter() - t0
+            reps += 1
+        t /= reps
         full = t * R / rs
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         return {"value": nbytes / 1e9 / full, "unit": "GB/s", "cores": cores_used, "kind": "port",
-                "sample": "first %d of %d RoIs of the same map (%.1f s), extrapolated linearly in RoIs; "
-                          "algorithmic bytes of the full workload / extrapolated time" % (rs, R, t)}
+                "sample": "first %d of %d RoIs of the same map, mean of %d runs (%.3f s each), extrapolated "
+                          "linearly in RoIs; algorithmic bytes of the full workload / extrapolated time"
+                          % (rs, R, reps, t)}
     if workload == "box_iou_rotated":
         b1, b2 = d["b1_np"][:16], d["b2_np"]
         t0 = time.perf_counter()

@@ -62,17 +62,28 @@ int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, jdet
  *   out     : (R, C, PH, PW) contiguous (the reference's output layout)
  *   sample_num : >0 fixed grid, <=0 adaptive ceil(roi_size / pooled_size)
  *   n_orient   : RiRoIAlign only (C % n_orient == 0); pass 1 otherwise
+ *   order      : optional (R) int32 permutation from jdet_roi_spatial_order, or NULL
  * Limits: PH*PW <= 256; any C >= 1 (C % 4 == 0 takes the vector path). */
 int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, int H, int W,
                            const float* rois, int R, int PH, int PW, float spatial_scale,
-                           int sample_num, int n_orient, float* out, jdet_stream_t stream);
+                           int sample_num, int n_orient, const int32_t* order, float* out,
+                           jdet_stream_t stream);
+
+/* XCD-aware spatial schedule for the RoIAlign kernels (no reference counterpart: the reference
+ * processes output elements in index order).  Writes a permutation `order` of [0,R): workgroup b
+ * processes RoI order[b].  RoIs are bucketed by the Morton code of their centre and contiguous
+ * runs are dealt to the 8 XCDs so that each XCD's private L2 sweeps one compact region of the
+ * map.  Pure performance hint: any permutation (or NULL = identity) gives identical results.
+ * `workspace`: R int32 of scratch.  roi_cols 6 (rotated) or 5 (horizontal). */
+int jdet_roi_spatial_order(const float* rois, int R, int roi_cols, float spatial_scale, int N,
+                           int H, int W, int32_t* order, int32_t* workspace, jdet_stream_t stream);
 
 /* RoIAlign backward w.r.t. the feature map.  Replaces roi_align_rotated.py:L286-307 (and the
  * _v1 / riroi / hbb twins).  grad_in_nhwc (N,H,W,C) is zero-filled then accumulated with
  * hardware fp32 atomics (order-nondeterministic in the last bits, as in the reference). */
 int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,
                             int C, int H, int W, int PH, int PW, float spatial_scale,
-                            int sample_num, int n_orient, float* grad_in_nhwc,
+                            int sample_num, int n_orient, const int32_t* order, float* grad_in_nhwc,
                             jdet_stream_t stream);
 
 /* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and

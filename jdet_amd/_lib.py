@@ -21,8 +21,9 @@ SIGNATURES = {
     "jdet_version": (_i, []),
     "jdet_nchw_to_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "jdet_nhwc_to_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
-    "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p]),
-    "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p]),
+    "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "jdet_roi_spatial_order": (_i, [_p, _i, _i, _f, _i, _i, _i, _p, _p, _p]),
     "jdet_box_iou_rotated": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "jdet_nms_rotated_workspace": (_sz, [_i]),
     "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),

@@ -29,6 +29,19 @@ def to_nhwc(x):
     return y
 
 
+# below this many RoIs the map traffic is too small for the XCD schedule to matter
+SPATIAL_ORDER_MIN_ROIS = 64
+
+
+def spatial_order(rois_c, spatial_scale, N, H, W):
+    """XCD-aware processing order (jdet_roi_spatial_order); a pure performance hint."""
+    R, cols = rois_c.shape
+    buf = torch.empty((2, R), dtype=torch.int32, device=rois_c.device)
+    L.check(L.lib().jdet_roi_spatial_order(L.ptr(rois_c), R, cols, spatial_scale, N, H, W, buf[0].data_ptr(),
+                                           buf[1].data_ptr(), L.stream_ptr(rois_c)), "jdet_roi_spatial_order")
+    return buf[0]
+
+
 class RoIAlignFunction(torch.autograd.Function):
     """forward(input (N,C,H,W), rois (R,6|5)) -> (R,C,PH,PW); grad only w.r.t. input
     (reference: `return input_grad, None`, roi_align_rotated.py:L308)."""
@@ -45,24 +58,25 @@ class RoIAlignFunction(torch.autograd.Function):
         N, C, H, W = feat.shape
         R = rois_c.shape[0]
         out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
+        order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
         L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
                                                float(spatial_scale), int(sample_num), int(n_orient),
-                                               L.ptr(out), L.stream_ptr(feat)),
+                                               L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
                 "jdet_roi_align_forward")
-        ctx.save_for_backward(rois_c)
+        ctx.save_for_backward(rois_c, order)
         ctx.cfg = (variant, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
-        (rois_c,) = ctx.saved_tensors
+        rois_c, order = ctx.saved_tensors
         variant, (N, C, H, W), PH, PW, scale, sample_num, n_orient = ctx.cfg
         g = L.f32c(grad_output)
         R = rois_c.shape[0]
         grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
                               memory_format=torch.channels_last)
         L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
-                                                scale, sample_num, n_orient, L.ptr(grad_in),
+                                                scale, sample_num, n_orient, L.ptr(order), L.ptr(grad_in),
                                                 L.stream_ptr(g)),
                 "jdet_roi_align_backward")
         return grad_in, None, None, None, None, None, None
