@@ -227,8 +227,14 @@ def main():
                        "parallelism": "image-parallel x%d (no collective)" % world},
         }
         ach = nbytes / 1e9 / (dev_ms / 1e3)
+        traffic = None
+        try:  # PMC HBM bytes per launch from the last committed rocprofv3 counter passes
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                traffic = json.load(f).get(a.workload, {}).get("traffic_bytes")
+        except OSError:
+            pass
         line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBPS, "traffic": None, "kernel": kname,
+                            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
                             "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)

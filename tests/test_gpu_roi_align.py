@@ -137,3 +137,24 @@ def test_layout_helpers(dev):
     z = torch.empty_like(x)
     L.check(L.lib().jdet_nhwc_to_nchw(y.data_ptr(), 3, 37, 19, 23, z.data_ptr(), L.stream_ptr(x)), "t")
     assert torch.equal(z, x)
+
+
+@pytest.mark.parametrize("R,N", [(1, 1), (7, 1), (64, 2), (2000, 1), (2003, 3), (9001, 2), (20000, 16)])
+def test_spatial_order_is_a_permutation(dev, R, N):
+    """jdet_roi_spatial_order is a pure scheduling hint: it must emit a permutation of [0,R) for any R
+    (LDS path R <= 8192, global-scratch path above), any image count, 6- and 5-column RoIs."""
+    from jdet_amd.ops._roi_common import spatial_order
+    rng = np.random.default_rng(R)
+    rois = I.rois_from_obbs(I.random_obbs(rng, R), rng.integers(0, N, R))
+    o = spatial_order(torch.from_numpy(rois).to(dev), 0.25, N, 256, 256).cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(R))
+    h = I.obb_to_hbb_rois(rois)
+    o5 = spatial_order(torch.from_numpy(h).to(dev), 0.25, N, 256, 256).cpu().numpy()
+    assert np.array_equal(np.sort(o5), np.arange(R))
+    if R >= 2000 and N == 1:
+        # consecutive workgroups of one XCD (b, b+8) are spatial neighbours: mean centre distance far
+        # below that of a random order
+        c = rois[o][:, 1:3]
+        d_sched = np.linalg.norm(c[8:] - c[:-8], axis=1).mean()
+        d_rand = np.linalg.norm(rois[8:, 1:3] - rois[:-8, 1:3], axis=1).mean()
+        assert d_sched < 0.25 * d_rand
