@@ -34,6 +34,9 @@ def parse():
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--workload", default="roi_align_rotated")
+    p.add_argument("--batch", type=int, default=2, help="images per GPU (s2anet_train)")
+    p.add_argument("--size", type=int, default=1024, help="tile size (s2anet_train)")
+    p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"])
     p.add_argument("--rois", type=int, default=2000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
@@ -122,6 +125,38 @@ def make_step(workload, d):
     raise SystemExit("unknown workload")
 
 
+S2ANET_CFG = dict(
+    model=dict(
+        type="S2ANet",
+        backbone=dict(type="Resnet50", frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"],
+                      pretrained=True),
+        neck=dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+                  add_extra_convs="on_input", num_outs=5),
+        bbox_head=dict(type="S2ANetHead", num_classes=16, in_channels=256, feat_channels=256, stacked_convs=2,
+                       with_orconv=True, anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_scales=[4],
+                       target_means=[.0, .0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0, 1.0])),
+    # configs/s2anet/s2anet_r50_fpn_1x_dota.py:L151-166 (model section identical to L2-96 there)
+    optimizer=dict(type="SGD", lr=0.01 / 4., momentum=0.9, weight_decay=0.0001, grad_clip=dict(max_norm=35, norm_type=2)),
+    scheduler=dict(type="StepLR", warmup="linear", warmup_iters=500, warmup_ratio=1.0 / 3, milestones=[7, 10]))
+
+
+def make_s2anet(a, rank, dev):
+    """S2ANet-R50-FPN train step (SURVEY 8d cfg 2): `batch` synthetic 1024x1024 tiles per GPU, 64 random OBB gts
+    each, random-init weights of the reference architecture, SGD+clip+StepLR, DDP when world > 1."""
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.runner import Runner, synthetic_batch
+    ref_cfg = "/root/reference/configs/s2anet/s2anet_r50_fpn_1x_dota.py"
+    torch.manual_seed(1234)  # identical replicas
+    amp = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.amp]
+    runner = Runner(S2ANET_CFG, device=dev, amp_dtype=amp)
+    images, targets = synthetic_batch(a.batch, a.size, dev, seed=2 + rank)
+    images = images.contiguous(memory_format=torch.channels_last)
+
+    def step():
+        runner.train_step(images, targets)
+    return step, runner
+
+
 def cpu_baseline(workload, d, R):
     """Oracle (kind=port: our CPU restatement, parity-pinned against the reference kernel text) on a
     bounded sample of the same workload, all host cores (OpenMP over RoIs / rows)."""
@@ -176,6 +211,45 @@ def cpu_baseline(workload, d, R):
     return None
 
 
+def timed(step, steps, warmup, dist, dev):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; returns
+    (wall seconds = max over ranks, device ms per step from HIP events on the launch stream)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / steps  # HIP events on torch's current stream = the launch stream
+    if dist is not None:
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    return t, dev_ms
+
+
+def roofline_obj(workload, nbytes, dev_ms, kname):
+    ach = nbytes / 1e9 / (dev_ms / 1e3)
+    traffic = None
+    try:  # PMC HBM bytes per launch from the last committed rocprofv3 counter passes
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            traffic = json.load(f).get(workload, {}).get("traffic_bytes")
+    except OSError:
+        pass
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "traffic": traffic, "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,56 +263,51 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    d = make_inputs(a.workload, a.rois, 1000 + rank, dev)
-    step, units, unit_name, nbytes, kname, dtype = make_step(a.workload, d)
 
-    for _ in range(a.warmup):
-        step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1) / a.steps  # HIP events on the launch stream (torch's current stream)
-    if dist is not None:
-        tt = torch.tensor([t], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t = float(tt.item())
-
-    if rank == 0:
-        value = units * a.steps * world / t
-        line = {
-            "metric": ("rotated RoIAlign forward algorithmic GB/s (1024x1024 tile, %d RoIs)" % a.rois
-                       if a.workload == "roi_align_rotated" else a.workload + " " + unit_name + "/s"),
-            "value": value, "unit": unit_name + "/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": a.workload, "fmap": "1x256x256x256 fp32 NHWC", "rois": a.rois,
-                       "pooled": "7x7", "sampling_ratio": 2, "spatial_scale": 0.25,
-                       "parallelism": "image-parallel x%d (no collective)" % world},
-        }
-        ach = nbytes / 1e9 / (dev_ms / 1e3)
-        traffic = None
-        try:  # PMC HBM bytes per launch from the last committed rocprofv3 counter passes
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                traffic = json.load(f).get(a.workload, {}).get("traffic_bytes")
-        except OSError:
-            pass
-        line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "kernel": kname,
-                            "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)
-        print(json.dumps(line))
+    if a.workload == "s2anet_train":
+        step, runner = make_s2anet(a, rank, dev)
+        t, dev_ms = timed(step, a.steps, a.warmup, dist, dev)
+        if rank == 0:
+            line = {
+                "metric": "img/s S2ANet-R50-FPN train step, %dx%d synthetic tiles" % (a.size, a.size),
+                "value": a.batch * world * a.steps / t, "unit": "img/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": {"none": "f32", "bf16": "bf16", "fp16": "f16"}[a.amp],
+                "data": "synthetic",
+                "config": {"workload": "s2anet_train", "model": "S2ANet-R50-FPN (configs/s2anet/s2anet_r50_fpn_1x_dota.py)",
+                           "global_batch": a.batch * world, "tile": "%dx%d" % (a.size, a.size), "gts_per_image": 64,
+                           "optimizer": "SGD lr 0.0025 mom 0.9 wd 1e-4 clip 35 + StepLR warm-up",
+                           "parallelism": "dp%d (DDP, RCCL all-reduce)" % world},
+            }
+            # roofline leg: the path's HBM-bound hand-written kernel at the north-star point, measured live
+            d = make_inputs("roi_align_rotated", a.rois, 1000, dev)
+            rstep, _, _, nbytes, kname, _ = make_step("roi_align_rotated", d)
+            _, rms = timed(rstep, 200, 20, None, dev)
+            line["roofline"] = roofline_obj("roi_align_rotated", nbytes, rms, kname)
+            if world == 1 and not a.no_cpu_baseline:
+                cb = cpu_baseline("roi_align_rotated", d, a.rois)
+                cb["sample"] = "rotated RoIAlign forward leg (the roofline kernel), not the whole train step: " + cb["sample"]
+                line["cpu_baseline"] = cb
+            print(json.dumps(line))
+    else:
+        d = make_inputs(a.workload, a.rois, 1000 + rank, dev)
+        step, units, unit_name, nbytes, kname, dtype = make_step(a.workload, d)
+        t, dev_ms = timed(step, a.steps, a.warmup, dist, dev)
+        if rank == 0:
+            line = {
+                "metric": ("rotated RoIAlign forward algorithmic GB/s (1024x1024 tile, %d RoIs)" % a.rois
+                           if a.workload == "roi_align_rotated" else a.workload + " " + unit_name + "/s"),
+                "value": units * a.steps * world / t, "unit": unit_name + "/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": {"workload": a.workload, "fmap": "1x256x256x256 fp32 NHWC", "rois": a.rois,
+                           "pooled": "7x7", "sampling_ratio": 2, "spatial_scale": 0.25,
+                           "parallelism": "image-parallel x%d (no collective)" % world},
+            }
+            line["roofline"] = roofline_obj(a.workload, nbytes, dev_ms, kname)
+            if world == 1 and not a.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)
+            print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
 

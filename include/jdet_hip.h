@@ -127,6 +127,31 @@ int jdet_arf_forward(const float* weight, const uint8_t* indices, int nOut, int 
 int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
                       int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream);
 
+/* Rotated box delta codec (fused elementwise).  Replace the Jittor tensor programs
+ * models/boxes/box_ops.py:L229-285 (delta2bbox_rotated: rois (n,5), deltas (n, ncls*5) -> out
+ * (n, ncls*5); max_shape / clip_border are accepted by the reference but never applied) and
+ * box_ops.py:L180-226 (bbox2delta_rotated: proposals (n,5), gt (n,5) -> (n,5)).
+ * means5 / stds5 are HOST pointers to 5 floats.  norm_angle is the floor-mod form L176-178. */
+int jdet_delta2bbox_rotated(const float* rois, const float* deltas, int n, int ncls,
+                            const float* means5, const float* stds5, float wh_ratio_clip, float* out,
+                            jdet_stream_t stream);
+int jdet_bbox2delta_rotated(const float* proposals, const float* gt, int n, const float* means5,
+                            const float* stds5, float* out, jdet_stream_t stream);
+
+/* MaxIoUAssigner.assign_wrt_overlaps (models/boxes/assigner.py:L160-219) in two launches, no host
+ * sync (the reference loops over gts in Python with a masked store per gt and jt.sync_all()).
+ *   overlaps (K, A) row-major, gts are rows (assigner.py:L143)
+ *   negatives: neg_iou_lo <= max < neg_iou_hi (float threshold: lo = 0)
+ *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
+ *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
+ * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+size_t jdet_assign_max_iou_workspace(int K);
+int jdet_assign_max_iou(const float* overlaps, int K, int A, float pos_iou_thr, float neg_iou_lo,
+                        float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                        int gt_max_assign_all, const int32_t* gt_labels, int labels_filled,
+                        int32_t* gt_inds, float* max_overlaps, int32_t* labels, void* workspace,
+                        size_t workspace_bytes, jdet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

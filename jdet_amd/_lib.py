@@ -32,6 +32,10 @@ SIGNATURES = {
     "jdet_deform_col2im_coord": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p]),
     "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
+    "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),
+    "jdet_bbox2delta_rotated": (_i, [_p, _p, _i, _p, _p, _p, _p]),
+    "jdet_assign_max_iou_workspace": (_sz, [_i]),
+    "jdet_assign_max_iou": (_i, [_p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i, _p, _p, _p, _p, _sz, _p]),
 }
 
 _lib = None

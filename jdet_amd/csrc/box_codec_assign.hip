@@ -1,0 +1,224 @@
+// Rotated box delta codec and max-IoU assignment for gfx950.
+//
+// Reference semantics (Jittor tensor programs, ~30 elementwise launches / a per-gt Python loop):
+//   python/jdet/models/boxes/box_ops.py:L176-178  norm_angle
+//   python/jdet/models/boxes/box_ops.py:L180-226  bbox2delta_rotated
+//   python/jdet/models/boxes/box_ops.py:L229-285  delta2bbox_rotated
+//   python/jdet/models/boxes/assigner.py:L160-219 MaxIoUAssigner.assign_wrt_overlaps
+//
+// All three are tiny HBM-bound passes (20 B per box in, 20 B out; the assigner reads the K x A
+// overlap matrix twice).  Their cost in the reference is launch count and host synchronisation
+// (`jt.sync_all()` every 100 gts, one masked store per gt), so each is ONE launch here:
+//   * codec kernels: one lane per (box, class) element, fully fused;
+//   * assignment: kernel 1 reduces each gt row to its max (one workgroup per gt, wave shuffles);
+//     kernel 2 owns one anchor per lane: column argmax (first maximum), neg / pos thresholds, the
+//     low-quality pass as "last gt i with overlaps[i,j] == gt_max[i] >= min_pos_iou wins"
+//     (equivalent to the reference's in-order overwrite loop), label gather.  No host sync.
+#include "common.h"
+
+namespace {
+
+// floor-mod norm_angle: (a + pi/4) mod pi - pi/4   (box_ops.py:L176-178, range [-pi/4, pi])
+__device__ __forceinline__ float norm_angle(float a) {
+  const float lo = (float)(-M_PI / 4), span = (float)M_PI;
+  const float x = a - lo;
+  float r = x - floorf(x / span) * span;  // python-style % for a positive modulus
+  return r + lo;
+}
+
+struct Vec5 {
+  float v[5];
+};
+
+__global__ __launch_bounds__(256) void delta2bbox_rotated_kernel(const float* __restrict__ rois,
+                                                                 const float* __restrict__ deltas, long n,
+                                                                 int ncls, Vec5 means, Vec5 stds,
+                                                                 float max_ratio, float* __restrict__ out) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n * ncls; idx += (long)gridDim.x * 256) {
+    const long i = idx / ncls;
+    const float* r = rois + i * 5;
+    const float* d = deltas + idx * 5;
+    const float dx = d[0] * stds.v[0] + means.v[0];
+    const float dy = d[1] * stds.v[1] + means.v[1];
+    float dw = d[2] * stds.v[2] + means.v[2];
+    float dh = d[3] * stds.v[3] + means.v[3];
+    const float da = d[4] * stds.v[4] + means.v[4];
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float rx = r[0], ry = r[1], rw = r[2], rh = r[3], ra = r[4];
+    const float c = cosf(ra), s = sinf(ra);
+    float* o = out + idx * 5;
+    o[0] = dx * rw * c - dy * rh * s + rx;
+    o[1] = dx * rw * s + dy * rh * c + ry;
+    o[2] = rw * expf(dw);
+    o[3] = rh * expf(dh);
+    o[4] = norm_angle((float)M_PI * da + ra);
+  }
+}
+
+__global__ __launch_bounds__(256) void bbox2delta_rotated_kernel(const float* __restrict__ proposals,
+                                                                 const float* __restrict__ gt, long n,
+                                                                 Vec5 means, Vec5 stds,
+                                                                 float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float* p = proposals + i * 5;
+    const float* g = gt + i * 5;
+    const float pw = p[2], ph = p[3], pa = p[4];
+    const float c = cosf(pa), s = sinf(pa);
+    const float cx = g[0] - p[0], cy = g[1] - p[1];
+    float d[5];
+    d[0] = (c * cx + s * cy) / pw;
+    d[1] = (-s * cx + c * cy) / ph;
+    // jt.safe_log = log(clamp(x, 1e-30, 1e30))
+    d[2] = logf(fminf(fmaxf(g[2] / pw, 1e-30f), 1e30f));
+    d[3] = logf(fminf(fmaxf(g[3] / ph, 1e-30f), 1e30f));
+    d[4] = norm_angle(g[4] - pa) / (float)M_PI;
+    float* o = out + i * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) o[k] = (d[k] - means.v[k]) / stds.v[k];
+  }
+}
+
+// ---- MaxIoUAssigner ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assign_row_max_kernel(const float* __restrict__ overlaps, int K, int A,
+                                                             float* __restrict__ gt_max) {
+  // one workgroup per gt row; max is order-independent -> bit-exact
+  __shared__ float s_part[4];
+  const int i = blockIdx.x;
+  const float* row = overlaps + (size_t)i * A;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < A; j += 256) m = fmaxf(m, row[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) gt_max[i] = fmaxf(fmaxf(s_part[0], s_part[1]), fmaxf(s_part[2], s_part[3]));
+}
+
+__global__ __launch_bounds__(256) void assign_anchor_kernel(
+    const float* __restrict__ overlaps, int K, int A, const float* __restrict__ gt_max, float pos_iou_thr,
+    float neg_lo, float neg_hi, float min_pos_iou, int match_low_quality, int gt_max_assign_all,
+    const int32_t* __restrict__ gt_labels, int labels_filled, int32_t* __restrict__ gt_inds,
+    float* __restrict__ max_overlaps, int32_t* __restrict__ labels) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= A) return;
+  // column argmax over the K gts (first maximum) -- coalesced: consecutive lanes, consecutive j
+  float best = -INFINITY;
+  int arg = 0;
+  int low = -1;  // last gt whose row maximum this anchor attains (step 4, gt_max_assign_all)
+  for (int i = 0; i < K; i++) {
+    const float v = overlaps[(size_t)i * A + j];
+    if (v > best) {
+      best = v;
+      arg = i;
+    }
+    if (match_low_quality && gt_max_assign_all) {
+      const float gm = gt_max[i];
+      if (gm >= min_pos_iou && v == gm) low = i;
+    }
+  }
+  int assigned = -1;                                        // 1. default -1
+  if (best >= neg_lo && best < neg_hi) assigned = 0;         // 2. negatives (assigner.py:L187-193)
+  if (best >= pos_iou_thr) assigned = arg + 1;               // 3. positives (L196-197)
+  if (low >= 0) assigned = low + 1;                          // 4. low-quality matches (L200-207)
+  gt_inds[j] = assigned;
+  max_overlaps[j] = best;
+  if (labels) {
+    labels[j] = (assigned > 0 && gt_labels) ? gt_labels[assigned - 1] : labels_filled;  // L211-215
+  }
+}
+
+// step 4 with gt_max_assign_all = False: only gt_argmax_overlaps[i] (first maximum of row i) is set,
+// in gt order (later gts overwrite).  One lane per gt finds its first-maximum column, then a single
+// lane applies the K updates in order (K is tiny).
+__global__ __launch_bounds__(256) void assign_row_argmax_apply_kernel(
+    const float* __restrict__ overlaps, int K, int A, const float* __restrict__ gt_max, float min_pos_iou,
+    const int32_t* __restrict__ gt_labels, int32_t* __restrict__ row_arg, int32_t* __restrict__ gt_inds,
+    int32_t* __restrict__ labels) {
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const float gm = gt_max[i];
+    int a = 0;
+    for (int j = 0; j < A; j++)
+      if (overlaps[(size_t)i * A + j] == gm) {
+        a = j;
+        break;
+      }
+    row_arg[i] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < K; i++)
+      if (gt_max[i] >= min_pos_iou) {
+        gt_inds[row_arg[i]] = i + 1;
+        if (labels && gt_labels) labels[row_arg[i]] = gt_labels[i];
+      }
+  }
+}
+
+inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g > 262144 ? 262144 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+JDET_API int jdet_delta2bbox_rotated(const float* rois, const float* deltas, int n, int ncls,
+                                     const float* means5, const float* stds5, float wh_ratio_clip,
+                                     float* out, jdet_stream_t stream) {
+  if (n < 0 || ncls <= 0 || !means5 || !stds5 || !(wh_ratio_clip > 0)) return JDET_E_BADARG;
+  if (n == 0) return JDET_OK;
+  if (!rois || !deltas || !out) return JDET_E_BADARG;
+  Vec5 m, s;
+  for (int k = 0; k < 5; k++) {
+    m.v[k] = means5[k];
+    s.v[k] = stds5[k];
+  }
+  const float max_ratio = fabsf(logf(wh_ratio_clip));
+  hipLaunchKernelGGL(delta2bbox_rotated_kernel, dim3(grid_for((long)n * ncls)), dim3(256), 0,
+                     (hipStream_t)stream, rois, deltas, (long)n, ncls, m, s, max_ratio, out);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_bbox2delta_rotated(const float* proposals, const float* gt, int n, const float* means5,
+                                     const float* stds5, float* out, jdet_stream_t stream) {
+  if (n < 0 || !means5 || !stds5) return JDET_E_BADARG;
+  if (n == 0) return JDET_OK;
+  if (!proposals || !gt || !out) return JDET_E_BADARG;
+  Vec5 m, s;
+  for (int k = 0; k < 5; k++) {
+    m.v[k] = means5[k];
+    s.v[k] = stds5[k];
+  }
+  hipLaunchKernelGGL(bbox2delta_rotated_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     proposals, gt, (long)n, m, s, out);
+  return jdet_launch_status();
+}
+
+JDET_API size_t jdet_assign_max_iou_workspace(int K) { return K > 0 ? (size_t)K * 8 : 0; }
+
+JDET_API int jdet_assign_max_iou(const float* overlaps, int K, int A, float pos_iou_thr, float neg_iou_lo,
+                                 float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                                 int gt_max_assign_all, const int32_t* gt_labels, int labels_filled,
+                                 int32_t* gt_inds, float* max_overlaps, int32_t* labels, void* workspace,
+                                 size_t workspace_bytes, jdet_stream_t stream) {
+  if (K <= 0 || A <= 0) return JDET_E_BADARG;  // the reference raises ValueError('No gt or proposals')
+  if (!overlaps || !gt_inds || !max_overlaps || !workspace) return JDET_E_BADARG;
+  if (workspace_bytes < jdet_assign_max_iou_workspace(K)) return JDET_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* gt_max = (float*)workspace;
+  int32_t* row_arg = (int32_t*)(gt_max + K);
+  hipLaunchKernelGGL(assign_row_max_kernel, dim3(K), dim3(256), 0, st, overlaps, K, A, gt_max);
+  int e = jdet_launch_status();
+  if (e) return e;
+  hipLaunchKernelGGL(assign_anchor_kernel, dim3((A + 255) / 256), dim3(256), 0, st, overlaps, K, A, gt_max,
+                     pos_iou_thr, neg_iou_lo, neg_iou_hi, min_pos_iou, match_low_quality, gt_max_assign_all,
+                     gt_labels, labels_filled, gt_inds, max_overlaps, labels);
+  e = jdet_launch_status();
+  if (e) return e;
+  if (match_low_quality && !gt_max_assign_all) {
+    hipLaunchKernelGGL(assign_row_argmax_apply_kernel, dim3(1), dim3(256), 0, st, overlaps, K, A, gt_max,
+                       min_pos_iou, gt_labels, row_arg, gt_inds, labels);
+    e = jdet_launch_status();
+  }
+  return e;
+}

@@ -1,0 +1,105 @@
+"""Cross entropy losses.  Mirrors python/jdet/models/losses/cross_entropy_loss.py: `CrossEntropyLoss`
+(manual log-sum-exp with safe_log, L57-78, L128-157) and `CrossEntropyLossForRcnn` (L6-55)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from jdet_amd.utils.registry import LOSSES
+
+
+def weighted_cross_entropy(pred, label, weight, avg_factor=None, reduce=True):
+    if avg_factor is None:
+        avg_factor = max(float((weight > 0).sum().item()), 1.0)
+    raw = F.cross_entropy(pred, label.long(), reduction="none")
+    if reduce:
+        return torch.sum(raw * weight)[None] / avg_factor
+    return raw * weight / avg_factor
+
+
+def _expand_binary_labels(labels, label_weights, label_channels):
+    bin_labels = torch.zeros((labels.size(0), label_channels), device=labels.device)
+    inds = torch.nonzero(labels >= 1)[:, 0]
+    if inds.numel() > 0:
+        bin_labels[inds, labels[inds].long() - 1] = 1
+    bin_label_weights = label_weights.view(-1, 1).expand(label_weights.size(0), label_channels)
+    return bin_labels, bin_label_weights
+
+
+def weighted_binary_cross_entropy(pred, label, weight, avg_factor=None):
+    if pred.dim() != label.dim():
+        label, weight = _expand_binary_labels(label, weight, pred.size(-1))
+    if avg_factor is None:
+        avg_factor = max(float((weight > 0).sum().item()), 1.0)
+    return F.binary_cross_entropy_with_logits(pred, label.float(), weight.float(), reduction="sum")[None] / avg_factor
+
+
+@LOSSES.register_module()
+class CrossEntropyLossForRcnn(nn.Module):
+    def __init__(self, use_sigmoid=False, use_mask=False, loss_weight=1.0):
+        super().__init__()
+        assert (use_sigmoid is False) or (use_mask is False)
+        self.use_sigmoid = use_sigmoid
+        self.use_mask = use_mask
+        self.loss_weight = loss_weight
+        if self.use_sigmoid:
+            self.cls_criterion = weighted_binary_cross_entropy
+        elif self.use_mask:
+            raise NotImplementedError
+        else:
+            self.cls_criterion = weighted_cross_entropy
+
+    def forward(self, cls_score, label, label_weight, *args, **kwargs):
+        return self.loss_weight * self.cls_criterion(cls_score, label, label_weight, *args, **kwargs)
+
+    execute = forward
+
+
+def cross_entropy_loss(pred, target, weight=None, avg_factor=None, reduction="mean"):
+    target = target.reshape(-1)
+    onehot = (torch.arange(pred.shape[1], device=pred.device)[None, :] == target[:, None]).to(pred.dtype)
+    output = pred - pred.max(dim=1, keepdim=True).values
+    logsum = torch.log(torch.clamp(output.exp().sum(1), 1e-30, 1e30))
+    loss = logsum - (output * onehot).sum(1)
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        avg_factor = max(loss.shape[0], 1)
+    if reduction == "mean":
+        loss = loss.sum() / avg_factor
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss
+
+
+def binary_cross_entropy_loss(pred, label, weight=None, reduction="mean", avg_factor=None, class_weight=None):
+    assert pred.dim() == label.dim()
+    assert class_weight is None
+    output, target = pred, label.float()
+    max_val = torch.clamp(-output, min=0)
+    loss = (1 - target) * output + max_val + ((-max_val).exp() + (-output - max_val).exp()).log()
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        avg_factor = max(loss.shape[0], 1)
+    if reduction == "mean":
+        loss = loss.sum() / avg_factor
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, reduction="mean", use_bce=False, loss_weight=1.0):
+        super().__init__()
+        self.reduction = reduction
+        self.loss_weight = loss_weight
+        self.use_bce = use_bce
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
+        assert reduction_override in (None, "none", "mean", "sum")
+        reduction = reduction_override if reduction_override else self.reduction
+        loss_func = binary_cross_entropy_loss if self.use_bce else cross_entropy_loss
+        return self.loss_weight * loss_func(pred, target, weight, reduction=reduction, avg_factor=avg_factor)
+
+    execute = forward

@@ -1,0 +1,401 @@
+"""S2ANet head (FAM + AlignConv + ODM).  Mirrors python/jdet/models/roi_heads/s2anet_head.py:
+`S2ANetHead` L20-629, `bbox_decode` L631-654, `AlignConv` L657-723.
+
+Layer names, channel plan (or_conv 256 -> 32x8, odm_cls tower fed by the 32-channel
+orientation-pooled map), initialisation, target dict keys and the loss bookkeeping follow the
+reference; the device work underneath is this repo's HIP path: DeformConv sampling, ARF gather,
+rotated IoU, fused max-IoU assignment, fused delta codec, rotated NMS.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
+from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
+from jdet_amd.models.boxes.box_ops import delta2bbox_rotated, rotated_box_to_poly
+from jdet_amd.models.utils.modules import ConvModule
+from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
+from jdet_amd.ops.dcn_v1 import DeformConv
+from jdet_amd.ops.nms_rotated import multiclass_nms_rotated
+from jdet_amd.ops.orn import ORConv2d, RotationInvariantPooling
+from jdet_amd.utils.general import multi_apply
+from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
+
+
+class _AttrDict(dict):
+    """dict with Config-like attribute access (missing -> None), for the default train/test cfgs"""
+
+    def __getattr__(self, name):
+        return self.get(name)
+
+    def copy(self):
+        return _AttrDict(self)
+
+
+def _cfg(d):
+    if type(d) is dict:  # plain dicts (the signature defaults); Config objects already have attribute access
+        return _AttrDict({k: _cfg(v) if isinstance(v, dict) else v for k, v in d.items()})
+    return d
+
+
+_DEFAULT_ASSIGN = dict(
+    assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1,
+                  iou_calculator=dict(type="BboxOverlaps2D_rotated")),
+    bbox_coder=dict(type="DeltaXYWHABBoxCoder", target_means=(0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1.),
+                    clip_border=True),
+    allowed_border=-1, pos_weight=-1, debug=False)
+
+
+@HEADS.register_module()
+class S2ANetHead(nn.Module):
+    def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=2, with_orconv=True,
+                 anchor_scales=[4], anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_base_sizes=None,
+                 target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0),
+                 loss_fam_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_fam_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0),
+                 loss_odm_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                 loss_odm_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0),
+                 test_cfg=dict(nms_pre=2000, min_bbox_size=0, score_thr=0.05,
+                               nms=dict(type="nms_rotated", iou_thr=0.1), max_per_img=2000),
+                 train_cfg=dict(fam_cfg=_DEFAULT_ASSIGN, odm_cfg=_DEFAULT_ASSIGN)):
+        super().__init__()
+        self.num_classes = num_classes
+        self.in_channels = in_channels
+        self.feat_channels = feat_channels
+        self.stacked_convs = stacked_convs
+        self.with_orconv = with_orconv
+        self.anchor_scales = anchor_scales
+        self.anchor_ratios = anchor_ratios
+        self.anchor_strides = list(anchor_strides)
+        self.anchor_base_sizes = list(anchor_strides) if anchor_base_sizes is None else anchor_base_sizes
+        self.target_means = target_means
+        self.target_stds = target_stds
+        self.use_sigmoid_cls = loss_odm_cls.get("use_sigmoid", False)
+        self.sampling = loss_odm_cls["type"] not in ["FocalLoss", "GHMC"]
+        self.cls_out_channels = num_classes - 1 if self.use_sigmoid_cls else num_classes
+        if self.cls_out_channels <= 0:
+            raise ValueError("num_classes={} is too small".format(num_classes))
+        self.loss_fam_cls = build_from_cfg(loss_fam_cls, LOSSES)
+        self.loss_fam_bbox = build_from_cfg(loss_fam_bbox, LOSSES)
+        self.loss_odm_cls = build_from_cfg(loss_odm_cls, LOSSES)
+        self.loss_odm_bbox = build_from_cfg(loss_odm_bbox, LOSSES)
+        self.train_cfg = _cfg(train_cfg)
+        self.test_cfg = _cfg(test_cfg)
+        self.anchor_generators = [AnchorGeneratorRotatedS2ANet(b, anchor_scales, anchor_ratios)
+                                  for b in self.anchor_base_sizes]
+        self.base_anchors = dict()   # anchor cache, keyed by (level, featmap size, device)
+        self._init_layers()
+
+    def _init_layers(self):
+        self.relu = nn.ReLU()
+        self.fam_reg_convs = nn.ModuleList()
+        self.fam_cls_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = self.in_channels if i == 0 else self.feat_channels
+            self.fam_reg_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1))
+            self.fam_cls_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1))
+        self.fam_reg = nn.Conv2d(self.feat_channels, 5, 1)
+        self.fam_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 1)
+        self.align_conv = AlignConv(self.feat_channels, self.feat_channels, kernel_size=3)
+        if self.with_orconv:
+            self.or_conv = ORConv2d(self.feat_channels, int(self.feat_channels / 8), kernel_size=3, padding=1,
+                                    arf_config=(1, 8))
+        else:
+            self.or_conv = nn.Conv2d(self.feat_channels, self.feat_channels, 3, padding=1)
+        self.or_pool = RotationInvariantPooling(256, 8)
+        self.odm_reg_convs = nn.ModuleList()
+        self.odm_cls_convs = nn.ModuleList()
+        for i in range(self.stacked_convs):
+            chn = int(self.feat_channels / 8) if i == 0 and self.with_orconv else self.feat_channels
+            self.odm_reg_convs.append(ConvModule(self.feat_channels, self.feat_channels, 3, stride=1, padding=1))
+            self.odm_cls_convs.append(ConvModule(chn, self.feat_channels, 3, stride=1, padding=1))
+        self.odm_cls = nn.Conv2d(self.feat_channels, self.cls_out_channels, 3, padding=1)
+        self.odm_reg = nn.Conv2d(self.feat_channels, 5, 3, padding=1)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.fam_reg_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.fam_cls_convs:
+            normal_init(m.conv, std=0.01)
+        bias_cls = bias_init_with_prob(0.01)
+        normal_init(self.fam_reg, std=0.01)
+        normal_init(self.fam_cls, std=0.01, bias=bias_cls)
+        self.align_conv.init_weights()
+        normal_init(self.or_conv, std=0.01)
+        for m in self.odm_reg_convs:
+            normal_init(m.conv, std=0.01)
+        for m in self.odm_cls_convs:
+            normal_init(m.conv, std=0.01)
+        normal_init(self.odm_cls, std=0.01, bias=bias_cls)
+        normal_init(self.odm_reg, std=0.01)
+
+    # ------------------------------------------------------------------ forward
+    def _init_anchors(self, level, featmap_size, device):
+        key = (level, tuple(featmap_size), str(device))
+        if key not in self.base_anchors:
+            self.base_anchors[key] = self.anchor_generators[level].grid_anchors(
+                featmap_size, self.anchor_strides[level], device=device)
+        return self.base_anchors[key]
+
+    def forward_single(self, x, stride):
+        fam_reg_feat = x
+        for conv in self.fam_reg_convs:
+            fam_reg_feat = conv(fam_reg_feat)
+        fam_bbox_pred = self.fam_reg(fam_reg_feat)
+        if self.training:   # the FAM classification tower only runs in training (L213-220)
+            fam_cls_feat = x
+            for conv in self.fam_cls_convs:
+                fam_cls_feat = conv(fam_cls_feat)
+            fam_cls_score = self.fam_cls(fam_cls_feat)
+        else:
+            fam_cls_score = None
+        num_level = self.anchor_strides.index(stride)
+        featmap_size = tuple(fam_bbox_pred.shape[-2:])
+        init_anchors = self._init_anchors(num_level, featmap_size, x.device)
+        refine_anchor = bbox_decode(fam_bbox_pred.detach(), init_anchors, self.target_means, self.target_stds)
+        align_feat = self.align_conv(x, refine_anchor.clone(), stride)
+        or_feat = self.or_conv(align_feat)
+        odm_reg_feat = or_feat
+        odm_cls_feat = self.or_pool(or_feat) if self.with_orconv else or_feat
+        for conv in self.odm_reg_convs:
+            odm_reg_feat = conv(odm_reg_feat)
+        for conv in self.odm_cls_convs:
+            odm_cls_feat = conv(odm_cls_feat)
+        odm_cls_score = self.odm_cls(odm_cls_feat)
+        odm_bbox_pred = self.odm_reg(odm_reg_feat)
+        return fam_cls_score, fam_bbox_pred, refine_anchor, odm_cls_score, odm_bbox_pred
+
+    def _valid_flags(self, featmap_sizes, img_metas, device):
+        valid_flag_list = []
+        for img_meta in img_metas:
+            multi_level_flags = []
+            all_valid = True
+            for i in range(len(featmap_sizes)):
+                anchor_stride = self.anchor_strides[i]
+                feat_h, feat_w = featmap_sizes[i]
+                w, h = img_meta["pad_shape"][:2]
+                valid_feat_h = min(int(np.ceil(h / anchor_stride)), feat_h)
+                valid_feat_w = min(int(np.ceil(w / anchor_stride)), feat_w)
+                all_valid = all_valid and valid_feat_h == feat_h and valid_feat_w == feat_w
+                multi_level_flags.append(self.anchor_generators[i].valid_flags(
+                    (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
+            # host-side fact (no device sync): every anchor is valid -> anchor_target skips the mask gather
+            img_meta["_all_valid"] = all_valid
+            valid_flag_list.append(multi_level_flags)
+        return valid_flag_list
+
+    def get_init_anchors(self, featmap_sizes, img_metas, device):
+        multi_level_anchors = [self._init_anchors(i, featmap_sizes[i], device) for i in range(len(featmap_sizes))]
+        anchor_list = [list(multi_level_anchors) for _ in range(len(img_metas))]
+        return anchor_list, self._valid_flags(featmap_sizes, img_metas, device)
+
+    def get_refine_anchors(self, featmap_sizes, refine_anchors, img_metas, is_train=True, device=None):
+        num_levels = len(featmap_sizes)
+        refine_anchors_list = []
+        for img_id in range(len(img_metas)):
+            refine_anchors_list.append([refine_anchors[i][img_id].reshape(-1, 5) for i in range(num_levels)])
+        valid_flag_list = self._valid_flags(featmap_sizes, img_metas, device) if is_train else []
+        return refine_anchors_list, valid_flag_list
+
+    # ------------------------------------------------------------------ loss
+    def loss(self, fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds, gt_bboxes,
+             gt_labels, img_metas, gt_bboxes_ignore=None):
+        cfg = self.train_cfg.copy()
+        featmap_sizes = [tuple(featmap.shape[-2:]) for featmap in odm_cls_scores]
+        assert len(featmap_sizes) == len(self.anchor_generators)
+        device = odm_cls_scores[0].device
+        anchor_list, valid_flag_list = self.get_init_anchors(featmap_sizes, img_metas, device)
+        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
+        concat_anchor_list = [torch.cat(anchor_list[i]) for i in range(len(anchor_list))]
+        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
+
+        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+        cls_reg_targets = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas, self.target_means,
+                                        self.target_stds, cfg.fam_cfg, gt_bboxes_ignore_list=gt_bboxes_ignore,
+                                        gt_labels_list=gt_labels, label_channels=label_channels,
+                                        sampling=self.sampling)
+        if cls_reg_targets is None:
+            return None
+        labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg = \
+            cls_reg_targets
+        num_total_samples = num_total_pos + num_total_neg if self.sampling else num_total_pos
+        losses_fam_cls, losses_fam_bbox = multi_apply(
+            self.loss_fam_single, fam_cls_scores, fam_bbox_preds, all_anchor_list, labels_list, label_weights_list,
+            bbox_targets_list, bbox_weights_list, num_total_samples=num_total_samples, cfg=cfg.fam_cfg)
+
+        refine_anchors_list, valid_flag_list = self.get_refine_anchors(featmap_sizes, refine_anchors, img_metas,
+                                                                       device=device)
+        num_level_anchors = [anchors.size(0) for anchors in refine_anchors_list[0]]
+        concat_anchor_list = [torch.cat(refine_anchors_list[i]) for i in range(len(refine_anchors_list))]
+        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
+        cls_reg_targets = anchor_target(refine_anchors_list, valid_flag_list, gt_bboxes, img_metas, self.target_means,
+                                        self.target_stds, cfg.odm_cfg, gt_bboxes_ignore_list=gt_bboxes_ignore,
+                                        gt_labels_list=gt_labels, label_channels=label_channels,
+                                        sampling=self.sampling)
+        if cls_reg_targets is None:
+            return None
+        (labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg) = \
+            cls_reg_targets
+        num_total_samples = num_total_pos + num_total_neg if self.sampling else num_total_pos
+        losses_odm_cls, losses_odm_bbox = multi_apply(
+            self.loss_odm_single, odm_cls_scores, odm_bbox_preds, all_anchor_list, labels_list, label_weights_list,
+            bbox_targets_list, bbox_weights_list, num_total_samples=num_total_samples, cfg=cfg.odm_cfg)
+        return dict(loss_fam_cls=losses_fam_cls, loss_fam_bbox=losses_fam_bbox, loss_odm_cls=losses_odm_cls,
+                    loss_odm_bbox=losses_odm_bbox)
+
+    def _loss_single(self, loss_cls_fn, loss_bbox_fn, cls_score, bbox_pred, anchors, labels, label_weights,
+                     bbox_targets, bbox_weights, num_total_samples, cfg):
+        labels = labels.reshape(-1)
+        label_weights = label_weights.reshape(-1)
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = loss_cls_fn(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        bbox_targets = bbox_targets.reshape(-1, 5)
+        bbox_weights = bbox_weights.reshape(-1, 5)
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 5)
+        if cfg.get("reg_decoded_bbox", False):
+            bbox_coder_cfg = cfg.get("bbox_coder", "")
+            if bbox_coder_cfg == "":
+                bbox_coder_cfg = dict(type="DeltaXYWHBBoxCoder")
+            bbox_coder = build_from_cfg(bbox_coder_cfg, BOXES)
+            bbox_pred = bbox_coder.decode(anchors.reshape(-1, 5), bbox_pred)
+        loss_bbox = loss_bbox_fn(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss_fam_single(self, fam_cls_score, fam_bbox_pred, anchors, labels, label_weights, bbox_targets,
+                        bbox_weights, num_total_samples, cfg):
+        return self._loss_single(self.loss_fam_cls, self.loss_fam_bbox, fam_cls_score, fam_bbox_pred, anchors, labels,
+                                 label_weights, bbox_targets, bbox_weights, num_total_samples, cfg)
+
+    def loss_odm_single(self, odm_cls_score, odm_bbox_pred, anchors, labels, label_weights, bbox_targets,
+                        bbox_weights, num_total_samples, cfg):
+        return self._loss_single(self.loss_odm_cls, self.loss_odm_bbox, odm_cls_score, odm_bbox_pred, anchors, labels,
+                                 label_weights, bbox_targets, bbox_weights, num_total_samples, cfg)
+
+    # ------------------------------------------------------------------ inference
+    def get_bboxes(self, fam_cls_scores, fam_bbox_preds, refine_anchors, odm_cls_scores, odm_bbox_preds, img_metas,
+                   rescale=True):
+        assert len(odm_cls_scores) == len(odm_bbox_preds)
+        cfg = self.test_cfg.copy()
+        featmap_sizes = [tuple(featmap.shape[-2:]) for featmap in odm_cls_scores]
+        num_levels = len(odm_cls_scores)
+        refine_anchors = self.get_refine_anchors(featmap_sizes, refine_anchors, img_metas, is_train=False)
+        result_list = []
+        for img_id in range(len(img_metas)):
+            cls_score_list = [odm_cls_scores[i][img_id].detach() for i in range(num_levels)]
+            bbox_pred_list = [odm_bbox_preds[i][img_id].detach() for i in range(num_levels)]
+            img_shape = img_metas[img_id]["img_shape"]
+            scale_factor = img_metas[img_id]["scale_factor"]
+            result_list.append(self.get_bboxes_single(cls_score_list, bbox_pred_list, refine_anchors[0][img_id],
+                                                      img_shape, scale_factor, cfg, rescale))
+        return result_list
+
+    def get_bboxes_single(self, cls_score_list, bbox_pred_list, mlvl_anchors, img_shape, scale_factor, cfg,
+                          rescale=False):
+        assert len(cls_score_list) == len(bbox_pred_list) == len(mlvl_anchors)
+        mlvl_bboxes, mlvl_scores = [], []
+        for cls_score, bbox_pred, anchors in zip(cls_score_list, bbox_pred_list, mlvl_anchors):
+            assert cls_score.shape[-2:] == bbox_pred.shape[-2:]
+            cls_score = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels)
+            scores = cls_score.sigmoid() if self.use_sigmoid_cls else cls_score.softmax(-1)
+            bbox_pred = bbox_pred.permute(1, 2, 0).reshape(-1, 5)
+            nms_pre = cfg.get("nms_pre", -1)
+            if nms_pre > 0 and scores.shape[0] > nms_pre:
+                max_scores = scores.max(dim=1).values if self.use_sigmoid_cls else scores[:, 1:].max(dim=1).values
+                _, topk_inds = max_scores.topk(nms_pre)
+                anchors = anchors[topk_inds, :]
+                bbox_pred = bbox_pred[topk_inds, :]
+                scores = scores[topk_inds, :]
+            mlvl_bboxes.append(delta2bbox_rotated(anchors, bbox_pred, self.target_means, self.target_stds, img_shape))
+            mlvl_scores.append(scores)
+        mlvl_bboxes = torch.cat(mlvl_bboxes)
+        if rescale:
+            mlvl_bboxes[..., :4] /= scale_factor
+        mlvl_scores = torch.cat(mlvl_scores)
+        if self.use_sigmoid_cls:
+            padding = mlvl_scores.new_zeros((mlvl_scores.shape[0], 1))
+            mlvl_scores = torch.cat([padding, mlvl_scores], dim=1)
+        det_bboxes, det_labels = multiclass_nms_rotated(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms,
+                                                        cfg.max_per_img)
+        boxes, scores = det_bboxes[:, :5], det_bboxes[:, 5]
+        return rotated_box_to_poly(boxes), scores, det_labels
+
+    def parse_targets(self, targets, is_train=True):
+        img_metas, gt_bboxes, gt_bboxes_ignore, gt_labels = [], [], [], []
+        for target in targets:
+            if is_train:
+                gt_bboxes.append(target["rboxes"])
+                gt_labels.append(target["labels"])
+                gt_bboxes_ignore.append(target["rboxes_ignore"])
+            img_metas.append(dict(img_shape=target["img_size"][::-1], scale_factor=target["scale_factor"],
+                                  pad_shape=target["pad_shape"]))
+        if not is_train:
+            return img_metas
+        return gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore
+
+    def forward(self, feats, targets):
+        outs = multi_apply(self.forward_single, feats, self.anchor_strides)
+        if self.training:
+            return self.loss(*outs, *self.parse_targets(targets))
+        return self.get_bboxes(*outs, self.parse_targets(targets, is_train=False))
+
+    execute = forward
+
+
+def bbox_decode(bbox_preds, anchors, means=[0, 0, 0, 0, 0], stds=[1, 1, 1, 1, 1]):
+    """bbox_preds (N,5,H,W), anchors (H*W,5) -> (N,H,W,5) refined anchors (s2anet_head.py:L631-654;
+    wh_ratio_clip = 1e-6).  All images in one fused decode launch."""
+    num_imgs, _, H, W = bbox_preds.shape
+    deltas = bbox_preds.permute(0, 2, 3, 1).reshape(num_imgs * H * W, 5)
+    rois = anchors.unsqueeze(0).expand(num_imgs, H * W, 5).reshape(num_imgs * H * W, 5)
+    bboxes = delta2bbox_rotated(rois, deltas, means, stds, wh_ratio_clip=1e-6)
+    return bboxes.reshape(num_imgs, H, W, 5)
+
+
+class AlignConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=3, deformable_groups=1):
+        super().__init__()
+        self.kernel_size = kernel_size
+        self.deform_conv = DeformConv(in_channels, out_channels, kernel_size=kernel_size,
+                                      padding=(kernel_size - 1) // 2, deformable_groups=deformable_groups)
+        self.relu = nn.ReLU()
+
+    def init_weights(self):
+        normal_init(self.deform_conv, std=0.01)
+
+    @torch.no_grad()
+    def get_offset(self, anchors, featmap_size, stride):
+        """anchors (N, H*W, 5) -> offsets (N, 2*k*k, H, W), (dy,dx) per tap: the k x k sampling grid of the
+        refined anchor minus the regular conv grid (s2anet_head.py:L676-713), batched over images."""
+        dtype, device = anchors.dtype, anchors.device
+        feat_h, feat_w = featmap_size
+        pad = (self.kernel_size - 1) // 2
+        idx = torch.arange(-pad, pad + 1, dtype=dtype, device=device)
+        yy, xx = torch.meshgrid(idx, idx, indexing="ij")
+        xx, yy = xx.reshape(-1), yy.reshape(-1)
+        xc = torch.arange(0, feat_w, dtype=dtype, device=device)
+        yc = torch.arange(0, feat_h, dtype=dtype, device=device)
+        yc, xc = torch.meshgrid(yc, xc, indexing="ij")
+        xc, yc = xc.reshape(-1), yc.reshape(-1)
+        x_conv = xc[:, None] + xx
+        y_conv = yc[:, None] + yy
+        x_ctr, y_ctr, w, h, a = torch.unbind(anchors, dim=-1)      # each (N, HW)
+        x_ctr, y_ctr, w, h = x_ctr / stride, y_ctr / stride, w / stride, h / stride
+        cos, sin = torch.cos(a), torch.sin(a)
+        dw, dh = w / self.kernel_size, h / self.kernel_size
+        x, y = dw[..., None] * xx, dh[..., None] * yy               # (N, HW, kk)
+        xr = cos[..., None] * x - sin[..., None] * y
+        yr = sin[..., None] * x + cos[..., None] * y
+        x_anchor, y_anchor = xr + x_ctr[..., None], yr + y_ctr[..., None]
+        offset_x = x_anchor - x_conv
+        offset_y = y_anchor - y_conv
+        offset = torch.stack([offset_y, offset_x], dim=-1)          # (N, HW, kk, 2)
+        n = anchors.shape[0]
+        return offset.reshape(n, feat_h * feat_w, -1).permute(0, 2, 1).reshape(n, -1, feat_h, feat_w)
+
+    def forward(self, x, anchors, stride):
+        num_imgs, H, W = anchors.shape[:3]
+        offset_tensor = self.get_offset(anchors.reshape(num_imgs, H * W, 5), (H, W), stride)
+        return self.relu(self.deform_conv(x, offset_tensor))
+
+    execute = forward

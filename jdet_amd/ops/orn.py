@@ -97,6 +97,9 @@ class RotationInvariantPooling(nn.Module):
         # every S2ANet checkpoint, so it stays for state_dict compatibility
         hidden = int(nInputPlane / nOrientation)
         self.conv = nn.Sequential(nn.Conv2d(hidden, nInputPlane, 1, 1), nn.BatchNorm2d(nInputPlane))
+        # never applied -> never receives a gradient; frozen so data-parallel wrappers do not wait for it
+        for p in self.conv.parameters():
+            p.requires_grad_(False)
 
     def forward(self, x):
         N, c, h, w = x.shape

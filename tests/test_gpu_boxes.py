@@ -1,0 +1,139 @@
+"""GPU parity: fused delta codec, fused MaxIoUAssigner, anchor generator, AlignConv offsets and
+anchor_target against the numpy / C++ oracles.  Integer outputs (gt_inds, labels, pos/neg sets)
+bit-exact; codec outputs within 2e-5 relative (device libm vs numpy for cos/sin/exp/log)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle as B
+from oracle import oracle as O
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_codec_vs_oracle(dev):
+    from jdet_amd.models.boxes.box_ops import bbox2delta_rotated, delta2bbox_rotated, norm_angle
+    rng = np.random.default_rng(0)
+    p, g = I.random_obbs(rng, 21824), I.random_obbs(rng, 21824)
+    m, s = (0.1, -0.2, 0.3, 0.0, 0.05), (0.1, 0.2, 0.2, 0.1, 0.5)
+    for means, stds in (((0,) * 5, (1,) * 5), (m, s)):
+        d = bbox2delta_rotated(_t(p, dev), _t(g, dev), means, stds).cpu().numpy()
+        np.testing.assert_allclose(d, B.bbox2delta_rotated(p, g, means, stds), rtol=2e-5, atol=2e-5)
+        for clip in (16 / 1000, 1e-6):
+            dd = (rng.standard_normal((21824, 15)) * 0.5).astype(np.float32)
+            out = delta2bbox_rotated(_t(p, dev), _t(dd, dev), means, stds, None, clip).cpu().numpy()
+            ref = B.delta2bbox_rotated(p, dd, means, stds, clip)
+            np.testing.assert_allclose(out[:, [0, 1, 2, 3, 5, 6, 7, 8]], ref[:, [0, 1, 2, 3, 5, 6, 7, 8]], rtol=3e-5, atol=2e-3)
+            da = np.abs(out[:, 4::5] - ref[:, 4::5])   # angles: equal modulo the wrap at the range edge
+            assert np.all((da < 1e-4) | (np.abs(da - math.pi) < 1e-4))
+    a = torch.tensor([-10., -3.2, -math.pi / 4, 0., 2.3, 9.7], device=dev)
+    np.testing.assert_allclose(norm_angle(a).cpu().numpy(), B.norm_angle(a.cpu().numpy()), atol=1e-6)
+    # differentiable torch form == fused form
+    pt, gt_ = _t(p[:100], dev), _t(g[:100], dev)
+    dt = _t((rng.standard_normal((100, 5)) * 0.3).astype(np.float32), dev).requires_grad_(True)
+    o1 = delta2bbox_rotated(pt, dt)
+    o2 = delta2bbox_rotated(pt, dt.detach())
+    assert o1.requires_grad and torch.allclose(o1, o2, rtol=1e-5, atol=1e-3)
+    o1.sum().backward()
+    assert torch.isfinite(dt.grad).all()
+
+
+@pytest.mark.parametrize("K,A", [(64, 21824), (1, 7), (3, 300), (200, 1000)])
+def test_assigner_vs_oracle(dev, K, A):
+    from jdet_amd.models.boxes.assigner import MaxIoUAssigner
+    rng = np.random.default_rng(K * 1000 + A)
+    gts = I.random_obbs(rng, K, wh=(16.0, 256.0))
+    anchors = B.grid_anchors_s2anet(8, [4], [1.0], (128, 128), 8)[rng.permutation(16384)[:A]] if A <= 16384 else \
+        np.concatenate([B.grid_anchors_s2anet(s, [4], [1.0], (1024 // s, 1024 // s), s) for s in (8, 16, 32, 64, 128)])
+    assert anchors.shape[0] == A
+    gl = rng.integers(1, 16, K).astype(np.int32)
+    ov = O.box_iou_rotated(gts, anchors)
+    for kw in (dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0),
+               dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.3, match_low_quality=True, assigned_labels_filled=-1),
+               dict(pos_iou_thr=0.7, neg_iou_thr=(0.1, 0.3), min_pos_iou=0.3, match_low_quality=False),
+               dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, gt_max_assign_all=False)):
+        asg = MaxIoUAssigner(iou_calculator=dict(type="BboxOverlaps2D_rotated"), **kw)
+        res = asg.assign(_t(anchors, dev), _t(gts, dev), None, _t(gl, dev))
+        gi, mo, lab = B.assign_wrt_overlaps(ov, kw["pos_iou_thr"], kw["neg_iou_thr"], kw.get("min_pos_iou", 0.0),
+                                            kw.get("match_low_quality", True), kw.get("gt_max_assign_all", True), gl,
+                                            kw.get("assigned_labels_filled", 0))
+        np.testing.assert_array_equal(res.gt_inds.cpu().numpy(), gi)
+        np.testing.assert_array_equal(res.max_overlaps.cpu().numpy(), mo)
+        np.testing.assert_array_equal(res.labels.cpu().numpy(), lab)
+        assert res.num_gts == K
+    asg = MaxIoUAssigner(0.5, 0.4, iou_calculator=dict(type="BboxOverlaps2D_rotated"))
+    r2 = asg.assign(_t(anchors, dev), _t(gts, dev))
+    assert r2.labels is None
+    with pytest.raises(ValueError):
+        asg.assign(_t(anchors, dev), torch.zeros((0, 5), device=dev))
+
+
+def test_hand_built_overlaps_on_device(dev):
+    from jdet_amd.models.boxes.assigner import assign_wrt_overlaps_device
+    ov = np.asarray([[0.9, 0.45, 0.3, 0.0, 0.2, 0.6], [0.1, 0.45, 0.6, 0.0, 0.2, 0.6], [0.0, 0.10, 0.1, 0.0, 0.2, 0.1]],
+                    np.float32)
+    gl = torch.tensor([7, 8, 9], dtype=torch.int32, device=dev)
+    gi, mo, lab = assign_wrt_overlaps_device(_t(ov, dev), 0.5, 0.4, 0.0, True, True, gl, 0)
+    assert gi.tolist() == [1, -1, 2, 0, 3, 2] and lab.tolist() == [7, 0, 8, 0, 9, 8]
+    gi, _, _ = assign_wrt_overlaps_device(_t(ov, dev), 0.5, 0.4, 0.0, True, False, None, 0)
+    assert gi.tolist() == [1, -1, 2, 0, 3, 1]
+    gi, _, _ = assign_wrt_overlaps_device(_t(ov, dev), 0.5, 0, 0.0, False, True, None, 0)   # int thr: no negatives
+    assert gi.tolist() == [1, -1, 2, -1, -1, 1]
+
+
+def test_anchor_generator_and_alignconv_offsets(dev):
+    from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedRetinaNet, AnchorGeneratorRotatedS2ANet
+    from jdet_amd.models.roi_heads.s2anet_head import AlignConv
+    g = AnchorGeneratorRotatedS2ANet(16, [4], [1.0])
+    a = g.grid_anchors((5, 7), 16, device=dev).cpu().numpy()
+    np.testing.assert_array_equal(a, B.grid_anchors_s2anet(16, [4], [1.0], (5, 7), 16))
+    f = g.valid_flags((5, 7), (4, 6), device=dev).cpu().numpy().reshape(5, 7)
+    assert f[:4, :6].all() and not f[4].any() and not f[:, 6].any()
+    r = AnchorGeneratorRotatedRetinaNet(8, None, [0.5, 1.0, 2.0], octave_base_scale=4, scales_per_octave=3)
+    assert r.num_base_anchors == 9
+    b = r.base_anchors.numpy()
+    np.testing.assert_allclose(b[:, 2] * b[:, 3], np.tile((8 * 4 * 2 ** (np.arange(3) / 3)) ** 2, 3), rtol=1e-5)
+    np.testing.assert_allclose(b[:3, 3] / b[:3, 2], 0.5, rtol=1e-5)     # ratio-major, then scale
+    rng = np.random.default_rng(1)
+    H, W, s = 9, 11, 16
+    anc = I.random_obbs(rng, 2 * H * W, extent=W * s, wh=(16.0, 128.0)).reshape(2, H * W, 5)
+    off = AlignConv(4, 4).to(dev).get_offset(_t(anc, dev), (H, W), s).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_allclose(off[i], B.align_conv_offsets(anc[i], (H, W), s), rtol=1e-5, atol=2e-5)
+
+
+def test_anchor_target_vs_oracle(dev):
+    """S2ANet FAM targets for one 1024x1024 image (21,824 anchors, 64 gts): labels / weights / pos / neg sets
+    bit-exact, regression targets 2e-5."""
+    from jdet_amd.models.boxes.anchor_target import anchor_target
+    from jdet_amd.models.roi_heads.s2anet_head import _DEFAULT_ASSIGN, _cfg
+    rng = np.random.default_rng(2)
+    strides = (8, 16, 32, 64, 128)
+    lv = [B.grid_anchors_s2anet(s, [4], [1.0], (1024 // s, 1024 // s), s) for s in strides]
+    gts = [I.random_obbs(rng, 64, wh=(16.0, 256.0)), I.random_obbs(rng, 30, wh=(16.0, 256.0))]
+    gls = [rng.integers(1, 16, 64).astype(np.int32), rng.integers(1, 16, 30).astype(np.int32)]
+    anchor_list = [[_t(a, dev) for a in lv] for _ in range(2)]
+    valid = [[torch.ones(a.shape[0], dtype=torch.bool, device=dev) for a in lv] for _ in range(2)]
+    metas = [dict(img_shape=(1024, 1024), pad_shape=(1024, 1024)) for _ in range(2)]
+    out = anchor_target(anchor_list, valid, [_t(g, dev) for g in gts], metas, (0,) * 5, (1,) * 5, _cfg(_DEFAULT_ASSIGN),
+                        gt_labels_list=[_t(g, dev) for g in gls], label_channels=15, sampling=False)
+    labels_list, lw_list, bt_list, bw_list, npos, nneg = out
+    flat = np.concatenate(lv)
+    tot_pos = tot_neg = 0
+    for i in range(2):
+        lab, lw, bt, bw, pos, neg = B.anchor_target_single(flat, gts[i], gls[i])
+        tot_pos += max(len(pos), 1)
+        tot_neg += max(len(neg), 1)
+        np.testing.assert_array_equal(torch.cat([l[i] for l in labels_list]).cpu().numpy(), lab)
+        np.testing.assert_array_equal(torch.cat([l[i] for l in lw_list]).cpu().numpy(), lw)
+        np.testing.assert_array_equal(torch.cat([l[i] for l in bw_list]).cpu().numpy(), bw)
+        np.testing.assert_allclose(torch.cat([l[i] for l in bt_list]).cpu().numpy(), bt, rtol=2e-5, atol=2e-5)
+    assert (npos, nneg) == (tot_pos, tot_neg)
+    assert [tuple(l.shape) for l in labels_list] == [(2, (1024 // s) ** 2) for s in strides]

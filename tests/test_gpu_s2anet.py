@@ -1,0 +1,82 @@
+"""GPU: the S2ANet detector built from the reference's own config runs a train step and an inference
+pass on the HIP path (DeformConv sampling, ARF, rotated IoU, fused assignment / codec, rotated NMS)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import inputs as I
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev):
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.utils.registry import MODELS, build_from_cfg
+    cfg = dict(
+        type="S2ANet",
+        backbone=dict(type="Resnet50", frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"],
+                      pretrained=True),
+        neck=dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+                  add_extra_convs="on_input", num_outs=5),
+        bbox_head=dict(type="S2ANetHead", num_classes=16, in_channels=256, feat_channels=256, stacked_convs=2,
+                       with_orconv=True, anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_scales=[4]))
+    torch.manual_seed(0)
+    return build_from_cfg(cfg, MODELS).to(dev)
+
+
+def _targets(n, size, dev, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = 12
+        out.append(dict(rboxes=torch.from_numpy(I.random_obbs(rng, k, extent=size, wh=(16.0, size / 4))).to(dev),
+                        labels=torch.from_numpy(rng.integers(1, 16, k).astype(np.int32)).to(dev),
+                        rboxes_ignore=torch.zeros((0, 5), device=dev), img_size=(size, size), scale_factor=1.0,
+                        pad_shape=(size, size)))
+    return out
+
+
+def test_train_step_and_inference(dev):
+    from jdet_amd.utils.general import parse_losses
+    m = _model(dev)
+    m.train()
+    size = 256
+    imgs = torch.randn(2, 3, size, size, device=dev)
+    losses = m(imgs, _targets(2, size, dev))
+    assert set(losses) == {"loss_fam_cls", "loss_fam_bbox", "loss_odm_cls", "loss_odm_bbox"}
+    total, parsed = parse_losses(losses)
+    assert torch.isfinite(total) and total.item() > 0
+    total.backward()
+    g = {n: p.grad for n, p in m.named_parameters() if p.requires_grad}
+    assert all(v is not None and torch.isfinite(v).all() for v in g.values()), [n for n, v in g.items() if v is None]
+    assert g["bbox_head.align_conv.deform_conv.weight"].abs().sum() > 0
+    assert g["bbox_head.or_conv.weight"].abs().sum() > 0
+    assert g["backbone.layer2.0.conv1.weight"].abs().sum() > 0
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("backbone.layer1"))
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("bbox_head.or_pool.conv"))
+    # focal-loss prior: at init the classification losses are ~ 1.1-1.2 per positive (bias_init_with_prob(0.01))
+    assert 0.3 < parsed["loss_odm_cls"].item() < 5.0
+    m.eval()
+    with torch.no_grad():
+        res = m(imgs, _targets(2, size, dev))
+    assert len(res) == 2
+    for polys, scores, labels in res:
+        assert polys.shape[1] == 8 and polys.shape[0] == scores.shape[0] == labels.shape[0]
+
+
+def test_runner_train_steps_reduce_loss(dev):
+    """Runner (SGD + clip + StepLR warm-up) on a fixed synthetic batch: the loss goes down and stays finite."""
+    from jdet_amd.runner import Runner, synthetic_batch
+    import bench
+    torch.manual_seed(0)
+    r = Runner(bench.S2ANET_CFG, device=dev)
+    images, targets = synthetic_batch(2, 256, dev, seed=3, num_gts=16)
+    first = None
+    for i in range(12):
+        loss, parts = r.train_step(images, targets)
+        assert torch.isfinite(loss)
+        first = loss.item() if first is None else first
+    assert loss.item() < first
+    assert abs(r.optimizer.cur_lr() - 0.0025 * (1 - (1 - 11 / 500) * (1 - 1 / 3))) < 1e-9
