@@ -79,12 +79,18 @@ int jdet_roi_spatial_order(const float* rois, int R, int roi_cols, float spatial
                            int H, int W, int32_t* order, int32_t* workspace, jdet_stream_t stream);
 
 /* RoIAlign backward w.r.t. the feature map.  Replaces roi_align_rotated.py:L286-307 (and the
- * _v1 / riroi / hbb twins).  grad_in_nhwc (N,H,W,C) is zero-filled then accumulated with
- * hardware fp32 atomics (order-nondeterministic in the last bits, as in the reference). */
+ * _v1 / riroi / hbb twins).  grad_in_nhwc (N,H,W,C) is fully overwritten.
+ * With a workspace of jdet_roi_align_backward_workspace(...) bytes the scatter is inverted once on the
+ * (roi, sample, tap) index space and executed as a sorted GATHER (integer atomics only, one store per
+ * pixel); with workspace = NULL, or when the query returns 0 (RiRoIAlign, sample_num <= 0, C % 4 != 0),
+ * it is the reference's scheme: zero-fill + hardware fp32 atomics.  Either way the last bits depend on
+ * accumulation order, as in the reference. */
+size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int C, int H, int W, int PH, int PW,
+                                         int sample_num);
 int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,
                             int C, int H, int W, int PH, int PW, float spatial_scale,
                             int sample_num, int n_orient, const int32_t* order, float* grad_in_nhwc,
-                            jdet_stream_t stream);
+                            void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
 /* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and
  * box_iou_rotated_v1.py:L512 (the python-side "too small" zeroing L515-523 stays in the

@@ -75,8 +75,10 @@ class RoIAlignFunction(torch.autograd.Function):
         R = rois_c.shape[0]
         grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
                               memory_format=torch.channels_last)
+        wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device) if wsb else None
         L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
                                                 scale, sample_num, n_orient, L.ptr(order), L.ptr(grad_in),
-                                                L.stream_ptr(g)),
+                                                L.ptr(ws), wsb, L.stream_ptr(g)),
                 "jdet_roi_align_backward")
         return grad_in, None, None, None, None, None, None

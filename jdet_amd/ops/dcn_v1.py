@@ -93,19 +93,25 @@ class DeformConvFunction(torch.autograd.Function):
         Ho, Wo = _out_hw(H, W, kh, kw, padding, stride, dilation)
         go = L.f32c(grad_output)
         wg = w.view(groups, Cout // groups, Cin_g * kh * kw)
-        grad_input = torch.empty_like(x)
-        grad_offset = torch.empty_like(off)
-        grad_weight = torch.zeros_like(wg)
+        need_x, need_off, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        grad_input = torch.empty_like(x) if need_x else None
+        grad_offset = torch.empty_like(off) if need_off else None   # AlignConv offsets are detached: skipped
+        grad_weight = torch.zeros_like(wg) if need_w else None
         for e in range(B // step):
             sl = slice(e * step, (e + 1) * step)
             xs, os_ = x[sl], off[sl]
             g = go[sl].permute(1, 0, 2, 3).reshape(groups, Cout // groups, step * Ho * Wo)
-            columns = torch.bmm(wg.transpose(1, 2), g).view(Cin * kh * kw, step, Ho, Wo)
-            grad_offset[sl] = deformable_col2im_coord(columns, xs, os_, kh, kw, padding, stride, dilation, dg)
-            grad_input[sl] = deformable_col2im(columns, os_, xs.shape, kh, kw, padding, stride, dilation, dg)
-            col = deformable_im2col(xs, os_, kh, kw, padding, stride, dilation, dg)
-            grad_weight += torch.bmm(g, col.view(groups, Cin_g * kh * kw, step * Ho * Wo).transpose(1, 2))
-        return grad_input, grad_offset, grad_weight.view_as(w), None, None, None, None, None, None
+            if need_x or need_off:
+                columns = torch.bmm(wg.transpose(1, 2), g).view(Cin * kh * kw, step, Ho, Wo)
+                if need_off:
+                    grad_offset[sl] = deformable_col2im_coord(columns, xs, os_, kh, kw, padding, stride, dilation, dg)
+                if need_x:
+                    grad_input[sl] = deformable_col2im(columns, os_, xs.shape, kh, kw, padding, stride, dilation, dg)
+            if need_w:
+                col = deformable_im2col(xs, os_, kh, kw, padding, stride, dilation, dg)
+                grad_weight += torch.bmm(g, col.view(groups, Cin_g * kh * kw, step * Ho * Wo).transpose(1, 2))
+        return (grad_input, grad_offset, grad_weight.view_as(w) if need_w else None, None, None, None, None, None,
+                None)
 
 
 def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
