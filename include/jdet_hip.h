@@ -63,6 +63,10 @@ int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float* y, jdet
  *   sample_num : >0 fixed grid, <=0 adaptive ceil(roi_size / pooled_size)
  *   n_orient   : RiRoIAlign only (C % n_orient == 0); pass 1 otherwise
  *   order      : optional (R) int32 permutation from jdet_roi_spatial_order, or NULL
+ * A RoI whose batch index is negative is skipped: its rows of `out` are left untouched and it adds
+ * nothing in backward.  (FPN level routing: call once per level on the SAME `out`, with the batch
+ * index of off-level RoIs set to -1 -- no mask / gather / scatter-add round trip and no host sync,
+ * cf. oriented_single_level.py:L105-112.)
  * Limits: PH*PW <= 256; any C >= 1 (C % 4 == 0 takes the vector path). */
 int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, int H, int W,
                            const float* rois, int R, int PH, int PW, float spatial_scale,

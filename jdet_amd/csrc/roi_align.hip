@@ -184,6 +184,7 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
   const int lane = threadIdx.x & 63;
   __amdgpu_buffer_rsrc_t rsrc;
   const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc);
+  if (g.batch < 0) return;  // masked RoI (belongs to another pyramid level): its output rows are not ours
   direct_chunk<VARIANT, NW, SG, ABL>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out);
   __syncthreads();
   float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_cached_kernel(
   const int tid = threadIdx.x;
   __amdgpu_buffer_rsrc_t rsrc;
   const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc);
+  if (g.batch < 0) return;  // masked RoI
   const int spb = g.grid_h * g.grid_w;
   const int S = nbins * spb;
   const int pix_bytes = C * 4;
@@ -400,6 +402,7 @@ __global__ __launch_bounds__(kBlock) void roi_align_fwd_kernel(
 
   const RoiGeom g = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH,
                                       PW, nO, false);
+  if (g.batch < 0) return;  // masked RoI (block-uniform)
   const float* __restrict__ img = feat + (size_t)g.batch * H * W * C;
 
   int src0[4], src1[4];
@@ -509,6 +512,7 @@ __global__ __launch_bounds__(kBlock) void roi_align_bwd_kernel(
   const int cc = min(kChunkC, C - c0);
   const int nbins = PH * PW;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)rois[(size_t)r * ROI_COLS] < 0) return;  // masked RoI (block-uniform, before any barrier)
 
   // stage grad_out[r, c0:c0+cc, :, :] (contiguous) into LDS
   {

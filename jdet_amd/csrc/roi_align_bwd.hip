@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void bwd_taps_kernel(const float* __restrict__
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     int key = -1;
-    if (sm.valid && w[k] != 0.f) {
+    if (sm.valid && w[k] != 0.f && g.batch >= 0) {  // batch < 0: masked RoI
       key = base + o[k];
       atomicAdd(&counts[key], 1);
     }

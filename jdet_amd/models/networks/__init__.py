@@ -1,1 +1,2 @@
+from .rcnn import RCNN, OrientedRCNN  # noqa: F401
 from .s2anet import S2ANet  # noqa: F401

@@ -1,0 +1,238 @@
+"""Oriented R-CNN RPN head.  Mirrors python/jdet/models/roi_heads/oriented_rpn_head.py:L9-492: 3x3 conv +
+1x1 cls (A*num_classes) + 1x1 reg (A*6); targets by MaxIoUAssigner on horizontal anchors vs the gts'
+enclosing boxes, RandomSampler(256), MidpointOffsetCoder; proposals by per-level top-k, midpoint-offset
+decode, horizontal NMS on the enclosing boxes with the per-level coordinate offset trick."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from jdet_amd.models.boxes.anchor_target import anchor_inside_flags, images_to_levels
+from jdet_amd.ops.bbox_transforms import bbox2type, get_bbox_dim, get_bbox_type, obb2hbb
+from jdet_amd.ops.nms import nms_dets
+from jdet_amd.utils.general import multi_apply
+from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
+
+
+@HEADS.register_module()
+class OrientedRPNHead(nn.Module):
+    def __init__(self, in_channels, num_classes=1, min_bbox_size=0, nms_thresh=0.8, nms_pre=2000, nms_post=2000,
+                 feat_channels=256, bbox_type="obb", reg_dim=6, background_label=0, reg_decoded_bbox=False,
+                 pos_weight=-1,
+                 anchor_generator=dict(type="AnchorGenerator", scales=[8], ratios=[0.5, 1.0, 2.0],
+                                       strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type="MidpointOffsetCoder", target_means=[.0, .0, .0, .0, .0, .0],
+                                 target_stds=[1.0, 1.0, 1.0, 1.0, 0.5, 0.5]),
+                 loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0),
+                 assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3,
+                               ignore_iof_thr=-1, match_low_quality=True, assigned_labels_filled=-1),
+                 sampler=dict(type="RandomSampler", num=256, pos_fraction=0.5, neg_pos_ub=-1,
+                              add_gt_as_proposals=False)):
+        super().__init__()
+        self.min_bbox_size = min_bbox_size
+        self.nms_thresh = nms_thresh
+        self.nms_pre = nms_pre
+        self.nms_post = nms_post
+        self.in_channels = in_channels
+        self.feat_channels = feat_channels
+        self.num_classes = num_classes
+        self.unmap_outputs = True
+        self.bbox_type = bbox_type
+        self.reg_dim = reg_dim
+        self.pos_weight = pos_weight
+        self.use_sigmoid_cls = loss_cls.get("use_sigmoid", False)
+        self.sampling = loss_cls["type"] not in ["FocalLoss", "GHMC", "QualityFocalLoss"]
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.background_label = num_classes if background_label is None else background_label
+        assert self.background_label == 0 or self.background_label == num_classes
+        self.bbox_coder = build_from_cfg(bbox_coder, BOXES)
+        self.loss_cls = build_from_cfg(loss_cls, LOSSES)
+        self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
+        self.assigner = build_from_cfg(assigner, BOXES)
+        self.sampler = build_from_cfg(sampler, BOXES)
+        self.anchor_generator = build_from_cfg(anchor_generator, BOXES)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        self._init_layers()
+
+    def _init_layers(self):
+        self.rpn_conv = nn.Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(self.feat_channels, self.num_anchors * self.num_classes, 1)
+        self.rpn_reg = nn.Conv2d(self.feat_channels, self.num_anchors * 6, 1)
+
+    @staticmethod
+    def unmap(data, count, inds, fill=0):
+        if data.dim() == 1:
+            ret = torch.full((count,), fill, dtype=data.dtype, device=data.device)
+            ret[inds.bool()] = data
+        else:
+            ret = torch.full((count,) + tuple(data.shape[1:]), fill, dtype=data.dtype, device=data.device)
+            ret[inds.bool(), :] = data
+        return ret
+
+    def forward_single(self, x):
+        x = F.relu(self.rpn_conv(x))
+        return self.rpn_cls(x), self.rpn_reg(x)
+
+    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape):
+        level_ids, mlvl_scores, mlvl_valid_anchors, mlvl_bbox_pred = [], [], [], []
+        for idx in range(len(cls_scores)):
+            rpn_cls_score, rpn_bbox_pred = cls_scores[idx], bbox_preds[idx]
+            assert rpn_cls_score.shape[-2:] == rpn_bbox_pred.shape[-2:]
+            rpn_cls_score = rpn_cls_score.permute(1, 2, 0)
+            if self.use_sigmoid_cls:
+                scores = rpn_cls_score.reshape(-1).sigmoid()
+            else:
+                scores = rpn_cls_score.reshape(-1, 2).softmax(dim=1)[:, 1]
+            rpn_bbox_pred = rpn_bbox_pred.permute(1, 2, 0).reshape(-1, self.reg_dim)
+            anchors = mlvl_anchors[idx]
+            if self.nms_pre > 0 and scores.shape[0] > self.nms_pre:
+                ranked_scores, rank_inds = scores.sort(descending=True, stable=True)
+                topk_inds = rank_inds[:self.nms_pre]
+                scores = ranked_scores[:self.nms_pre]
+                rpn_bbox_pred = rpn_bbox_pred[topk_inds, :]
+                anchors = anchors[topk_inds, :]
+            mlvl_scores.append(scores)
+            mlvl_bbox_pred.append(rpn_bbox_pred)
+            mlvl_valid_anchors.append(anchors)
+            level_ids.append(torch.full((scores.size(0),), idx, dtype=torch.long, device=scores.device))
+        anchors = torch.cat(mlvl_valid_anchors)
+        rpn_bbox_pred = torch.cat(mlvl_bbox_pred)
+        scores = torch.cat(mlvl_scores)
+        proposals = self.bbox_coder.decode(anchors, rpn_bbox_pred, max_shape=img_shape)
+        ids = torch.cat(level_ids)
+        if self.min_bbox_size >= 0:
+            w, h = proposals[:, 2], proposals[:, 3]
+            valid_mask = (w > self.min_bbox_size) & (h > self.min_bbox_size)
+            if not bool(valid_mask.all()):
+                proposals, scores, ids = proposals[valid_mask], scores[valid_mask], ids[valid_mask]
+        hproposals = obb2hbb(proposals)
+        max_coordinate = hproposals.max() - hproposals.min()
+        offsets = ids.to(hproposals.dtype) * (max_coordinate + 1)   # per-level NMS via coordinate offsets
+        hproposals = hproposals + offsets[:, None]
+        keep = nms_dets(torch.cat([hproposals, scores.unsqueeze(1)], dim=1), self.nms_thresh)
+        dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[keep, :]
+        return dets[:self.nms_post]
+
+    def get_bboxes(self, cls_scores, bbox_preds, targets):
+        assert len(cls_scores) == len(bbox_preds)
+        num_levels = len(cls_scores)
+        featmap_sizes = [tuple(cls_scores[i].shape[-2:]) for i in range(num_levels)]
+        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=cls_scores[0].device)
+        result_list = []
+        for img_id, target in enumerate(targets):
+            cls_score_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
+            bbox_pred_list = [bbox_preds[i][img_id].detach() for i in range(num_levels)]
+            result_list.append(self._get_bboxes_single(cls_score_list, bbox_pred_list, mlvl_anchors,
+                                                       target["img_size"]))
+        return result_list
+
+    def _get_targets_single(self, anchors_list, valid_flag_list, target):
+        if target["rboxes"] is None:
+            gt_bboxes = None
+        else:
+            gt_bboxes = target["rboxes"].clone()
+            gt_bboxes[:, -1] *= -1     # Oriented R-CNN angle convention
+        if target.get("rboxes_ignore") is None or target["rboxes_ignore"].numel() == 0:
+            gt_bboxes_ignore = None
+        else:
+            gt_bboxes_ignore = target["rboxes_ignore"].clone()
+            gt_bboxes_ignore[:, -1] *= -1
+        gt_labels = None
+        flat_anchors = torch.cat(anchors_list)
+        valid_flags = torch.cat(valid_flag_list)
+        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, target["img_size"][:2], allowed_border=0)
+        if not bool(inside_flags.any()):
+            return (None,) * 7
+        anchors = flat_anchors[inside_flags, :]
+        anchor_bbox_type = get_bbox_type(anchors)
+        gt_bbox_type = get_bbox_type(gt_bboxes)
+        target_bboxes = bbox2type(gt_bboxes, anchor_bbox_type)
+        target_bboxes_ignore = None if gt_bboxes_ignore is None or gt_bboxes_ignore.numel() == 0 else \
+            bbox2type(gt_bboxes_ignore, anchor_bbox_type)
+        assign_result = self.assigner.assign(anchors, target_bboxes, target_bboxes_ignore,
+                                             None if self.sampling else gt_labels)
+        sampling_result = self.sampler.sample(assign_result, anchors, target_bboxes)
+        if anchor_bbox_type != gt_bbox_type:
+            if gt_bboxes.numel() == 0:
+                sampling_result.pos_gt_bboxes = gt_bboxes.new_empty((0, get_bbox_dim(gt_bbox_type)))
+            else:
+                sampling_result.pos_gt_bboxes = gt_bboxes[sampling_result.pos_assigned_gt_inds, :]
+        num_valid_anchors = anchors.shape[0]
+        bbox_targets = anchors.new_zeros((anchors.size(0), self.reg_dim))
+        bbox_weights = anchors.new_zeros((anchors.size(0), self.reg_dim))
+        labels = torch.full((num_valid_anchors,), self.background_label, dtype=torch.long, device=anchors.device)
+        label_weights = anchors.new_zeros((num_valid_anchors,))
+        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
+        if len(pos_inds) > 0:
+            if not self.reg_decoded_bbox:
+                pos_bbox_targets = self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
+            else:
+                pos_bbox_targets = sampling_result.pos_gt_bboxes
+            bbox_targets[pos_inds, :] = pos_bbox_targets
+            bbox_weights[pos_inds, :] = 1.0
+            if gt_labels is None:
+                labels[pos_inds] = 1
+            else:
+                labels[pos_inds] = gt_labels[sampling_result.pos_assigned_gt_inds]
+            label_weights[pos_inds] = 1.0 if self.pos_weight <= 0 else self.pos_weight
+        if len(neg_inds) > 0:
+            label_weights[neg_inds] = 1.0
+        if self.unmap_outputs:
+            num_total_anchors = flat_anchors.size(0)
+            labels = self.unmap(labels, num_total_anchors, inside_flags, fill=self.background_label)
+            label_weights = self.unmap(label_weights, num_total_anchors, inside_flags)
+            bbox_targets = self.unmap(bbox_targets, num_total_anchors, inside_flags)
+            bbox_weights = self.unmap(bbox_weights, num_total_anchors, inside_flags)
+        return (labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, sampling_result)
+
+    def get_targets(self, anchor_list, valid_flag_list, targets):
+        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
+        (all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_inds_list, neg_inds_list,
+         sampling_results_list) = multi_apply(self._get_targets_single, anchor_list, valid_flag_list, targets)
+        num_total_pos = sum([max(inds.numel(), 1) for inds in pos_inds_list])
+        num_total_neg = sum([max(inds.numel(), 1) for inds in neg_inds_list])
+        return (images_to_levels(all_labels, num_level_anchors), images_to_levels(all_label_weights, num_level_anchors),
+                images_to_levels(all_bbox_targets, num_level_anchors),
+                images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
+
+    def loss_single(self, cls_score, bbox_pred, anchors, labels, label_weights, bbox_targets, bbox_weights,
+                    num_total_samples):
+        labels = labels.reshape(-1)
+        label_weights = label_weights.reshape(-1)
+        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        bbox_targets = bbox_targets.reshape(-1, self.reg_dim)
+        bbox_weights = bbox_weights.reshape(-1, self.reg_dim)
+        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, self.reg_dim)
+        if self.reg_decoded_bbox:
+            bbox_pred = self.bbox_coder.decode(anchors.reshape(-1, anchors.size(-1)), bbox_pred)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss(self, cls_scores, bbox_preds, targets):
+        featmap_sizes = [tuple(featmap.shape[-2:]) for featmap in cls_scores]
+        assert len(featmap_sizes) == self.anchor_generator.num_levels
+        device = cls_scores[0].device
+        multi_level_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=device)
+        anchor_list = [multi_level_anchors for _ in range(len(targets))]
+        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, target["pad_shape"], device=device)
+                           for target in targets]
+        labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg = \
+            self.get_targets(anchor_list, valid_flag_list, targets)
+        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
+        concat_anchor_list = [torch.cat(anchor_list[i]) for i in range(len(anchor_list))]
+        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
+        num_total_samples = num_total_pos + num_total_neg
+        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list,
+                                              label_weights_list, bbox_targets_list, bbox_weights_list,
+                                              num_total_samples=num_total_samples)
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
+
+    def forward(self, features, targets):
+        outs = multi_apply(self.forward_single, features)
+        losses = self.loss(*outs, targets) if self.training else dict()
+        proposals = self.get_bboxes(*outs, targets)
+        return proposals, losses
+
+    execute = forward

@@ -82,3 +82,67 @@ class RoIAlignFunction(torch.autograd.Function):
                                                 L.ptr(ws), wsb, L.stream_ptr(g)),
                 "jdet_roi_align_backward")
         return grad_in, None, None, None, None, None, None
+
+
+class MultiLevelRoIAlignFunction(torch.autograd.Function):
+    """FPN-routed RoIAlign: every RoI is pooled from the pyramid level `target_lvls[r]`.
+
+    The reference (oriented_single_level.py:L91-114, rbox_single_level.py:L75-95, single_level.py:L70-85)
+    loops over levels with a boolean mask, an `any_()` host sync, a gather, the kernel and a masked
+    `+=`.  Here each level is one launch over ALL RoIs on the SAME output buffer, with off-level RoIs
+    masked by a negative batch index (skipped inside the kernel): no sync, no gather / scatter-add.
+    forward(rois, target_lvls, cfg, *feats) -> (R, C, PH, PW); gradients flow to every level map.
+    """
+
+    @staticmethod
+    def forward(ctx, rois, target_lvls, cfg, *feats):
+        variant, output_size, scales, sample_num, n_orient = cfg
+        L.need_device(rois, *feats)
+        PH, PW = output_size
+        rois_c = L.f32c(rois)
+        R = rois_c.shape[0]
+        C = feats[0].shape[1]
+        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device)
+        lvl = target_lvls.to(rois_c.device)
+        masked, shapes = [], []
+        for i, f in enumerate(feats):
+            fm = to_nhwc(f)
+            N, Ci, H, W = fm.shape
+            assert Ci == C
+            r_i = rois_c.clone()
+            r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
+            if R:
+                L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
+                                                       float(scales[i]), int(sample_num), int(n_orient), None,
+                                                       L.ptr(out), L.stream_ptr(fm)), "jdet_roi_align_forward")
+            masked.append(r_i)
+            shapes.append((N, C, H, W))
+        ctx.save_for_backward(*masked)
+        ctx.cfg = (variant, PH, PW, scales, int(sample_num), int(n_orient), shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        masked = ctx.saved_tensors
+        variant, PH, PW, scales, sample_num, n_orient, shapes = ctx.cfg
+        g = L.f32c(grad_output)
+        grads = []
+        for i, (r_i, (N, C, H, W)) in enumerate(zip(masked, shapes)):
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+                continue
+            R = r_i.shape[0]
+            grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
+                                  memory_format=torch.channels_last)
+            wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device) if wsb else None
+            L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(r_i), R, N, C, H, W, PH, PW,
+                                                    float(scales[i]), sample_num, n_orient, None, L.ptr(grad_in),
+                                                    L.ptr(ws), wsb, L.stream_ptr(g)), "jdet_roi_align_backward")
+            grads.append(grad_in)
+        return (None, None, None, *grads)
+
+
+def multi_level_roi_align(variant, feats, rois, target_lvls, scales, output_size, sample_num, n_orient=1):
+    return MultiLevelRoIAlignFunction.apply(rois, target_lvls, (variant, _pair(output_size), tuple(scales),
+                                                               sample_num, n_orient), *feats)

@@ -1,0 +1,36 @@
+"""Horizontal NMS.  Mirrors python/jdet/ops/nms.py:L4-9 (`nms(boxes, scores, thresh)` -> `jt.nms`).
+
+`jt.nms` is a Jittor builtin with no source in the reference tree: **parity unpinned** (SURVEY 8c).
+Documented assumption: standard greedy NMS, suppress when IoU > thresh, no "+1" pixel convention,
+kept indices returned in descending-score order.  It runs on the same device path as rotated NMS
+(axis-aligned boxes are rotated boxes with theta = 0): tile bitmask kernel + on-device scan.
+"""
+import torch
+
+from .. import _lib as L
+
+
+def nms(boxes, scores, thresh):
+    assert boxes.shape[-1] == 4 and len(scores) == len(boxes)
+    if scores.dim() == 2:
+        scores = scores[:, 0]
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device)
+    L.need_device(boxes, scores)
+    b = boxes.float()
+    obb = torch.stack([(b[:, 0] + b[:, 2]) * 0.5, (b[:, 1] + b[:, 3]) * 0.5, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+                       torch.zeros_like(b[:, 0])], dim=1).contiguous()
+    order = torch.argsort(scores.float(), descending=True, stable=True)
+    o32 = order.to(torch.int32).contiguous()
+    keep = torch.empty((n,), dtype=torch.uint8, device=b.device)
+    wsb = L.lib().jdet_nms_rotated_workspace(n)
+    ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=b.device)
+    L.check(L.lib().jdet_nms_rotated(L.ptr(obb), n, 5, L.ptr(o32), float(thresh), 0, 0, L.ptr(keep), L.ptr(ws), wsb,
+                                     L.stream_ptr(b)), "jdet_nms_rotated (horizontal)")
+    return order[keep[order].bool()]
+
+
+def nms_dets(dets, thresh):
+    """`jt.nms(dets (n,5) [x1,y1,x2,y2,score], thresh)`"""
+    return nms(dets[:, :4], dets[:, 4], thresh)
