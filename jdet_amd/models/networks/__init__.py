@@ -1,2 +1,3 @@
 from .rcnn import RCNN, OrientedRCNN  # noqa: F401
 from .s2anet import S2ANet  # noqa: F401
+from .rotated_retinanet import RotatedRetinaNet  # noqa: F401

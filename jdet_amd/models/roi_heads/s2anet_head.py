@@ -6,20 +6,20 @@ orientation-pooled map), initialisation, target dict keys and the loss bookkeepi
 reference; the device work underneath is this repo's HIP path: DeformConv sampling, ARF gather,
 rotated IoU, fused max-IoU assignment, fused delta codec, rotated NMS.
 """
-import numpy as np
 import torch
 from torch import nn
 
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
-from jdet_amd.models.boxes.box_ops import delta2bbox_rotated, rotated_box_to_poly
+from jdet_amd.models.boxes.box_ops import delta2bbox_rotated
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.ops.dcn_v1 import DeformConv
-from jdet_amd.ops.nms_rotated import multiclass_nms_rotated
 from jdet_amd.ops.orn import ORConv2d, RotationInvariantPooling
 from jdet_amd.utils.general import multi_apply
-from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
+from jdet_amd.utils.registry import HEADS, LOSSES, build_from_cfg
+
+from ._anchor_head_common import RotatedAnchorHeadMixin
 
 
 class _AttrDict(dict):
@@ -47,7 +47,7 @@ _DEFAULT_ASSIGN = dict(
 
 
 @HEADS.register_module()
-class S2ANetHead(nn.Module):
+class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
     def __init__(self, num_classes, in_channels, feat_channels=256, stacked_convs=2, with_orconv=True,
                  anchor_scales=[4], anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_base_sizes=None,
                  target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0),
@@ -131,13 +131,6 @@ class S2ANetHead(nn.Module):
         normal_init(self.odm_reg, std=0.01)
 
     # ------------------------------------------------------------------ forward
-    def _init_anchors(self, level, featmap_size, device):
-        key = (level, tuple(featmap_size), str(device))
-        if key not in self.base_anchors:
-            self.base_anchors[key] = self.anchor_generators[level].grid_anchors(
-                featmap_size, self.anchor_strides[level], device=device)
-        return self.base_anchors[key]
-
     def forward_single(self, x, stride):
         fam_reg_feat = x
         for conv in self.fam_reg_convs:
@@ -165,30 +158,6 @@ class S2ANetHead(nn.Module):
         odm_cls_score = self.odm_cls(odm_cls_feat)
         odm_bbox_pred = self.odm_reg(odm_reg_feat)
         return fam_cls_score, fam_bbox_pred, refine_anchor, odm_cls_score, odm_bbox_pred
-
-    def _valid_flags(self, featmap_sizes, img_metas, device):
-        valid_flag_list = []
-        for img_meta in img_metas:
-            multi_level_flags = []
-            all_valid = True
-            for i in range(len(featmap_sizes)):
-                anchor_stride = self.anchor_strides[i]
-                feat_h, feat_w = featmap_sizes[i]
-                w, h = img_meta["pad_shape"][:2]
-                valid_feat_h = min(int(np.ceil(h / anchor_stride)), feat_h)
-                valid_feat_w = min(int(np.ceil(w / anchor_stride)), feat_w)
-                all_valid = all_valid and valid_feat_h == feat_h and valid_feat_w == feat_w
-                multi_level_flags.append(self.anchor_generators[i].valid_flags(
-                    (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
-            # host-side fact (no device sync): every anchor is valid -> anchor_target skips the mask gather
-            img_meta["_all_valid"] = all_valid
-            valid_flag_list.append(multi_level_flags)
-        return valid_flag_list
-
-    def get_init_anchors(self, featmap_sizes, img_metas, device):
-        multi_level_anchors = [self._init_anchors(i, featmap_sizes[i], device) for i in range(len(featmap_sizes))]
-        anchor_list = [list(multi_level_anchors) for _ in range(len(img_metas))]
-        return anchor_list, self._valid_flags(featmap_sizes, img_metas, device)
 
     def get_refine_anchors(self, featmap_sizes, refine_anchors, img_metas, is_train=True, device=None):
         num_levels = len(featmap_sizes)
@@ -244,24 +213,6 @@ class S2ANetHead(nn.Module):
         return dict(loss_fam_cls=losses_fam_cls, loss_fam_bbox=losses_fam_bbox, loss_odm_cls=losses_odm_cls,
                     loss_odm_bbox=losses_odm_bbox)
 
-    def _loss_single(self, loss_cls_fn, loss_bbox_fn, cls_score, bbox_pred, anchors, labels, label_weights,
-                     bbox_targets, bbox_weights, num_total_samples, cfg):
-        labels = labels.reshape(-1)
-        label_weights = label_weights.reshape(-1)
-        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
-        loss_cls = loss_cls_fn(cls_score, labels, label_weights, avg_factor=num_total_samples)
-        bbox_targets = bbox_targets.reshape(-1, 5)
-        bbox_weights = bbox_weights.reshape(-1, 5)
-        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 5)
-        if cfg.get("reg_decoded_bbox", False):
-            bbox_coder_cfg = cfg.get("bbox_coder", "")
-            if bbox_coder_cfg == "":
-                bbox_coder_cfg = dict(type="DeltaXYWHBBoxCoder")
-            bbox_coder = build_from_cfg(bbox_coder_cfg, BOXES)
-            bbox_pred = bbox_coder.decode(anchors.reshape(-1, 5), bbox_pred)
-        loss_bbox = loss_bbox_fn(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
-        return loss_cls, loss_bbox
-
     def loss_fam_single(self, fam_cls_score, fam_bbox_pred, anchors, labels, label_weights, bbox_targets,
                         bbox_weights, num_total_samples, cfg):
         return self._loss_single(self.loss_fam_cls, self.loss_fam_bbox, fam_cls_score, fam_bbox_pred, anchors, labels,
@@ -289,49 +240,6 @@ class S2ANetHead(nn.Module):
             result_list.append(self.get_bboxes_single(cls_score_list, bbox_pred_list, refine_anchors[0][img_id],
                                                       img_shape, scale_factor, cfg, rescale))
         return result_list
-
-    def get_bboxes_single(self, cls_score_list, bbox_pred_list, mlvl_anchors, img_shape, scale_factor, cfg,
-                          rescale=False):
-        assert len(cls_score_list) == len(bbox_pred_list) == len(mlvl_anchors)
-        mlvl_bboxes, mlvl_scores = [], []
-        for cls_score, bbox_pred, anchors in zip(cls_score_list, bbox_pred_list, mlvl_anchors):
-            assert cls_score.shape[-2:] == bbox_pred.shape[-2:]
-            cls_score = cls_score.permute(1, 2, 0).reshape(-1, self.cls_out_channels)
-            scores = cls_score.sigmoid() if self.use_sigmoid_cls else cls_score.softmax(-1)
-            bbox_pred = bbox_pred.permute(1, 2, 0).reshape(-1, 5)
-            nms_pre = cfg.get("nms_pre", -1)
-            if nms_pre > 0 and scores.shape[0] > nms_pre:
-                max_scores = scores.max(dim=1).values if self.use_sigmoid_cls else scores[:, 1:].max(dim=1).values
-                _, topk_inds = max_scores.topk(nms_pre)
-                anchors = anchors[topk_inds, :]
-                bbox_pred = bbox_pred[topk_inds, :]
-                scores = scores[topk_inds, :]
-            mlvl_bboxes.append(delta2bbox_rotated(anchors, bbox_pred, self.target_means, self.target_stds, img_shape))
-            mlvl_scores.append(scores)
-        mlvl_bboxes = torch.cat(mlvl_bboxes)
-        if rescale:
-            mlvl_bboxes[..., :4] /= scale_factor
-        mlvl_scores = torch.cat(mlvl_scores)
-        if self.use_sigmoid_cls:
-            padding = mlvl_scores.new_zeros((mlvl_scores.shape[0], 1))
-            mlvl_scores = torch.cat([padding, mlvl_scores], dim=1)
-        det_bboxes, det_labels = multiclass_nms_rotated(mlvl_bboxes, mlvl_scores, cfg.score_thr, cfg.nms,
-                                                        cfg.max_per_img)
-        boxes, scores = det_bboxes[:, :5], det_bboxes[:, 5]
-        return rotated_box_to_poly(boxes), scores, det_labels
-
-    def parse_targets(self, targets, is_train=True):
-        img_metas, gt_bboxes, gt_bboxes_ignore, gt_labels = [], [], [], []
-        for target in targets:
-            if is_train:
-                gt_bboxes.append(target["rboxes"])
-                gt_labels.append(target["labels"])
-                gt_bboxes_ignore.append(target["rboxes_ignore"])
-            img_metas.append(dict(img_shape=target["img_size"][::-1], scale_factor=target["scale_factor"],
-                                  pad_shape=target["pad_shape"]))
-        if not is_train:
-            return img_metas
-        return gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore
 
     def forward(self, feats, targets):
         outs = multi_apply(self.forward_single, feats, self.anchor_strides)
