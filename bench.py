@@ -157,10 +157,10 @@ def make_s2anet(a, rank, dev):
     each, random-init weights of the reference architecture, SGD+clip+StepLR, DDP when world > 1."""
     import jdet_amd.models  # noqa: F401
     from jdet_amd.runner import Runner, synthetic_batch
-    ref_cfg = "/root/reference/configs/s2anet/s2anet_r50_fpn_1x_dota.py"
     torch.manual_seed(1234)  # identical replicas
     amp = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.amp]
-    runner = Runner(S2ANET_CFG, device=dev, amp_dtype=amp)
+    runner = Runner(S2ANET_CFG, device=dev, amp_dtype=amp,
+                    conv_autotune=os.environ.get("JDET_CUDNN_BENCHMARK", "1") == "1")
     images, targets = synthetic_batch(a.batch, a.size, dev, seed=2 + rank)
     images = images.contiguous(memory_format=torch.channels_last)
 

@@ -129,6 +129,21 @@ int jdet_deform_col2im_coord(const float* col, const float* im, const float* off
                              int stride_w, int dil_h, int dil_w, int deform_groups,
                              float* grad_offset, jdet_stream_t stream);
 
+/* Channels-last deformable sampling (groups = 1, deform_groups = 1, C % 4 == 0; else JDET_E_UNSUPPORTED).
+ * Same arithmetic as jdet_deform_im2col / jdet_deform_col2im (dcn_v1.py:L130-184, L185-241), different
+ * layout: x_nhwc (B,H,W,C); offset stays (B, 2*kh*kw, Ho, Wo); cols / grad_cols are
+ * (B*Ho*Wo, kh*kw, C) so that  out_nhwc = cols . W^T  and  grad_cols = grad_out_nhwc . W  are plain
+ * row-major GEMMs.  col2im is a sorted gather (no fp atomics); workspace size from the _workspace query. */
+int jdet_deform_im2col_nhwc(const float* x_nhwc, const float* offset, int B, int C, int H, int W,
+                            int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                            int dil_h, int dil_w, float* cols, jdet_stream_t stream);
+size_t jdet_deform_col2im_nhwc_workspace(int B, int C, int H, int W, int kh, int kw, int pad_h,
+                                         int pad_w, int stride_h, int stride_w, int dil_h, int dil_w);
+int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, int C, int H, int W,
+                            int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w,
+                            int dil_h, int dil_w, float* grad_x_nhwc, void* workspace,
+                            size_t workspace_bytes, jdet_stream_t stream);
+
 /* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
  * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
  * out (nOut*nRot, nIn*nOri, kH, kW). */

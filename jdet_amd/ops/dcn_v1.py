@@ -1,9 +1,17 @@
 """Deformable convolution v1 (AlignConv's engine).  Mirrors python/jdet/ops/dcn_v1.py:
 `DeformConvFunction` (L559-648), `deform_conv` (L650), `DeformConv` (L652-696).
 
-y = W . im2col_deform(x, offset); offset (N, dg*2*kh*kw, Ho, Wo) ordered (dy,dx) per tap.  The
-bilinear gather / scatter kernels are csrc/deform_arf.hip; the dense contraction is a library GEMM
-(torch.bmm -> rocBLAS/hipBLASLt), as in the reference (`jt.matmul`, dcn_v1.py:L447,L490,L547).
+y = W . im2col_deform(x, offset); offset (N, dg*2*kh*kw, Ho, Wo) ordered (dy,dx) per tap.  The dense
+contraction is a library GEMM (rocBLAS/hipBLASLt), as in the reference (`jt.matmul`, dcn_v1.py:L447,
+L490,L547); the bilinear gather / scatter around it is hand-written:
+
+* channels-last path (groups = 1, deformable_groups = 1, Cin % 4 == 0 -- every AlignConv): csrc/
+  deform_nhwc.hip.  x NHWC, columns (B*Ho*Wo, kh*kw, Cin), so out_nhwc = cols @ Wt^T, grad_cols =
+  grad_out_nhwc @ Wt and grad_Wt = grad_out_nhwc^T @ cols are plain row-major GEMMs with no layout
+  copies, and the input gradient is a sorted gather (no fp atomics).
+* general path (groups / deformable groups / offset gradient): csrc/deform_arf.hip, the reference's
+  NCHW column layout.
+Both compute the same per-element arithmetic.
 """
 import math
 
@@ -56,7 +64,77 @@ def deformable_col2im_coord(col, x, offset, kh, kw, pad, stride, dil, dg):
     return goff
 
 
+def deformable_im2col_nhwc(x_nhwc, offset, kh, kw, pad, stride, dil):
+    """x_nhwc (B,H,W,C) contiguous, offset (B,2*kh*kw,Ho,Wo) -> columns (B*Ho*Wo, kh*kw*C)"""
+    B, H, W, C = x_nhwc.shape
+    Ho, Wo = _out_hw(H, W, kh, kw, pad, stride, dil)
+    cols = torch.empty((B * Ho * Wo, kh * kw * C), dtype=torch.float32, device=x_nhwc.device)
+    L.check(L.lib().jdet_deform_im2col_nhwc(L.ptr(x_nhwc), L.ptr(offset),
+                                            *_geom_args(B, C, H, W, kh, kw, pad, stride, dil, 1)[:-1],
+                                            L.ptr(cols), L.stream_ptr(x_nhwc)), "jdet_deform_im2col_nhwc")
+    return cols
+
+
+def deformable_col2im_nhwc(grad_cols, offset, nhwc_shape, kh, kw, pad, stride, dil):
+    """grad_cols (B*Ho*Wo, kh*kw*C) -> grad_x (B,H,W,C)"""
+    B, H, W, C = nhwc_shape
+    geom = _geom_args(B, C, H, W, kh, kw, pad, stride, dil, 1)[:-1]
+    nbytes = L.lib().jdet_deform_col2im_nhwc_workspace(*geom)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=grad_cols.device)
+    gx = torch.empty((B, H, W, C), dtype=torch.float32, device=grad_cols.device)
+    L.check(L.lib().jdet_deform_col2im_nhwc(L.ptr(grad_cols), L.ptr(offset), *geom, L.ptr(gx), L.ptr(ws), nbytes,
+                                            L.stream_ptr(grad_cols)), "jdet_deform_col2im_nhwc")
+    return gx
+
+
+def _nhwc(t):
+    """(B,C,H,W) logical -> (B,H,W,C) contiguous fp32; free when t is already channels-last"""
+    return L.f32c(t.permute(0, 2, 3, 1))
+
+
+# 288 GB of HBM: keep the forward's column matrix for grad_weight instead of re-sampling it (the
+# reference recomputes, dcn_v1.py:L541-547).  S2ANet 1024^2 batch 2: ~0.8 GB over both AlignConvs.
+SAVE_COLUMNS = True
+
+
 class DeformConvFunction(torch.autograd.Function):
+    @staticmethod
+    def _forward_nhwc(ctx, input, off, weight, stride, padding, dilation):
+        B, Cin, H, W = input.shape
+        Cout, _, kh, kw = weight.shape
+        Ho, Wo = _out_hw(H, W, kh, kw, padding, stride, dilation)
+        x = _nhwc(input)
+        wt = L.f32c(weight.permute(0, 2, 3, 1)).view(Cout, kh * kw * Cin)   # K index = tap*Cin + c
+        cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
+        out = torch.mm(cols, wt.t())                                          # (B*Ho*Wo, Cout) == NHWC
+        keep = SAVE_COLUMNS and weight.requires_grad
+        ctx.save_for_backward(x, off, wt, cols if keep else None)
+        return out.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _backward_nhwc(ctx, grad_output):
+        x, off, wt, cols = ctx.saved_tensors
+        stride, padding, dilation = ctx.cfg[:3]
+        Cout, Cin, kh, kw = ctx.wshape
+        B, H, W, _ = x.shape
+        need_x, need_off, need_w = ctx.needs_input_grad[:3]
+        if need_off:   # coordinate gradient lives on the general path
+            ctx.nhwc = False
+            ctx.saved_nchw = (L.f32c(x.permute(0, 3, 1, 2)), off,
+                              L.f32c(wt.view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)))
+            return DeformConvFunction.backward(ctx, grad_output)
+        g = _nhwc(grad_output).view(-1, Cout)
+        grad_input = grad_weight = None
+        if need_x:
+            gcols = torch.mm(g, wt)
+            gx = deformable_col2im_nhwc(gcols, off, x.shape, kh, kw, padding, stride, dilation)
+            grad_input = gx.permute(0, 3, 1, 2)
+        if need_w:
+            if cols is None:
+                cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
+            grad_weight = torch.mm(g.t(), cols).view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+        return grad_input, None, grad_weight, None, None, None, None, None, None
+
     @staticmethod
     def forward(ctx, input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
                 im2col_step=64):
@@ -64,9 +142,9 @@ class DeformConvFunction(torch.autograd.Function):
             raise ValueError("Expected 4D tensor as input, got {}D tensor instead.".format(input.dim()))
         L.need_device(input, offset, weight)
         stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
-        x, off, w = L.f32c(input), L.f32c(offset), L.f32c(weight)
-        B, Cin, H, W = x.shape
-        Cout, Cin_g, kh, kw = w.shape
+        off = L.f32c(offset)
+        B, Cin, H, W = input.shape
+        Cout, Cin_g, kh, kw = weight.shape
         Ho, Wo = _out_hw(H, W, kh, kw, padding, stride, dilation)
         if not (Ho > 0 and Wo > 0):
             raise ValueError("convolution input is too small (output would be {}x{}x{}x{})".format(B, Cout, Ho, Wo))
@@ -74,6 +152,11 @@ class DeformConvFunction(torch.autograd.Function):
         step = min(im2col_step, B)
         assert B % step == 0, "im2col step must divide batchsize"
         ctx.cfg = (stride, padding, dilation, groups, deformable_groups, step)
+        ctx.wshape = tuple(weight.shape)
+        ctx.nhwc = groups == 1 and deformable_groups == 1 and Cin % 4 == 0 and Cin_g == Cin
+        if ctx.nhwc:
+            return DeformConvFunction._forward_nhwc(ctx, input, off, weight, stride, padding, dilation)
+        x, w = L.f32c(input), L.f32c(weight)
         ctx.save_for_backward(x, off, w)
         out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
         wg = w.view(groups, Cout // groups, Cin_g * kh * kw)
@@ -86,7 +169,9 @@ class DeformConvFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_output):
-        x, off, w = ctx.saved_tensors
+        if ctx.nhwc:
+            return DeformConvFunction._backward_nhwc(ctx, grad_output)
+        x, off, w = getattr(ctx, "saved_nchw", None) or ctx.saved_tensors
         stride, padding, dilation, groups, dg, step = ctx.cfg
         B, Cin, H, W = x.shape
         Cout, Cin_g, kh, kw = w.shape

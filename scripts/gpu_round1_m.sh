@@ -1,0 +1,4 @@
+set -x
+timeout 900 python -m pytest tests/test_gpu_dcn_arf.py tests/test_gpu_roi_align.py tests/test_gpu_oriented_rcnn.py tests/test_gpu_s2anet.py -m gpu -x -q 2>&1 | tail -8
+timeout 300 python bench.py --workload roi_align_rotated_bwd --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
+timeout 600 python bench.py --workload s2anet_train --steps 10 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-300

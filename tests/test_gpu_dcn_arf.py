@@ -24,6 +24,54 @@ def test_dcn_kernels_vs_golden(golden, dev):
         np.testing.assert_array_equal(D.deformable_col2im_coord(gcol, im, off, *a).cpu().numpy(), g["goff_" + nm])
 
 
+def test_dcn_nhwc_kernels_vs_golden(golden, dev):
+    """channels-last kernels against the same reference-generated vectors: im2col bit-exact (same
+    arithmetic, other layout), col2im (sorted gather) to fp32 summation-order tolerance"""
+    from jdet_amd.ops import dcn_v1 as D
+    g = golden("deform_conv")
+    for nm in "ac":     # deformable_groups == 1, C % 4 == 0
+        k, pad, stride, dil, dg = [int(v) for v in g["cfg_" + nm]]
+        a = (k, k, (pad, pad), (stride, stride), (dil, dil))
+        im, off, gcol = g["im_" + nm], g["off_" + nm], g["gcol_" + nm]
+        B, C, H, W = im.shape
+        Ho, Wo = off.shape[2:]
+        x = _t(im.transpose(0, 2, 3, 1), dev)
+        cols = D.deformable_im2col_nhwc(x, _t(off, dev), *a).cpu().numpy()
+        ref = g["col_" + nm].reshape(C, k * k, B, Ho, Wo).transpose(2, 3, 4, 1, 0).reshape(B * Ho * Wo, k * k * C)
+        np.testing.assert_array_equal(cols, ref)
+        gc = gcol.reshape(C, k * k, B, Ho, Wo).transpose(2, 3, 4, 1, 0).reshape(B * Ho * Wo, k * k * C)
+        gx = D.deformable_col2im_nhwc(_t(gc, dev), _t(off, dev), (B, H, W, C), *a).cpu().numpy()
+        np.testing.assert_allclose(gx.transpose(0, 3, 1, 2), g["gim_" + nm], atol=2e-5)
+
+
+@pytest.mark.parametrize("cl", [False, True])
+def test_deform_conv_nhwc_path_vs_oracle(dev, cl):
+    """AlignConv usage: offsets detached -> the whole forward/backward runs on the channels-last path.
+    Offsets large enough to leave the image; C = 260 exercises the second 256-channel chunk."""
+    from jdet_amd.ops.dcn_v1 import DeformConv
+    rng = np.random.default_rng(5)
+    B, Cin, Cout, H, W = 2, 260, 12, 11, 14
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    off = (rng.standard_normal((B, 18, H, W)) * 3).astype(np.float32)
+    conv = DeformConv(Cin, Cout, 3, padding=1).to(dev)
+    w = conv.weight.detach().cpu().numpy()
+    xt = _t(x, dev)
+    if cl:
+        xt = xt.contiguous(memory_format=torch.channels_last)
+    xt.requires_grad_(True)
+    y = conv(xt, _t(off, dev))
+    a = (3, 3, (1, 1), (1, 1), (1, 1), 1)
+    col = O.deform_im2col(x, off, *a)
+    ref = (w.reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64)).reshape(Cout, B, H, W).transpose(1, 0, 2, 3)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-4)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(_t(gy, dev))
+    gcol = (w.reshape(Cout, -1).T.astype(np.float64) @ gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64)).astype(np.float32).reshape(col.shape)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), O.deform_col2im(gcol, off, x.shape, *a), rtol=1e-4, atol=3e-4)
+    gw = gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64).T
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Cout, -1), gw, rtol=1e-4, atol=3e-4)
+
+
 def test_deform_conv_module_vs_oracle(dev):
     """S2ANet AlignConv shape family (3x3, pad 1, dg 1), small: forward = W . im2col, backward through
     the three kernels; GEMMs are rocBLAS fp32 so tolerance 1e-4 relative."""
