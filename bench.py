@@ -92,6 +92,7 @@ def make_step(workload, d):
         fp, rp, op = feat.data_ptr(), rois.data_ptr(), out.data_ptr()
         o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
         use_order = os.environ.get("JDET_BENCH_NO_ORDER", "0") != "1"
+        lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
 
         def step():
             # the XCD-aware schedule is recomputed every step: RoIs arrive in arbitrary order

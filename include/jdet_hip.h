@@ -73,6 +73,13 @@ int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, in
                            int sample_num, int n_orient, const int32_t* order, float* out,
                            jdet_stream_t stream);
 
+/* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
+ *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);
+ *                equals the reference up to fp32 re-association of the bilinear weights.
+ *   1          : the reference's operation order (roi_align_rotated.py:L70-118) -- bit-identical to the
+ *                CPU oracle; used by the parity tests. */
+int jdet_set_roi_forward_mode(int mode);
+
 /* XCD-aware spatial schedule for the RoIAlign kernels (no reference counterpart: the reference
  * processes output elements in index order).  Writes a permutation `order` of [0,R): workgroup b
  * processes RoI order[b].  RoIs are bucketed by the Morton code of their centre and contiguous

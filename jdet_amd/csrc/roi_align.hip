@@ -56,12 +56,12 @@ __device__ __forceinline__ void acc_sample4(float (&acc)[4], float w1, float w2,
 // Per-RoI prologue shared by the vector kernels: geometry with the control-flow / addressing
 // scalars pinned into SGPRs (hipcc otherwise wraps every buffer_load in a waterfall loop, guide
 // T20), and a raw buffer descriptor over the RoI's image (out-of-range reads return 0).
-template <int VARIANT>
+template <int VARIANT, bool TRIG = true>
 __device__ __forceinline__ RoiGeom vec_prologue(const float* feat, const float* rois, int r, int C, int H,
                                                 int W, int PH, int PW, float spatial_scale,
                                                 int sample_num, __amdgpu_buffer_rsrc_t& rsrc) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
-  RoiGeom g = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, false);
+  RoiGeom g = roi_geom<VARIANT, TRIG>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, false);
   g.batch = __builtin_amdgcn_readfirstlane(g.batch);
   g.grid_h = __builtin_amdgcn_readfirstlane(g.grid_h);
   g.grid_w = __builtin_amdgcn_readfirstlane(g.grid_w);
@@ -193,6 +193,173 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
     return;
   }
   // coalesced write-out of the contiguous [cc][nbins] block (cc % 4 == 0 -> 16 B aligned)
+  const int total = cc * nbins;
+  const float4* s4 = reinterpret_cast<const float4*>(s_out);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (int i = threadIdx.x; i < (total >> 2); i += NW * 64) d4[i] = s4[i];
+}
+
+// ---- merged-tap path (sample_num == 2: the configuration every reference config uses) -----------
+// PMC on the reference-order kernel above (profiles/r01_roi_align_fwd_rocprofv3_summary.txt): 2714 VALU
+// instructions per wave -- 8 fp32 ops per tap-channel-quad with contraction off, 4 divides per bin,
+// double-precision trig in every wave -- keep the SIMDs ~45 % busy, and 1.51 M dwordx4 tap loads keep
+// the vector-memory path ~60 % busy: co-limited, neither hides behind the other.  This path attacks both:
+//   * the 4 samples of a bin sit bin/2 apart; whenever that is under a pixel their 16 taps revisit
+//     the same few pixels (bench RoIs: 58 % of the taps are distinct within their bin).  Lane =
+//     sample; inside each quad of lanes (= one bin) every tap looks up the other 15, the first
+//     occurrence of a pixel takes the summed weight (pre-divided by the sample count), the rest are
+//     dropped; survivors are compacted per bin through a 2 KiB/wave LDS scratch (overlaid on the
+//     output staging block, before anything is staged) so that lane 4*bin+i holds entries i, 4+i, ...
+//   * the tap loop runs over the dense list in batches of 4 loads: per surviving tap one
+//     buffer_load_dwordx4 + two v_pk_fma_f32, no guards, no divides.
+//   * sin/cos in double once per workgroup (wave 0) instead of once per wave.
+// Result = reference value up to fp32 re-association of the weights (<= a few ulp of sum|w.v|);
+// jdet_set_roi_forward_mode(1) selects the reference-order kernel above (bit-identical to the oracle).
+template <int VARIANT, int NW, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
+    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+    int C, int H, int W, int PH, int PW, float spatial_scale, const int32_t* __restrict__ order, int abl_mask) {
+  extern __shared__ __attribute__((aligned(16))) float s_out[];  // [cc][nbins]; first 2 KiB/wave: tap lists
+  __shared__ float s_trig[2];
+  const int r = order ? order[blockIdx.x] : blockIdx.x;
+  const int c0 = blockIdx.y * kChunkC;
+  const int cc = min(kChunkC, C - c0);
+  const int nbins = PH * PW;                       // <= 16 * NW on this path
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
+  constexpr bool kRot = ROI_COLS == 6;
+  const float* roi = rois + (size_t)r * ROI_COLS;
+  if (kRot && wave == 0 && lane == 0) {
+    s_trig[0] = (float)cos((double)roi[5]);
+    s_trig[1] = (float)sin((double)roi[5]);
+  }
+  __amdgpu_buffer_rsrc_t rsrc;
+  RoiGeom g = vec_prologue<VARIANT, false>(feat, rois, r, C, H, W, PH, PW, spatial_scale, 2, rsrc);
+  if (g.batch < 0) return;
+  if (kRot) {
+    __syncthreads();
+    g.cosT = s_trig[0];
+    g.sinT = s_trig[1];
+  }
+
+  const bool lane_ok = lane * 4 < cc;
+  const int voff = (c0 + (lane_ok ? lane * 4 : 0)) * 4;
+  const int pix_bytes = C * 4;
+  const int q = lane & 3, qbase = lane & ~3, kb_mine = lane >> 2;
+  // wave w owns bins w, w+NW, ... (measured: better than contiguous runs -- neighbouring bins in flight
+  // together share their L1 misses)
+  const int nb = (nbins - wave + NW - 1) / NW;
+  const int my_bin = wave + NW * kb_mine;
+  const bool bin_ok = kb_mine < nb;
+  const int bb = bin_ok ? my_bin : 0;
+  Sample s = make_sample<VARIANT>(g, bb / PW, bb % PW, q >> 1, q & 1, H, W);
+  if (!bin_ok) s.valid = 0;
+  if (ABL & 1) {   // profiling builds: same tap structure, every tap inside one (abl_mask+1)-pixel window
+    s.o1 &= abl_mask; s.o2 &= abl_mask; s.o3 &= abl_mask; s.o4 &= abl_mask;
+  }
+  const int o[4] = {s.o1 * pix_bytes, s.o2 * pix_bytes, s.o3 * pix_bytes, s.o4 * pix_bytes};
+  const float w[4] = {s.w1, s.w2, s.w3, s.w4};
+  float tw[4] = {w[0], w[1], w[2], w[3]};
+  bool first[4] = {true, true, true, true};
+#pragma unroll
+  for (int k = 1; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < k; j++)
+      if (o[j] == o[k]) {   // x_high == x_low / y_high == y_low at the map border
+        tw[j] += w[k];      // (first occurrence collects; later ones are dropped)
+        first[k] = false;
+      }
+#pragma unroll
+  for (int d = 1; d < 4; d++) {
+    const int src = qbase | ((q + d) & 3);
+    const bool earlier = ((q + d) & 3) < q;
+    const int ov = __shfl(s.valid, src, 64);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int oo = __shfl(o[j], src, 64);
+      const float ww = __shfl(w[j], src, 64);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool same = ov && oo == o[k];
+        tw[k] += same ? ww : 0.f;
+        first[k] = first[k] && !(same && earlier);
+      }
+    }
+  }
+  const float inv_count = 1.f / g.count;   // count == 4 here: exact
+  int keep[4], mycnt = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    keep[k] = s.valid && first[k];
+    mycnt += keep[k];
+  }
+  // compaction: position inside the bin = kept taps of lower quad lanes + own lower kept taps
+  int below = 0, n_bin = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int ci = __shfl(mycnt, qbase | i, 64);
+    below += i < q ? ci : 0;
+    n_bin += ci;
+  }
+  int2* list = reinterpret_cast<int2*>(s_out) + wave * 256 + kb_mine * 16;
+  int pos = below;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (keep[k]) list[pos++] = make_int2(o[k], __float_as_int(tw[k] * inv_count));
+  __builtin_amdgcn_wave_barrier();   // list is private to the wave; LDS ops of a wave retire in order
+  int e_o[4];
+  float e_w[4];
+  const int2 e0 = list[0];
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int2 e = list[4 * b + q];
+    const bool live = 4 * b + q < n_bin;
+    e_o[b] = live ? e.x : e0.x;                       // pad: entry 0's pixel (a tap of this bin) ...
+    e_w[b] = live ? __int_as_float(e.y) : 0.f;        // ... with weight 0
+  }
+  __syncthreads();   // every wave has read its list: s_out may now be used for results
+
+  auto tap = [&](int soff) -> v4f {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+  };
+  for (int kb = 0; kb < nb; kb++) {
+    const int bin = wave + NW * kb;
+    const int l0 = kb * 4;
+    const int n = jdet_readlane_i(n_bin, l0);
+    v4f t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (4 * b < n) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[b][i] = tap(jdet_readlane_i(e_o[b], l0 + i));
+      }
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (4 * b < n) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float wt = jdet_readlane_f(e_w[b], l0 + i);
+          acc.x = __builtin_fmaf(wt, t[b][i].x, acc.x);
+          acc.y = __builtin_fmaf(wt, t[b][i].y, acc.y);
+          acc.z = __builtin_fmaf(wt, t[b][i].z, acc.z);
+          acc.w = __builtin_fmaf(wt, t[b][i].w, acc.w);
+        }
+      }
+    if (lane_ok) {
+      s_out[(lane * 4 + 0) * nbins + bin] = acc.x;
+      s_out[(lane * 4 + 1) * nbins + bin] = acc.y;
+      s_out[(lane * 4 + 2) * nbins + bin] = acc.z;
+      s_out[(lane * 4 + 3) * nbins + bin] = acc.w;
+    }
+  }
+  __syncthreads();
+  float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
+  if (ABL & 4) {
+    if (threadIdx.x == 0) dst[0] = s_out[0];
+    return;
+  }
   const int total = cc * nbins;
   const float4* s4 = reinterpret_cast<const float4*>(s_out);
   float4* d4 = reinterpret_cast<float4*>(dst);
@@ -773,6 +940,9 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// 0 = merged taps (default), 1 = reference operation order (bit-identical to the CPU oracle)
+int g_fwd_reference_order = 0;
+
 template <int VARIANT>
 int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, int H, int W, int PH,
                int PW, float scale, int sample_num, int nO, const int32_t* order, hipStream_t st) {
@@ -802,6 +972,28 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
     }
     hipLaunchKernelGGL((roi_align_fwd_cached_kernel<V>), dim3(R), dim3(256), lds_c, st, feat, rois, out,
                        C, H, W, PH, PW, scale, sample_num, order, cache_floats);
+  } else if (vec && sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && lds >= 8 * 2048) {
+    constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
+    static const int nw = env_int("JDET_ROI_FWD_WAVES", 4);
+    static const int abl = env_int("JDET_ROI_ABLATE", 0);  // profiling builds only
+    if (abl == 1)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 1>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (abl == 4)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 4>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (abl == 5)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 5>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (nw == 8)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 8>), grid, dim3(512), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (nw == 2 && nbins <= 32)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 2>), grid, dim3(128), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
   } else if (vec) {
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;  // never RiRoI here
     static const int nw = env_int("JDET_ROI_FWD_WAVES", 4);
@@ -870,6 +1062,12 @@ JDET_API int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float
                                jdet_stream_t stream) {
   if (N < 0 || C < 0 || H < 0 || W < 0 || ((long)N * C * H * W > 0 && (!x || !y))) return JDET_E_BADARG;
   return launch_transpose(x, y, N, H * W, C, (hipStream_t)stream);
+}
+
+JDET_API int jdet_set_roi_forward_mode(int mode) {
+  const int prev = g_fwd_reference_order;
+  if (mode == 0 || mode == 1) g_fwd_reference_order = mode;
+  return prev;
 }
 
 JDET_API int jdet_roi_spatial_order(const float* rois, int R, int roi_cols, float spatial_scale, int N,

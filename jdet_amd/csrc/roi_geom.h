@@ -22,7 +22,7 @@ struct RoiGeom {
   int ind;
 };
 
-template <int VARIANT>
+template <int VARIANT, bool TRIG = true>
 __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float spatial_scale,
                                             int sample_num, int PH, int PW, int nO, bool backward) {
   RoiGeom g;
@@ -66,8 +66,12 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float
     g.start_w = -roi_width / 2.0f;
     // once per RoI: double-precision trig rounded to fp32 (what the host-compiled reference
     // text does; CUDA's cosf agrees to <= 1 ulp)
-    g.cosT = (float)cos((double)theta);
-    g.sinT = (float)sin((double)theta);
+    if (TRIG) {
+      g.cosT = (float)cos((double)theta);
+      g.sinT = (float)sin((double)theta);
+    } else {
+      g.cosT = g.sinT = 0.f;   // caller fills them in (computed once per workgroup)
+    }
     if (VARIANT == JDET_ROI_RIROI) {
       // riroi_align.py:L105-113, PI literal L8
       float ind_float = (float)((double)(theta * nO) / (2 * 3.141592653));

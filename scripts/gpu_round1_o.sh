@@ -1,0 +1,6 @@
+run() { timeout 300 python bench.py --workload roi_align_rotated --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(round(d["ms_per_step"]*1000,1),"us/step")'; }
+echo "merged: $(run)"
+for a in 11 12 13; do echo "aux $((a-10)): $(JDET_ROI_ABLATE=$a run)"; done
+echo "contiguous bins NW4: $(JDET_ROI_ABLATE=20 run)"
+echo "contiguous bins NW8: $(JDET_ROI_ABLATE=21 run)"
+timeout 600 python -m pytest tests/test_gpu_roi_align.py -m gpu -x -q 2>&1 | tail -2
