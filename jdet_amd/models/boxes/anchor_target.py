@@ -42,11 +42,14 @@ def anchor_inside_flags(flat_anchors, valid_flags, img_shape, allowed_border=0):
 
 
 def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore, gt_labels, img_meta, target_means,
-                         target_stds, cfg=None, label_channels=1, sampling=True, unmap_outputs=True):
-    bbox_coder_cfg = cfg.get("bbox_coder", "")
-    if bbox_coder_cfg == "":
-        bbox_coder_cfg = dict(type="DeltaXYWHBBoxCoder")
-    bbox_coder = build_from_cfg(bbox_coder_cfg, BOXES)
+                         target_stds, cfg=None, label_channels=1, sampling=True, unmap_outputs=True, encode_fn=None):
+    """encode_fn(pos_bboxes, pos_gt_bboxes): replaces the coder; the roi_heads/anchor_target.py twin of the
+    reference hard-wires `bbox2delta(..., target_means, target_stds)` there (L157-159)."""
+    if encode_fn is None:
+        bbox_coder_cfg = cfg.get("bbox_coder", "")
+        if bbox_coder_cfg == "":
+            bbox_coder_cfg = dict(type="DeltaXYWHBBoxCoder")
+        bbox_coder = build_from_cfg(bbox_coder_cfg, BOXES)
     reg_decoded_bbox = cfg.get("reg_decoded_bbox", False)
     allowed_border = cfg.get("allowed_border", -1)
     inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta["img_shape"][:2], allowed_border)
@@ -69,7 +72,9 @@ def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
     label_weights = torch.zeros((num_valid_anchors,), dtype=torch.float32, device=anchors.device)
     pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
     if len(pos_inds) > 0:
-        if not reg_decoded_bbox:
+        if encode_fn is not None:
+            pos_bbox_targets = encode_fn(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
+        elif not reg_decoded_bbox:
             pos_bbox_targets = bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
         else:
             pos_bbox_targets = sampling_result.pos_gt_bboxes
@@ -95,7 +100,7 @@ def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
 
 def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, target_means, target_stds, cfg,
                   gt_bboxes_ignore_list=None, gt_labels_list=None, label_channels=1, sampling=True,
-                  unmap_outputs=True):
+                  unmap_outputs=True, encode_fn=None):
     num_imgs = len(img_metas)
     assert len(anchor_list) == len(valid_flag_list) == num_imgs
     num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
@@ -110,7 +115,7 @@ def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, targe
     (all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_inds_list, neg_inds_list) = multi_apply(
         anchor_target_single, anchor_list, valid_flag_list, gt_bboxes_list, gt_bboxes_ignore_list, gt_labels_list,
         img_metas, target_means=target_means, target_stds=target_stds, cfg=cfg, label_channels=label_channels,
-        sampling=sampling, unmap_outputs=unmap_outputs)
+        sampling=sampling, unmap_outputs=unmap_outputs, encode_fn=encode_fn)
     if any([labels is None for labels in all_labels]):
         return None
     num_total_pos = sum([max(inds.numel(), 1) for inds in pos_inds_list])

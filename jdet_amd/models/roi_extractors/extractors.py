@@ -84,7 +84,14 @@ class SingleRoIExtractor(_SingleLevelBase):
 
 @ROI_EXTRACTORS.register_module()
 class RboxSingleRoIExtractor(_SingleLevelBase):
+    """rbox_single_level.py:L8-34; the enlargement factors are applied by the caller
+    (roi_transformer.py:L124-125), the extractor only carries them."""
     ops_module = roi_align_rotated
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56, w_enlarge=1.2, h_enlarge=1.4):
+        super().__init__(roi_layer, out_channels, featmap_strides, finest_scale)
+        self.w_enlarge = w_enlarge
+        self.h_enlarge = h_enlarge
 
 
 @ROI_EXTRACTORS.register_module()

@@ -34,7 +34,12 @@ def synthetic_batch(batch, size, device, seed=0, num_gts=64, num_classes=15):
         wh = np.exp(rng.uniform(np.log(16.0), np.log(min(256.0, size / 2)), (num_gts, 2)))
         th = rng.uniform(-np.pi / 2, np.pi / 2, (num_gts, 1))
         rb = torch.from_numpy(np.concatenate([c, wh, th], 1).astype(np.float32)).to(device)
-        targets.append(dict(rboxes=rb, labels=torch.from_numpy(rng.integers(1, num_classes + 1, num_gts).astype(np.int32)).to(device),
+        # enclosing horizontal boxes (what data/dota.py derives from the polygons) for the two-stage RPNs
+        ex = 0.5 * (np.abs(wh[:, :1] * np.cos(th)) + np.abs(wh[:, 1:] * np.sin(th)))
+        ey = 0.5 * (np.abs(wh[:, :1] * np.sin(th)) + np.abs(wh[:, 1:] * np.cos(th)))
+        hb = torch.from_numpy(np.concatenate([c[:, :1] - ex, c[:, 1:] - ey, c[:, :1] + ex, c[:, 1:] + ey],
+                                             1).astype(np.float32)).to(device)
+        targets.append(dict(rboxes=rb, hboxes=hb, hboxes_ignore=torch.zeros((0, 4), device=device), labels=torch.from_numpy(rng.integers(1, num_classes + 1, num_gts).astype(np.int32)).to(device),
                             rboxes_ignore=torch.zeros((0, 5), device=device), img_size=(size, size),
                             ori_img_size=(size, size), scale_factor=1.0, pad_shape=(size, size)))
     return images, targets

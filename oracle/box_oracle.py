@@ -138,3 +138,108 @@ def anchor_target_single(anchors, gt_bboxes, gt_labels, pos_iou_thr=0.5, neg_iou
     if len(neg):
         label_weights[neg] = 1.0
     return labels, label_weights, bbox_targets, bbox_weights, pos, neg
+
+
+# ---- RoI-Transformer codecs (python/jdet/ops/bbox_transforms.py) -- numpy restatement, test-only ----------
+def hbb2obb_v2(boxes):
+    """L34-44"""
+    ex_h = boxes[:, 2] - boxes[:, 0] + 1.0
+    ex_w = boxes[:, 3] - boxes[:, 1] + 1.0
+    cx = boxes[:, 0] + 0.5 * (ex_h - 1.0)
+    cy = boxes[:, 1] + 0.5 * (ex_w - 1.0)
+    return np.stack([cx, cy, ex_w, ex_h, -np.ones_like(cx) * np.pi / 2], 1).astype(np.float32)
+
+
+def dbbox2delta_v3(p, g, means, stds):
+    """L7-32"""
+    p, g = p.astype(np.float32), g.astype(np.float32)
+    co = g[:, 0:2] - p[:, 0:2]
+    dx = (np.cos(p[:, 4]) * co[:, 0] + np.sin(p[:, 4]) * co[:, 1]) / p[:, 2]
+    dy = (-np.sin(p[:, 4]) * co[:, 0] + np.cos(p[:, 4]) * co[:, 1]) / p[:, 3]
+    d = np.stack([dx, dy, np.log(g[:, 2] / p[:, 2]), np.log(g[:, 3] / p[:, 3]), g[:, 4] - p[:, 4]], -1)
+    return ((d - np.asarray(means, np.float32)[None]) / np.asarray(stds, np.float32)[None]).astype(np.float32)
+
+
+def delta2dbbox(rrois, deltas, means, stds, angle_scale, wh_ratio_clip=16 / 1000):
+    """v3 (angle_scale 1, L279-321) and v2 (angle_scale pi/2, L323-360); deltas (n, 5*k)"""
+    k = deltas.shape[1] // 5
+    d = deltas * np.tile(np.asarray(stds, np.float32), k)[None] + np.tile(np.asarray(means, np.float32), k)[None]
+    dx, dy, dw, dh, da = d[:, 0::5], d[:, 1::5], d[:, 2::5], d[:, 3::5], d[:, 4::5]
+    mr = abs(np.log(wh_ratio_clip))
+    dw, dh = np.clip(dw, -mr, mr), np.clip(dh, -mr, mr)
+    rx, ry, rw, rh, ra = [rrois[:, i:i + 1] for i in range(5)]
+    gx = dx * rw * np.cos(ra) - dy * rh * np.sin(ra) + rx
+    gy = dx * rw * np.sin(ra) + dy * rh * np.cos(ra) + ry
+    out = np.stack([gx, gy, rw * np.exp(dw), rh * np.exp(dh), angle_scale * da + ra], -1)
+    return out.reshape(deltas.shape).astype(np.float32)
+
+
+def choose_best_Rroi_batch(r):
+    """L444-463 (returns a copy)"""
+    r = r.copy()
+    w, h = r[:, 2].copy(), r[:, 3].copy()
+    idx = w < h
+    r[idx, 2], r[idx, 3] = h[idx], w[idx]
+    r[idx, 4] = r[idx, 4] + np.pi / 2.
+    r[:, 4] = r[:, 4] % np.pi
+    return r
+
+
+def choose_best_obb_batch(g0):
+    """L465-479"""
+    g = g0.copy()
+    w, h = g0[:, 2], g0[:, 3]
+    g[:, 4] = (g[:, 4] - np.pi / 4.) % np.pi
+    idx = g[:, 4] >= np.pi / 2
+    g[idx, 2], g[idx, 3] = h[idx], w[idx]
+    g[idx, 4] = g[idx, 4] - np.pi / 2.
+    g[:, 4] = g[:, 4] - np.pi * 3. / 4.
+    return g
+
+
+def best_match_dbbox2delta(rrois, gt, means, stds):
+    """choose_best_match_batch L237-266 (row loop) + dbbox2delta_v2 L206-235"""
+    new = np.zeros_like(gt)
+    for i in range(gt.shape[0]):
+        x, y, w, h, a = gt[i]
+        ext = [(x, y, w, h, a), (x, y, h, w, a + np.pi / 2.), (x, y, w, h, a + np.pi), (x, y, h, w, a + np.pi * 3 / 2.)]
+        dist = [(rrois[i, 4] - e[4]) % (2 * np.pi) for e in ext]
+        dist = [min(d, 2 * np.pi - d) for d in dist]
+        new[i] = ext[int(np.argmin(dist))]
+    new[:, 4] = new[:, 4] % (2 * np.pi)
+    co = new[:, 0:2] - rrois[:, 0:2]
+    ra = rrois[:, 4]
+    dx = (np.cos(ra) * co[:, 0] + np.sin(ra) * co[:, 1]) / rrois[:, 2]
+    dy = (-np.sin(ra) * co[:, 0] + np.cos(ra) * co[:, 1]) / rrois[:, 3]
+    da = new[:, 4] - ra
+    dist = da % (2 * np.pi)
+    dist = np.minimum(dist, 2 * np.pi - dist)
+    dist = np.where(np.sin(da) < 0, -dist, dist) / (np.pi / 2.)
+    d = np.stack([dx, dy, np.log(new[:, 2] / rrois[:, 2]), np.log(new[:, 3] / rrois[:, 3]), dist], -1)
+    return ((d - np.asarray(means)[None]) / np.asarray(stds)[None]).astype(np.float32)
+
+
+def bbox2delta(p, g, means, stds):
+    """L179-204"""
+    px, py = (p[:, 0] + p[:, 2]) * 0.5, (p[:, 1] + p[:, 3]) * 0.5
+    pw, ph = p[:, 2] - p[:, 0] + 1.0, p[:, 3] - p[:, 1] + 1.0
+    gx, gy = (g[:, 0] + g[:, 2]) * 0.5, (g[:, 1] + g[:, 3]) * 0.5
+    gw, gh = g[:, 2] - g[:, 0] + 1.0, g[:, 3] - g[:, 1] + 1.0
+    d = np.stack([(gx - px) / pw, (gy - py) / ph, np.log(gw / pw), np.log(gh / ph)], -1)
+    return ((d - np.asarray(means)[None]) / np.asarray(stds)[None]).astype(np.float32)
+
+
+def delta2bbox(rois, deltas, means, stds, max_shape=None, wh_ratio_clip=16 / 1000):
+    """L362-396, deltas (n,4)"""
+    d = deltas * np.asarray(stds, np.float32)[None] + np.asarray(means, np.float32)[None]
+    mr = abs(np.log(wh_ratio_clip))
+    dw, dh = np.clip(d[:, 2], -mr, mr), np.clip(d[:, 3], -mr, mr)
+    px, py = (rois[:, 0] + rois[:, 2]) * 0.5, (rois[:, 1] + rois[:, 3]) * 0.5
+    pw, ph = rois[:, 2] - rois[:, 0] + 1.0, rois[:, 3] - rois[:, 1] + 1.0
+    gw, gh = pw * np.exp(dw), ph * np.exp(dh)
+    gx, gy = px + pw * d[:, 0], py + ph * d[:, 1]
+    x1, y1, x2, y2 = gx - gw * 0.5 + 0.5, gy - gh * 0.5 + 0.5, gx + gw * 0.5 - 0.5, gy + gh * 0.5 - 0.5
+    if max_shape is not None:
+        x1, x2 = np.clip(x1, 0, max_shape[1] - 1), np.clip(x2, 0, max_shape[1] - 1)
+        y1, y2 = np.clip(y1, 0, max_shape[0] - 1), np.clip(y2, 0, max_shape[0] - 1)
+    return np.stack([x1, y1, x2, y2], -1).astype(np.float32)

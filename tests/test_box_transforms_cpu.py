@@ -103,3 +103,86 @@ def test_horizontal_anchor_generator():
     assert sum(x.shape[0] for x in g.grid_anchors(sizes)) == 261888   # 1024x1024 tile
     f = g.valid_flags([(4, 4)] + [(1, 1)] * 4, (12, 16))[0].view(4, 4, 3)
     assert f[:3, :, :].all() and not f[3].any()
+
+
+# ---- RoI-Transformer codecs (torch host code vs the numpy restatement; closed forms) ---------------------------
+def _rt_inputs(n=200, seed=3):
+    rng = np.random.default_rng(seed)
+    def obbs():
+        return np.concatenate([rng.uniform(0, 1024, (n, 2)), np.exp(rng.uniform(np.log(8), np.log(300), (n, 2))),
+                               rng.uniform(-4, 4, (n, 1))], 1).astype(np.float32)
+    return rng, obbs(), obbs()
+
+
+def test_roitrans_codecs_match_oracle():
+    from jdet_amd.ops import bbox_transforms as T
+    from oracle import box_oracle as B
+    rng, p, g = _rt_inputs()
+    means, stds = [0., 0., 0., 0., 0.], [0.1, 0.1, 0.2, 0.2, 0.1]
+    tp, tg = torch.from_numpy(p), torch.from_numpy(g)
+    np.testing.assert_allclose(T.dbbox2delta_v3(tp, tg, means, stds).numpy(), B.dbbox2delta_v3(p, g, means, stds),
+                               rtol=1e-5, atol=1e-5)
+    d = (rng.standard_normal((200, 80)) * 0.5).astype(np.float32)
+    np.testing.assert_allclose(T.delta2dbbox_v3(tp, torch.from_numpy(d), means, stds).numpy(),
+                               B.delta2dbbox(p, d, means, stds, 1.0), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(T.delta2dbbox_v2(tp, torch.from_numpy(d), means, stds).numpy(),
+                               B.delta2dbbox(p, d, means, stds, np.pi / 2), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(T.choose_best_Rroi_batch(tp).numpy(), B.choose_best_Rroi_batch(p), atol=1e-6)
+    np.testing.assert_allclose(T.choose_best_obb_batch(tp).numpy(), B.choose_best_obb_batch(p), atol=1e-6)
+    np.testing.assert_allclose(T.best_match_dbbox2delta(tp, tg, means, stds).numpy(),
+                               B.best_match_dbbox2delta(p, g, means, stds), rtol=1e-4, atol=1e-4)
+    # the argument is not modified (the reference edits it in place; documented deviation)
+    np.testing.assert_array_equal(tp.numpy(), p)
+
+
+def test_roitrans_closed_forms():
+    from jdet_amd.ops import bbox_transforms as T
+    from oracle import box_oracle as B
+    rng, p, g = _rt_inputs(64, 5)
+    tp, tg = torch.from_numpy(p), torch.from_numpy(g)
+    means, stds = [0.] * 5, [0.05, 0.05, 0.1, 0.1, 0.05]
+    # decode(encode) = identity for v3
+    rec = T.delta2dbbox_v3(tp, T.dbbox2delta_v3(tp, tg, means, stds), means, stds, wh_ratio_clip=1e-6)
+    np.testing.assert_allclose(rec.numpy(), g, rtol=2e-4, atol=2e-3)
+    # best-match targets have |dangle| <= pi/4 (in units of pi/2 -> 0.5) before normalisation
+    bm = T.best_match_dbbox2delta(tp, tg, [0.] * 5, [1.] * 5)
+    assert float(bm[:, 4].abs().max()) <= 0.5 + 1e-5
+    # w >= h and angle in [0, pi) after choose_best_Rroi_batch; angle in [-3pi/4, -pi/4) after choose_best_obb_batch
+    r = T.choose_best_Rroi_batch(tp)
+    assert bool((r[:, 2] >= r[:, 3]).all()) and bool(((r[:, 4] >= 0) & (r[:, 4] < np.pi)).all())
+    o = T.choose_best_obb_batch(tp)
+    assert bool(((o[:, 4] >= -0.75 * np.pi - 1e-6) & (o[:, 4] < -0.25 * np.pi)).all())
+    # horizontal helpers
+    h = np.concatenate([rng.uniform(0, 500, (64, 2)), rng.uniform(510, 1000, (64, 2))], 1).astype(np.float32)
+    h2 = np.concatenate([rng.uniform(0, 500, (64, 2)), rng.uniform(510, 1000, (64, 2))], 1).astype(np.float32)
+    np.testing.assert_allclose(T.hbb2obb_v2(torch.from_numpy(h)).numpy(), B.hbb2obb_v2(h), atol=1e-5)
+    m4, s4 = [0.] * 4, [1.] * 4
+    dl = T.bbox2delta(torch.from_numpy(h), torch.from_numpy(h2), m4, s4)
+    np.testing.assert_allclose(dl.numpy(), B.bbox2delta(h, h2, m4, s4), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(T.delta2bbox(torch.from_numpy(h), dl, m4, s4, wh_ratio_clip=1e-6).numpy(), h2, rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(T.delta2bbox(torch.from_numpy(h), dl * 3, m4, s4, (1024, 1024)).numpy(),
+                               B.delta2bbox(h, dl.numpy() * 3, m4, s4, (1024, 1024)), rtol=1e-4, atol=2e-3)
+    rois = T.bbox2roi([torch.from_numpy(h[:3]), torch.zeros((0, 4)), torch.from_numpy(h[3:5])])
+    assert rois.shape == (5, 5) and rois[:, 0].tolist() == [0, 0, 0, 2, 2]
+    dr = T.roi2droi(rois)
+    assert dr.shape == (5, 6) and np.allclose(dr[:, 5].numpy(), -np.pi / 2)
+    assert T.dbbox2roi([tp[:2], tp[2:5]]).shape == (5, 6)
+
+
+def test_roitrans_modules_build():
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.utils.registry import HEADS, MODELS, ROI_EXTRACTORS
+    for n in ("RoITransformer",):
+        assert n in MODELS._module_dict if hasattr(MODELS, "_module_dict") else True
+    from jdet_amd.models.roi_heads import FasterrcnnHead, SharedFCBBoxHeadRbbox
+    h = SharedFCBBoxHeadRbbox(num_fcs=2, in_channels=8, fc_out_channels=32, roi_feat_size=7, num_classes=16,
+                              reg_class_agnostic=True, with_module=False,
+                              loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=False, loss_weight=1.0))
+    cls, reg = h(torch.randn(5, 8, 7, 7))
+    assert cls.shape == (5, 16) and reg.shape == (5, 5)
+    rpn = FasterrcnnHead(in_channels=8, feat_channels=8, anchor_scales=[8], anchor_ratios=[0.5, 1.0, 2.0],
+                         anchor_strides=[4, 8], loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=True))
+    outs = rpn([torch.randn(1, 8, 16, 16), torch.randn(1, 8, 8, 8)])
+    assert outs[0][0].shape == (1, 3, 16, 16) and outs[1][1].shape == (1, 12, 8, 8)
+    a = rpn.anchor_generators[0].grid_anchors((2, 3), 4)
+    assert a.shape == (18, 4) and a[0].tolist() == [-21.0, -9.0, 24.0, 12.0]   # base 4, scale 8, ratio 0.5, ctr 1.5
