@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--steps", type=int, default=None)
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--workload", default="s2anet_train")
-    p.add_argument("--batch", type=int, default=2, help="images per GPU (s2anet_train)")
+    p.add_argument("--batch", type=int, default=2, help="images per GPU (train workloads)")
     p.add_argument("--size", type=int, default=1024, help="tile size (s2anet_train)")
     p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"])
     p.add_argument("--rois", type=int, default=2000)
@@ -138,29 +138,30 @@ def make_step(workload, d):
     raise SystemExit("unknown workload")
 
 
-S2ANET_CFG = dict(
-    model=dict(
-        type="S2ANet",
-        backbone=dict(type="Resnet50", frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"],
-                      pretrained=True),
-        neck=dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
-                  add_extra_convs="on_input", num_outs=5),
-        bbox_head=dict(type="S2ANetHead", num_classes=16, in_channels=256, feat_channels=256, stacked_convs=2,
-                       with_orconv=True, anchor_ratios=[1.0], anchor_strides=[8, 16, 32, 64, 128], anchor_scales=[4],
-                       target_means=[.0, .0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0, 1.0])),
-    # configs/s2anet/s2anet_r50_fpn_1x_dota.py:L151-166 (model section identical to L2-96 there)
-    optimizer=dict(type="SGD", lr=0.01 / 4., momentum=0.9, weight_decay=0.0001, grad_clip=dict(max_norm=35, norm_type=2)),
-    scheduler=dict(type="StepLR", warmup="linear", warmup_iters=500, warmup_ratio=1.0 / 3, milestones=[7, 10]))
 
 
-def make_s2anet(a, rank, dev):
-    """S2ANet-R50-FPN train step (SURVEY 8d cfg 2): `batch` synthetic 1024x1024 tiles per GPU, 64 random OBB gts
-    each, random-init weights of the reference architecture, SGD+clip+StepLR, DDP when world > 1."""
+from jdet_amd.config.named import ORCNN_CFG, RETINANET_CFG, S2ANET_CFG, roitrans_train_cfg  # noqa: E402
+
+
+TRAIN_WORKLOADS = {
+    # name: (config, model title, images per GPU in BASELINE.json, config-file note)
+    "s2anet_train": (lambda: S2ANET_CFG, "S2ANet-R50-FPN", "configs/s2anet/s2anet_r50_fpn_1x_dota.py"),
+    "orcnn_train": (lambda: ORCNN_CFG, "Oriented-RCNN R50-FPN", "configs/oriented_rcnn_r50_fpn_1x_dota_with_flip.py"),
+    "roitrans_train": (lambda: roitrans_train_cfg("Resnet101"), "RoI-Transformer R101-FPN",
+                       "configs/faster_rcnn_RoITrans_r50_fpn_1x_dota.py with Resnet101 (SURVEY 8d cfg 4)"),
+    "roitrans_r50_train": (lambda: roitrans_train_cfg("Resnet50"), "RoI-Transformer R50-FPN",
+                           "configs/faster_rcnn_RoITrans_r50_fpn_1x_dota.py"),
+}
+
+
+def make_train(a, rank, dev):
+    """One train step of a named config (SURVEY 8d cfg 2/3/4): `batch` synthetic tiles per GPU, 64 random OBB gts
+    each, random-init weights of the reference architecture, SGD + clip + StepLR, DDP (RCCL) when world > 1."""
     import jdet_amd.models  # noqa: F401
     from jdet_amd.runner import Runner, synthetic_batch
     torch.manual_seed(1234)  # identical replicas
     amp = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.amp]
-    runner = Runner(S2ANET_CFG, device=dev, amp_dtype=amp,
+    runner = Runner(TRAIN_WORKLOADS[a.workload][0](), device=dev, amp_dtype=amp,
                     conv_autotune=os.environ.get("JDET_CUDNN_BENCHMARK", "1") == "1")
     images, targets = synthetic_batch(a.batch, a.size, dev, seed=2 + rank)
     images = images.contiguous(memory_format=torch.channels_last)
@@ -168,19 +169,6 @@ def make_s2anet(a, rank, dev):
     def step():
         runner.train_step(images, targets)
     return step, runner
-
-
-RETINANET_CFG = dict(
-    # configs/rotated_retinanet/rotated_retinanet_obb_r50_fpn_1x_dota.py:L2-57 (L1Loss only matters in training)
-    model=dict(
-        type="RotatedRetinaNet",
-        backbone=dict(type="Resnet50", frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"],
-                      pretrained=True),
-        neck=dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
-                  add_extra_convs="on_input", num_outs=5),
-        bbox_head=dict(type="RotatedRetinaHead", num_classes=16, in_channels=256, feat_channels=256, stacked_convs=4,
-                       octave_base_scale=4, scales_per_octave=3, anchor_ratios=[1.0, 0.5, 2.0],
-                       anchor_strides=[8, 16, 32, 64, 128], loss_bbox=dict(type="L1Loss", loss_weight=1.0))))
 
 
 def make_retinanet_infer(a, rank, dev):
@@ -326,11 +314,11 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    if a.workload in ("s2anet_train", "retinanet_infer"):
-        if a.workload == "s2anet_train":
-            step, runner = make_s2anet(a, rank, dev)
+    if a.workload in TRAIN_WORKLOADS or a.workload == "retinanet_infer":
+        if a.workload in TRAIN_WORKLOADS:
+            step, runner = make_train(a, rank, dev)
             per_step = a.batch
-            title = "img/s S2ANet-R50-FPN train step, %dx%d synthetic tiles" % (a.size, a.size)
+            title = "img/s %s train step, %dx%d synthetic tiles" % (TRAIN_WORKLOADS[a.workload][1], a.size, a.size)
         else:
             step, runner = make_retinanet_infer(a, rank, dev)
             per_step = 1
@@ -343,10 +331,11 @@ def main():
                 "warmup": a.warmup, "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": {"none": "f32", "bf16": "bf16", "fp16": "f16"}[a.amp],
                 "data": "synthetic",
-                "config": ({"workload": "s2anet_train", "model": "S2ANet-R50-FPN (configs/s2anet/s2anet_r50_fpn_1x_dota.py)",
+                "config": ({"workload": a.workload,
+                            "model": "%s (%s)" % TRAIN_WORKLOADS[a.workload][1:],
                             "global_batch": a.batch * world, "tile": "%dx%d" % (a.size, a.size), "gts_per_image": 64,
-                            "optimizer": "SGD lr 0.0025 mom 0.9 wd 1e-4 clip 35 + StepLR warm-up",
-                            "parallelism": "dp%d (DDP, RCCL all-reduce)" % world} if a.workload == "s2anet_train" else
+                            "optimizer": "SGD mom 0.9 wd 1e-4 clip 35 + StepLR warm-up (the config's lr)",
+                            "parallelism": "dp%d (DDP, RCCL all-reduce)" % world} if a.workload in TRAIN_WORKLOADS else
                            {"workload": "retinanet_infer",
                             "model": "RetinaNet-OBB R50-FPN (configs/rotated_retinanet/rotated_retinanet_obb_r50_fpn_1x_dota.py)",
                             "global_batch": world, "tile": "%dx%d" % (a.size, a.size),

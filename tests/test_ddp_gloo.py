@@ -55,7 +55,7 @@ def _worker(rank, world, port, out):
         from jdet_amd.utils.general import sync
         _register_tiny()
         torch.manual_seed(7)                      # identical replicas
-        r = Runner(CFG, device="cpu", channels_last=False)
+        r = Runner(CFG, device="cpu", channels_last=False, conv_autotune=False)
         assert r.world_size == world and isinstance(r.train_model, nn.parallel.DistributedDataParallel)
         losses = []
         for it in range(3):
@@ -84,7 +84,7 @@ def test_ddp_matches_single_process_on_the_global_batch(tmp_path):
     from jdet_amd.runner import Runner
     _register_tiny()
     torch.manual_seed(7)
-    r = Runner(CFG, device="cpu", channels_last=False, ddp=False)
+    r = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
     losses = []
     for it in range(3):
         i0, t0 = _batch(100 + 10 * it + 0)

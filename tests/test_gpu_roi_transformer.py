@@ -8,57 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def roitrans_cfg(backbone="Resnet50"):
-    # configs/faster_rcnn_RoITrans_r50_fpn_1x_dota.py:L1-125
-    return dict(
-        type="RoITransformer",
-        backbone=dict(type=backbone, frozen_stages=1, return_stages=["layer1", "layer2", "layer3", "layer4"],
-                      pretrained=False),
-        neck=dict(type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=0,
-                  add_extra_convs=False, num_outs=5),
-        rpn_head=dict(type="FasterrcnnHead", in_channels=256, feat_channels=256, anchor_scales=[8],
-                      anchor_ratios=[0.5, 1.0, 2.0], anchor_strides=[4, 8, 16, 32, 64],
-                      target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0],
-                      loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=True, loss_weight=1.0),
-                      loss_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0)),
-        bbox_roi_extractor=dict(type="SingleRoIExtractor",
-                                roi_layer=dict(type="ROIAlign", output_size=7, sampling_ratio=2, version=1),
-                                out_channels=256, featmap_strides=[4, 8, 16, 32]),
-        bbox_head=dict(type="SharedFCBBoxHeadRbbox", num_fcs=2, in_channels=256, fc_out_channels=1024,
-                       roi_feat_size=7, num_classes=16, target_means=[0., 0., 0., 0., 0.],
-                       target_stds=[0.1, 0.1, 0.2, 0.2, 0.1], reg_class_agnostic=True, with_module=False,
-                       loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=False, loss_weight=1.0),
-                       loss_bbox=dict(type="SmoothL1Loss", beta=1.0, loss_weight=1.0)),
-        rbbox_roi_extractor=dict(type="RboxSingleRoIExtractor",
-                                 roi_layer=dict(type="ROIAlignRotated", output_size=7, sampling_ratio=2),
-                                 out_channels=256, featmap_strides=[4, 8, 16, 32]),
-        rbbox_head=dict(type="SharedFCBBoxHeadRbbox", num_fcs=2, in_channels=256, fc_out_channels=1024,
-                        roi_feat_size=7, num_classes=16, target_means=[0., 0., 0., 0., 0.],
-                        target_stds=[0.05, 0.05, 0.1, 0.1, 0.05], reg_class_agnostic=False,
-                        loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=False, loss_weight=1.0),
-                        loss_bbox=dict(type="SmoothL1Loss", beta=1.0, loss_weight=1.0)),
-        train_cfg=dict(
-            rpn=dict(assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3,
-                                   ignore_iof_thr=-1, iou_calculator=dict(type="BboxOverlaps2D_v1")),
-                     sampler=dict(type="RandomSampler", num=256, pos_fraction=0.5, neg_pos_ub=-1,
-                                  add_gt_as_proposals=False),
-                     allowed_border=0, pos_weight=-1, debug=False),
-            rpn_proposal=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7,
-                              min_bbox_size=0),
-            rcnn=[dict(assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5,
-                                     ignore_iof_thr=-1, iou_calculator=dict(type="BboxOverlaps2D_v1")),
-                       sampler=dict(type="RandomSampler", num=512, pos_fraction=0.25, neg_pos_ub=-1,
-                                    add_gt_as_proposals=True),
-                       pos_weight=-1, debug=False),
-                  dict(assigner=dict(type="MaxIoUAssignerRbbox", pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5,
-                                     ignore_iof_thr=-1, iou_calculator=dict(type="BboxOverlaps2D_rotated")),
-                       sampler=dict(type="RandomSamplerRotated", num=512, pos_fraction=0.25, neg_pos_ub=-1,
-                                    add_gt_as_proposals=True),
-                       pos_weight=-1, debug=False)]),
-        test_cfg=dict(rpn=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7,
-                               min_bbox_size=0),
-                      rcnn=dict(score_thr=0.05, nms=dict(type="py_cpu_nms_poly_fast", iou_thr=0.1),
-                                max_per_img=2000)))
+from jdet_amd.config.named import roitrans_cfg  # noqa: E402
+
+
 
 
 def test_roi_transformer_train_step_and_inference(dev):

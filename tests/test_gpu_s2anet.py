@@ -69,9 +69,9 @@ def test_train_step_and_inference(dev):
 def test_runner_train_steps_reduce_loss(dev):
     """Runner (SGD + clip + StepLR warm-up) on a fixed synthetic batch: the loss goes down and stays finite."""
     from jdet_amd.runner import Runner, synthetic_batch
-    import bench
+    from jdet_amd.config.named import RETINANET_CFG, S2ANET_CFG  # noqa: F401
     torch.manual_seed(0)
-    r = Runner(bench.S2ANET_CFG, device=dev)
+    r = Runner(S2ANET_CFG, device=dev, conv_autotune=False)   # no solver search in tests
     images, targets = synthetic_batch(2, 256, dev, seed=3, num_gts=16)
     first = None
     for i in range(12):
@@ -85,13 +85,13 @@ def test_runner_train_steps_reduce_loss(dev):
 def test_retinanet_obb_train_and_infer(dev):
     """RetinaNet-OBB (BASELINE configs[1]) built from the reference config shape: train losses finite, 9 anchors
     per location, inference returns (polys, scores, labels)."""
-    import bench
+    from jdet_amd.config.named import RETINANET_CFG, S2ANET_CFG  # noqa: F401
     import jdet_amd.models  # noqa: F401
     from jdet_amd.runner import synthetic_batch
     from jdet_amd.utils.general import parse_losses
     from jdet_amd.utils.registry import MODELS, build_from_cfg
     torch.manual_seed(0)
-    m = build_from_cfg(bench.RETINANET_CFG["model"], MODELS).to(dev)
+    m = build_from_cfg(RETINANET_CFG["model"], MODELS).to(dev)
     assert m.bbox_head.num_anchors == 9 and m.bbox_head.retina_reg.out_channels == 45
     images, targets = synthetic_batch(2, 256, dev, seed=4, num_gts=8)
     m.train()
