@@ -170,6 +170,18 @@ int jdet_delta2bbox_rotated(const float* rois, const float* deltas, int n, int n
 int jdet_bbox2delta_rotated(const float* proposals, const float* gt, int n, const float* means5,
                             const float* stds5, float* out, jdet_stream_t stream);
 
+/* Dense anchor targets: replaces the index-list scatter of anchor_target_single
+ * (models/boxes/anchor_target.py:L137-168) for the PseudoSampler case.  gt_inds (A) is the assigner's
+ * output (0 negative, -1 ignored, i+1 = gt i); every anchor gets label (gt_labels[i] or 1 when gt_labels is
+ * NULL; 0 otherwise), label weight (pos_weight / 1 / 0), encoded target (bbox2delta_rotated arithmetic, zeros
+ * for non-positives) and box weight (1 / 0).  *num_pos (device, zeroed by the caller) += number of positives.
+ * means5 / stds5 are HOST pointers. */
+int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int32_t* gt_labels,
+                                const int32_t* gt_inds, int A, int K, const float* means5,
+                                const float* stds5, float pos_weight, int32_t* labels,
+                                float* label_weights, float* bbox_targets, float* bbox_weights,
+                                int32_t* num_pos, jdet_stream_t stream);
+
 /* MaxIoUAssigner.assign_wrt_overlaps (models/boxes/assigner.py:L160-219) in two launches, no host
  * sync (the reference loops over gts in Python with a masked store per gt and jt.sync_all()).
  *   overlaps (K, A) row-major, gts are rows (assigner.py:L143)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),
     "jdet_bbox2delta_rotated": (_i, [_p, _p, _i, _p, _p, _p, _p]),
+    "jdet_anchor_targets_rotated": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "jdet_assign_max_iou_workspace": (_sz, [_i]),
     "jdet_assign_max_iou": (_i, [_p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i, _p, _p, _p, _p, _sz, _p]),
 }
@@ -113,6 +114,11 @@ def f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+def vec5(v):
+    """host float[5] argument (codec means / stds)"""
+    return (ctypes.c_float * 5)(*[float(x) for x in v])
 
 
 def ptr(t):

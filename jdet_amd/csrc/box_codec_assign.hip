@@ -56,27 +56,61 @@ __global__ __launch_bounds__(256) void delta2bbox_rotated_kernel(const float* __
   }
 }
 
+__device__ __forceinline__ void encode_one(const float* __restrict__ p, const float* __restrict__ g, const Vec5& means,
+                                           const Vec5& stds, float* __restrict__ o) {
+  const float pw = p[2], ph = p[3], pa = p[4];
+  const float c = cosf(pa), s = sinf(pa);
+  const float cx = g[0] - p[0], cy = g[1] - p[1];
+  float d[5];
+  d[0] = (c * cx + s * cy) / pw;
+  d[1] = (-s * cx + c * cy) / ph;
+  // jt.safe_log = log(clamp(x, 1e-30, 1e30))
+  d[2] = logf(fminf(fmaxf(g[2] / pw, 1e-30f), 1e30f));
+  d[3] = logf(fminf(fmaxf(g[3] / ph, 1e-30f), 1e30f));
+  d[4] = norm_angle(g[4] - pa) / (float)M_PI;
+#pragma unroll
+  for (int k = 0; k < 5; k++) o[k] = (d[k] - means.v[k]) / stds.v[k];
+}
+
 __global__ __launch_bounds__(256) void bbox2delta_rotated_kernel(const float* __restrict__ proposals,
                                                                  const float* __restrict__ gt, long n,
                                                                  Vec5 means, Vec5 stds,
                                                                  float* __restrict__ out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float* p = proposals + i * 5;
-    const float* g = gt + i * 5;
-    const float pw = p[2], ph = p[3], pa = p[4];
-    const float c = cosf(pa), s = sinf(pa);
-    const float cx = g[0] - p[0], cy = g[1] - p[1];
-    float d[5];
-    d[0] = (c * cx + s * cy) / pw;
-    d[1] = (-s * cx + c * cy) / ph;
-    // jt.safe_log = log(clamp(x, 1e-30, 1e30))
-    d[2] = logf(fminf(fmaxf(g[2] / pw, 1e-30f), 1e30f));
-    d[3] = logf(fminf(fmaxf(g[3] / ph, 1e-30f), 1e30f));
-    d[4] = norm_angle(g[4] - pa) / (float)M_PI;
-    float* o = out + i * 5;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    encode_one(proposals + i * 5, gt + i * 5, means, stds, out + i * 5);
+}
+
+// ---- dense anchor targets ---------------------------------------------------------------------
+// anchor_target_single (models/boxes/anchor_target.py:L105-180) for the PseudoSampler case, without
+// the pos_inds / neg_inds index lists: every anchor writes its own label, label weight, encoded box
+// target and box weight from its assignment (0 = negative, -1 = ignored, i+1 = gt i).  Fixed shapes
+// in and out -- no nonzero(), no host sync; the number of positives stays on the device.
+__global__ __launch_bounds__(256) void anchor_targets_rotated_kernel(
+    const float* __restrict__ anchors, const float* __restrict__ gt, const int32_t* __restrict__ gt_labels,
+    const int32_t* __restrict__ gt_inds, int A, Vec5 means, Vec5 stds, float pos_weight,
+    int32_t* __restrict__ labels, float* __restrict__ label_weights, float* __restrict__ bbox_targets,
+    float* __restrict__ bbox_weights, int32_t* __restrict__ num_pos) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int gi = j < A ? gt_inds[j] : 0;
+  const bool pos = gi > 0;
+  if (j < A) {
+    float* t = bbox_targets + (size_t)j * 5;
+    float* w = bbox_weights + (size_t)j * 5;
+    if (pos) {
+      encode_one(anchors + (size_t)j * 5, gt + (size_t)(gi - 1) * 5, means, stds, t);
 #pragma unroll
-    for (int k = 0; k < 5; k++) o[k] = (d[k] - means.v[k]) / stds.v[k];
+      for (int k = 0; k < 5; k++) w[k] = 1.f;
+      labels[j] = gt_labels ? gt_labels[gi - 1] : 1;
+      label_weights[j] = pos_weight;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) t[k] = w[k] = 0.f;
+      labels[j] = 0;
+      label_weights[j] = gi == 0 ? 1.f : 0.f;
+    }
   }
+  const unsigned long long m = __ballot(pos);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(num_pos, __popcll(m));
 }
 
 // ---- MaxIoUAssigner ------------------------------------------------------------------------
@@ -191,6 +225,27 @@ JDET_API int jdet_bbox2delta_rotated(const float* proposals, const float* gt, in
   }
   hipLaunchKernelGGL(bbox2delta_rotated_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                      proposals, gt, (long)n, m, s, out);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int32_t* gt_labels,
+                                         const int32_t* gt_inds, int A, int K, const float* means5,
+                                         const float* stds5, float pos_weight, int32_t* labels,
+                                         float* label_weights, float* bbox_targets, float* bbox_weights,
+                                         int32_t* num_pos, jdet_stream_t stream) {
+  if (A < 0 || K < 0) return JDET_E_BADARG;
+  if (A == 0) return JDET_OK;
+  if (!anchors || !gt_inds || !means5 || !stds5 || !labels || !label_weights || !bbox_targets || !bbox_weights ||
+      !num_pos || (K > 0 && !gt))
+    return JDET_E_BADARG;
+  Vec5 m, s;
+  for (int k = 0; k < 5; k++) {
+    m.v[k] = means5[k];
+    s.v[k] = stds5[k];
+  }
+  hipLaunchKernelGGL(anchor_targets_rotated_kernel, dim3((A + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     anchors, gt, gt_labels, gt_inds, A, m, s, pos_weight, labels, label_weights, bbox_targets,
+                     bbox_weights, num_pos);
   return jdet_launch_status();
 }
 

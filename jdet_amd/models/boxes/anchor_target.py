@@ -98,9 +98,57 @@ def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
     return (labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds)
 
 
+def _dense_ok(cfg, sampling, img_metas, gt_bboxes_ignore_list, anchors, encode_fn):
+    """the case every single-stage rotated config hits: PseudoSampler, every anchor valid, no ignore
+    regions, MaxIoUAssigner on 5-parameter boxes, DeltaXYWHABBoxCoder targets, device tensors"""
+    if sampling or encode_fn is not None or cfg.get("reg_decoded_bbox", False) or cfg.get("allowed_border", -1) >= 0:
+        return False
+    if not all(bool(m.get("_all_valid", False)) for m in img_metas):
+        return False
+    if any(g is not None and g.numel() > 0 for g in gt_bboxes_ignore_list):
+        return False
+    coder, assigner = cfg.get("bbox_coder", ""), cfg.get("assigner", "")
+    if coder == "" or assigner == "" or coder.get("type") != "DeltaXYWHABBoxCoder":
+        return False
+    if assigner.get("type") != "MaxIoUAssigner" or assigner.get("ignore_iof_thr", -1) > 0:
+        return False
+    return anchors.is_cuda and anchors.shape[-1] == 5 and anchors.dtype == torch.float32
+
+
+def anchor_target_dense(anchor_list, gt_bboxes_list, gt_labels_list, cfg):
+    """Fixed-shape twin of `anchor_target` (same values): per image one IoU launch, the fused assigner and
+    ONE fused target launch (jdet_anchor_targets_rotated) instead of nonzero + 6 index scatters; the number of
+    positives stays on the device.  anchor_list: per image a (A,5) tensor."""
+    from jdet_amd import _lib as L
+    assigner = build_from_cfg(cfg.get("assigner", ""), BOXES)
+    coder = build_from_cfg(cfg.get("bbox_coder", ""), BOXES)
+    pos_weight = cfg.get("pos_weight", -1)
+    pos_weight = 1.0 if pos_weight <= 0 else float(pos_weight)
+    num_imgs = len(anchor_list)
+    dev = anchor_list[0].device
+    A = anchor_list[0].shape[0]
+    labels = torch.empty((num_imgs, A), dtype=torch.int32, device=dev)
+    label_weights = torch.empty((num_imgs, A), dtype=torch.float32, device=dev)
+    bbox_targets = torch.empty((num_imgs, A, 5), dtype=torch.float32, device=dev)
+    bbox_weights = torch.empty((num_imgs, A, 5), dtype=torch.float32, device=dev)
+    num_pos = torch.zeros((num_imgs,), dtype=torch.int32, device=dev)
+    means, stds = L.vec5(coder.means), L.vec5(coder.stds)
+    for i in range(num_imgs):
+        anchors, gt = L.f32c(anchor_list[i]), L.f32c(gt_bboxes_list[i])
+        res = assigner.assign(anchors, gt, None, None)
+        gl = gt_labels_list[i].to(torch.int32).contiguous() if gt_labels_list[i] is not None else None
+        L.check(L.lib().jdet_anchor_targets_rotated(
+            L.ptr(anchors), L.ptr(gt), L.ptr(gl), L.ptr(res.gt_inds), A, gt.shape[0], means, stds, pos_weight,
+            L.ptr(labels[i]), L.ptr(label_weights[i]), L.ptr(bbox_targets[i]), L.ptr(bbox_weights[i]),
+            L.ptr(num_pos[i:i + 1]), L.stream_ptr(anchors)), "jdet_anchor_targets_rotated")
+    # sum_img max(npos_img, 1) (anchor_target.py:L77) as a 0-dim device tensor: the loss normaliser never
+    # forces a host sync
+    return labels, label_weights, bbox_targets, bbox_weights, num_pos.clamp(min=1).sum().to(torch.float32)
+
+
 def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, target_means, target_stds, cfg,
                   gt_bboxes_ignore_list=None, gt_labels_list=None, label_channels=1, sampling=True,
-                  unmap_outputs=True, encode_fn=None):
+                  unmap_outputs=True, encode_fn=None, dense=True):
     num_imgs = len(img_metas)
     assert len(anchor_list) == len(valid_flag_list) == num_imgs
     num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
@@ -112,6 +160,11 @@ def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, targe
         gt_bboxes_ignore_list = [None for _ in range(num_imgs)]
     if gt_labels_list is None:
         gt_labels_list = [None for _ in range(num_imgs)]
+    if dense and _dense_ok(cfg, sampling, img_metas, gt_bboxes_ignore_list, anchor_list[0], encode_fn):
+        labels, label_weights, bbox_targets, bbox_weights, npos = anchor_target_dense(
+            anchor_list, gt_bboxes_list, gt_labels_list, cfg)
+        split = lambda t: list(torch.split(t, num_level_anchors, dim=1))  # noqa: E731
+        return (split(labels), split(label_weights), split(bbox_targets), split(bbox_weights), npos, 0)
     (all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_inds_list, neg_inds_list) = multi_apply(
         anchor_target_single, anchor_list, valid_flag_list, gt_bboxes_list, gt_bboxes_ignore_list, gt_labels_list,
         img_metas, target_means=target_means, target_stds=target_stds, cfg=cfg, label_channels=label_channels,

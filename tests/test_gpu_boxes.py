@@ -137,3 +137,46 @@ def test_anchor_target_vs_oracle(dev):
         np.testing.assert_allclose(torch.cat([l[i] for l in bt_list]).cpu().numpy(), bt, rtol=2e-5, atol=2e-5)
     assert (npos, nneg) == (tot_pos, tot_neg)
     assert [tuple(l.shape) for l in labels_list] == [(2, (1024 // s) ** 2) for s in strides]
+
+
+def test_dense_anchor_targets_equal_index_path(dev):
+    """fixed-shape target path (fused kernel, no nonzero / host sync) == the reference-shaped index path"""
+    from jdet_amd.models.boxes.anchor_target import anchor_target
+    rng = np.random.default_rng(11)
+    sizes = [(16, 16), (8, 8), (4, 4)]
+    strides = [8, 16, 32]
+    cfg = dict(assigner=dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0,
+                             ignore_iof_thr=-1, iou_calculator=dict(type="BboxOverlaps2D_rotated")),
+               bbox_coder=dict(type="DeltaXYWHABBoxCoder", target_means=(0., 0., 0., 0., 0.),
+                               target_stds=(0.5, 0.5, 1., 1., 2.), clip_border=True),
+               allowed_border=-1, pos_weight=-1, debug=False)
+
+    def inputs():
+        anchors, flags = [], []
+        for (h, w), s in zip(sizes, strides):
+            yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+            a = np.stack([xx.ravel() * s + s / 2, yy.ravel() * s + s / 2, np.full(h * w, 4.0 * s), np.full(h * w, 4.0 * s),
+                          rng.uniform(-0.6, 0.6, h * w)], 1).astype(np.float32)
+            anchors.append(torch.from_numpy(a).to(dev))
+            flags.append(torch.ones(h * w, dtype=torch.bool, device=dev))
+        return anchors, flags
+    a0, f0 = inputs()
+    gts, labels = [], []
+    for k in (7, 1):
+        g = np.concatenate([rng.uniform(10, 118, (k, 2)), rng.uniform(20, 70, (k, 2)), rng.uniform(-1.5, 1.5, (k, 1))], 1)
+        gts.append(torch.from_numpy(g.astype(np.float32)).to(dev))
+        labels.append(torch.from_numpy(rng.integers(1, 16, k).astype(np.int32)).to(dev))
+    metas = [dict(img_shape=(128, 128), pad_shape=(128, 128), _all_valid=True) for _ in range(2)]
+    outs = []
+    for dense in (True, False):
+        al = [list(a0), list(a0)]
+        fl = [list(f0), list(f0)]
+        outs.append(anchor_target(al, fl, gts, [dict(m) for m in metas], None, None, cfg, gt_labels_list=labels,
+                                  label_channels=15, sampling=False, dense=dense))
+    d, s = outs
+    assert torch.is_tensor(d[4]) and d[4].dim() == 0 and isinstance(s[4], int)
+    assert float(d[4]) == float(s[4]) and s[4] >= 2
+    for k in range(4):
+        for lv in range(3):
+            assert d[k][lv].shape == s[k][lv].shape
+            assert torch.equal(d[k][lv].float(), s[k][lv].float()), (k, lv)
