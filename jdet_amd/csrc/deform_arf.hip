@@ -254,8 +254,8 @@ JDET_API int jdet_deform_col2im(const float* col, const float* offset, int B, in
   if (e) return e;
   if (B == 0) return JDET_OK;
   if (!col || !offset || !grad_im) return JDET_E_BADARG;
-  hipError_t he = hipMemsetAsync(grad_im, 0, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
-  if (he != hipSuccess) return (int)he;
+  int he = jdet_zero_async(grad_im, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
+  if (he) return he;
   const long n = (long)C * kh * kw * p.Ho * p.Wo * B;
   hipLaunchKernelGGL(deform_col2im_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, col,
                      offset, p, grad_im);

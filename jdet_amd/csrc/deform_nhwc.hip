@@ -165,8 +165,8 @@ JDET_API int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset
   CsrWs w = csr_carve(workspace, npix, ntaps);
   if (workspace_bytes < w.bytes) return JDET_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t he = hipMemsetAsync(w.counts, 0, sizeof(int) * npix, st);
-  if (he != hipSuccess) return (int)he;
+  int he = jdet_zero_async(w.counts, sizeof(int) * npix, st);
+  if (he) return he;
   hipLaunchKernelGGL(deform_taps_kernel, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, st, offset, p, nitems,
                      w.tap_key, w.tap_w, w.counts);
   return csr_finish_and_gather(w, npix, ntaps, 4, grad_cols, C, grad_x_nhwc, st);

@@ -1111,8 +1111,8 @@ int jdet_roi_align_backward_atomic(int variant, const float* grad_out, const flo
   if (!grad_in && (long)N * C * H * W > 0) return JDET_E_BADARG;
   int e = check_common(variant, grad_out, rois, grad_in, N, C, H, W, R, PH, PW, n_orient);
   if (e) return e;
-  hipError_t he = hipMemsetAsync(grad_in, 0, sizeof(float) * (size_t)N * C * H * W, st);
-  if (he != hipSuccess) return (int)he;
+  int he = jdet_zero_async(grad_in, sizeof(float) * (size_t)N * C * H * W, st);
+  if (he) return he;
   if (R == 0) return JDET_OK;
   switch (variant) {
     case JDET_ROI_ROTATED:

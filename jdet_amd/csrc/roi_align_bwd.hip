@@ -82,8 +82,8 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
   const long npix = (long)N * H * W, ntaps = (long)R * nbins * spb * 4;
   CsrWs w = csr_carve(ws, npix, ntaps);
   float* gT = (float*)((char*)ws + w.bytes);
-  hipError_t he = hipMemsetAsync(w.counts, 0, sizeof(int) * npix, st);
-  if (he != hipSuccess) return (int)he;
+  int he = jdet_zero_async(w.counts, sizeof(int) * npix, st);
+  if (he) return he;
   const long nsamp = (long)R * nbins * spb;
   hipLaunchKernelGGL((bwd_taps_kernel<VARIANT>), dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, rois, R,
                      H, W, PH, PW, scale, sample_num, w.tap_key, w.tap_w, w.counts);

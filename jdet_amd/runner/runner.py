@@ -46,8 +46,13 @@ def synthetic_batch(batch, size, device, seed=0, num_gts=64, num_classes=15):
 
 
 class Runner:
-    def __init__(self, cfg, device=None, ddp=None, channels_last=True, amp_dtype=None, conv_autotune=True):
+    def __init__(self, cfg, device=None, ddp=None, channels_last=True, amp_dtype=None, conv_autotune=True,
+                 graph=None):
         self.cfg = cfg
+        # graph=True: the whole step (forward, losses, backward | one flat all-reduce | clip + SGD) replays as
+        # HIP graphs; needs a model whose step is fixed-shape and sync-free (the single-stage heads)
+        self.use_graph = (os.environ.get("JDET_TRAIN_GRAPH", "0") == "1") if graph is None else bool(graph)
+        self._graphs = {}
         if conv_autotune:
             # DOTA tiles have one fixed shape: let MIOpen time its solvers once per conv geometry instead of
             # taking the heuristic pick (measured 63.6 -> 58.0 ms per S2ANet step, profiles/r01_miopen_find.txt)
@@ -72,6 +77,11 @@ class Runner:
         self.scheduler = build_from_cfg(dict(sch_cfg), SCHEDULERS, optimizer=self.optimizer) if sch_cfg else None
         use_ddp = self.world_size > 1 if ddp is None else ddp
         self.train_model = self.model
+        if self.use_graph and self.device.type == "cuda":
+            use_ddp = False    # graph mode all-reduces one flat gradient buffer itself
+            if self.world_size > 1:
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, 0)
         if use_ddp:
             self.train_model = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
@@ -79,7 +89,120 @@ class Runner:
         self.iter = 0
         self.epoch = 0
 
+    # ------------------------------------------------------------------ HIP-graph step
+    def _graph_key(self, images, targets):
+        return (tuple(images.shape),) + tuple((k, tuple(v.shape)) for t in targets for k, v in sorted(t.items())
+                                              if torch.is_tensor(v))
+
+    def _flat_grads(self):
+        """one fp32 buffer holding every gradient; p.grad are views with the parameter's own strides, so
+        autograd accumulates in place, the norm / all-reduce see ONE tensor"""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+                o, i, kh, kw = p.shape
+                p.grad = flat[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+            else:
+                p.grad = flat[off:off + n].view(p.shape)
+            off += n
+        return params, flat
+
+    def _capture(self, images, targets):
+        st = dict(images=images.clone(), targets=[{k: (v.clone() if torch.is_tensor(v) else v) for k, v in t.items()}
+                                                   for t in targets])
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        st["lr"] = torch.tensor(float(group["lr"]), device=self.device)
+        params, flat = self._flat_grads()
+        st["flat"] = flat
+        bufs = []
+        for p in params:
+            if opt.state[p].get("momentum_buffer") is None:   # parameter without gradient so far
+                opt.state[p]["momentum_buffer"] = torch.zeros_like(p)
+            bufs.append(opt.state[p]["momentum_buffer"])
+        momentum, wd = group["momentum"], group["weight_decay"]
+        clip = opt.grad_clip
+
+        def fwd_bwd():
+            flat.zero_()
+            if self.amp_dtype is not None:
+                with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
+                    losses = self.model(st["images"], st["targets"])
+            else:
+                losses = self.model(st["images"], st["targets"])
+            total, parsed = parse_losses(losses)
+            total.backward()
+            return total.detach(), {k: v.detach() for k, v in parsed.items()}
+
+        @torch.no_grad()
+        def update():
+            if clip is not None:   # torch.nn.utils.clip_grad_norm_ on the flat buffer: two kernels
+                norm = torch.linalg.vector_norm(flat, float(clip.get("norm_type", 2)))
+                flat.mul_(torch.clamp(clip["max_norm"] / (norm + 1e-6), max=1.0))
+            grads = [p.grad for p in params]
+            if wd != 0:
+                grads = torch._foreach_add(grads, params, alpha=wd)
+            torch._foreach_mul_(bufs, momentum)
+            torch._foreach_add_(bufs, grads)
+            torch._foreach_sub_(params, torch._foreach_mul(bufs, st["lr"]))
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):    # capture-stream warm-up (allocator, MIOpen workspaces)
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        single = self.world_size == 1
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1):
+            st["out"] = fwd_bwd()
+            if single:
+                update()
+        st["g1"] = g1
+        if not single:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                update()
+            st["g2"] = g2
+        return st
+
+    def _graph_step(self, images, targets):
+        if self.iter < 2:    # momentum buffers, anchor caches and the solver search happen eagerly, once
+            return self._eager_step(images, targets)
+        key = self._graph_key(images, targets)
+        st = self._graphs.get(key)
+        if st is None:
+            self.model.train()
+            st = self._graphs[key] = self._capture(images, targets)
+        else:
+            st["images"].copy_(images, non_blocking=True)
+            for dst, src in zip(st["targets"], targets):
+                for k, v in src.items():
+                    if torch.is_tensor(v):
+                        dst[k].copy_(v, non_blocking=True)
+        st["lr"].fill_(float(self.optimizer.param_groups[0]["lr"]))
+        st["g1"].replay()
+        if self.world_size > 1:
+            dist.all_reduce(st["flat"])
+            st["flat"].div_(self.world_size)
+            st["g2"].replay()
+        if self.scheduler is not None:
+            self.scheduler.step(self.iter, self.epoch, by_epoch=True)
+        self.iter += 1
+        return st["out"]
+
     def train_step(self, images, targets):
+        if self.use_graph and self.device.type == "cuda":
+            if self.channels_last and images.dim() == 4:
+                images = images.contiguous(memory_format=torch.channels_last)
+            return self._graph_step(images, targets)
+        return self._eager_step(images, targets)
+
+    def _eager_step(self, images, targets):
         self.train_model.train()
         if self.channels_last and images.dim() == 4:
             images = images.contiguous(memory_format=torch.channels_last)

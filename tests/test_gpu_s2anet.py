@@ -82,6 +82,32 @@ def test_runner_train_steps_reduce_loss(dev):
     assert abs(r.optimizer.cur_lr() - 0.0025 * (1 - (1 - 11 / 500) * (1 - 1 / 3))) < 1e-9
 
 
+def test_graph_step_matches_eager_step(dev):
+    """HIP-graph replay of the whole train step (forward, fused targets, losses, backward, clip, SGD with the lr
+    as a device scalar) follows the eager trajectory: same losses step by step (fp32 atomics in the conv /
+    deform backward make the last digits run-to-run different, hence the tolerance), same lr schedule."""
+    from jdet_amd.config.named import S2ANET_CFG
+    from jdet_amd.runner import Runner, synthetic_batch
+    images, targets = synthetic_batch(2, 256, dev, seed=3, num_gts=16)
+    hist = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        r = Runner(S2ANET_CFG, device=dev, conv_autotune=False, graph=mode)
+        hist[mode] = [float(r.train_step(images, targets)[0]) for _ in range(8)]
+        assert abs(r.optimizer.cur_lr() - 0.0025 * (1 - (1 - 7 / 500) * (1 - 1 / 3))) < 1e-9
+        if mode:
+            assert len(r._graphs) == 1
+    e, g = np.array(hist[False]), np.array(hist[True])
+    assert np.all(np.isfinite(g)) and g[-1] < g[0]
+    np.testing.assert_allclose(g, e, rtol=2e-2)
+    # new data of the same shape replays the same graph; a new shape captures another
+    images2, targets2 = synthetic_batch(2, 256, dev, seed=9, num_gts=16)
+    l2 = float(r.train_step(images2, targets2)[0])
+    assert np.isfinite(l2) and len(r._graphs) == 1
+    images3, targets3 = synthetic_batch(2, 256, dev, seed=9, num_gts=5)
+    assert np.isfinite(float(r.train_step(images3, targets3)[0])) and len(r._graphs) == 2
+
+
 def test_retinanet_obb_train_and_infer(dev):
     """RetinaNet-OBB (BASELINE configs[1]) built from the reference config shape: train losses finite, 9 anchors
     per location, inference returns (polys, scores, labels)."""
