@@ -151,6 +151,24 @@ int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, 
                             int dil_h, int dil_w, float* grad_x_nhwc, void* workspace,
                             size_t workspace_bytes, jdet_stream_t stream);
 
+/* Inference-mode ("frozen statistics") BatchNorm fused with ReLU and the residual add, channels-last.
+ * Replaces the nn.BatchNorm (eval) -> (+identity) -> relu chains of the backbone (models/backbones/resnet.py:
+ * L33-59 BasicBlock, L61-93 Bottleneck, L177-185 norm_eval) -- framework primitives in the reference, not jt.code.
+ *   y = act((x - mean) * rsqrt(var + eps) * weight + bias (+ residual)),  tensors [P = N*H*W][C], C % 4 == 0,
+ *   C/4 a divisor of 256 or in (256, 1024]; weight / bias may be NULL (1 / 0); relu: 0 | 1.
+ * backward: grad_x always; grad_residual (= masked grad_y) if non-NULL; grad_weight / grad_bias if non-NULL (then
+ * x_nhwc and a workspace from the _workspace query are required); y_nhwc is required when relu = 1. */
+int jdet_frozen_bn_act_forward(const float* x_nhwc, const float* residual_nhwc, long P, int C,
+                               const float* weight, const float* bias, const float* running_mean,
+                               const float* running_var, float eps, int relu, float* y_nhwc,
+                               jdet_stream_t stream);
+size_t jdet_frozen_bn_act_backward_workspace(long P, int C);
+int jdet_frozen_bn_act_backward(const float* grad_y_nhwc, const float* y_nhwc, const float* x_nhwc, long P,
+                                int C, const float* weight, const float* bias, const float* running_mean,
+                                const float* running_var, float eps, int relu, float* grad_x_nhwc,
+                                float* grad_residual_nhwc, float* grad_weight, float* grad_bias,
+                                void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
 /* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
  * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
  * out (nOut*nRot, nIn*nOri, kH, kW). */

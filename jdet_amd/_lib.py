@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjdet_hip.so")
 
-_i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+_i, _f, _p, _sz, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes); mirrors include/jdet_hip.h one to one (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -35,6 +35,9 @@ SIGNATURES = {
     "jdet_deform_im2col_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p]),
     "jdet_deform_col2im_nhwc_workspace": (_sz, [_i] * 12),
     "jdet_deform_col2im_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p, _sz, _p]),
+    "jdet_frozen_bn_act_forward": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
+    "jdet_frozen_bn_act_backward_workspace": (_sz, [_l, _i]),
+    "jdet_frozen_bn_act_backward": (_i, [_p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),

@@ -1,0 +1,287 @@
+// Inference-mode BatchNorm fused with its neighbours, channels-last (NHWC).
+//
+// The reference trains its detectors with every backbone BatchNorm in eval mode (resnet.py:L177-185:
+// `norm_eval`), affine parameters still trainable outside the frozen stages.  A bottleneck is therefore
+//   conv -> bn -> relu,  conv -> bn -> relu,  conv -> bn -> (+identity) -> relu      (resnet.py:L61-93)
+// with bn(x) = (x - mean) * rsqrt(var + eps) * w + b a per-channel affine map.  Framework ops run this as
+// bn / relu / add kernels forward and relu-backward / per-channel reduce / scale kernels backward: 11 tensor
+// passes per layer, the reduction at ~1.3 TB/s (profiles/r01_s2anet_train_steady_state_kernels.txt, 4.3 ms
+// of a 41.6 ms S2ANet step).  Here:
+//   forward   y = act(x * a + sh (+ res))                              1 read (+1), 1 write
+//   backward  g = dy * [y > 0];  dx = g * a;  (dres = g);  dbeta = sum g;  dgamma = sum g * xhat
+//             one pass: reads dy, y, x; writes dx (, g); the two per-channel sums accumulate in registers
+//             (a thread keeps the same 4 channels for its whole grid-stride loop), are combined per
+//             workgroup through LDS and finished by a second tiny launch -- deterministic, no atomics.
+// Tensors are [P][C] with P = N*H*W, C % 4 == 0, every access a float4.
+#include "common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct BnParams {
+  const float* w;
+  const float* b;
+  const float* mean;
+  const float* var;
+  float eps;
+};
+
+// a = w * rsqrt(var + eps) and sh = b - mean * a of the 4 channels starting at c
+__device__ __forceinline__ void affine4(const BnParams& p, int c, v4f& a, v4f& sh, v4f& mean, v4f& invstd) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float is = 1.0f / sqrtf(p.var[c + k] + p.eps);
+    const float w = p.w ? p.w[c + k] : 1.f;
+    const float b = p.b ? p.b[c + k] : 0.f;
+    invstd[k] = is;
+    mean[k] = p.mean[c + k];
+    a[k] = w * is;
+    sh[k] = b - p.mean[c + k] * (w * is);
+  }
+}
+
+// launch geometry: blockDim = max(256, C/4) (<= 1024), gridDim*blockDim is a multiple of C/4, so the channel
+// quad of a thread, (global thread id) % (C/4), is the same in every iteration of its grid-stride loop
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(1024) void frozen_bn_fwd_kernel(const v4f* __restrict__ x, const v4f* __restrict__ res,
+                                                             v4f* __restrict__ y, BnParams p, int cpt, size_t n4) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  v4f a, sh, mean, invstd;
+  affine4(p, (int)(g % cpt) * 4, a, sh, mean, invstd);
+  size_t i = g;
+  for (; i + 3 * stride < n4; i += 4 * stride) {   // 4 independent loads in flight per lane
+    v4f v[4], r[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = x[i + u * stride];
+    if (RES) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) r[u] = res[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      v4f o = v[u] * a + sh;
+      if (RES) o += r[u];
+      if (RELU) o = __builtin_elementwise_max(o, (v4f){0.f, 0.f, 0.f, 0.f});
+      y[i + u * stride] = o;
+    }
+  }
+  for (; i < n4; i += stride) {
+    v4f o = x[i] * a + sh;
+    if (RES) o += res[i];
+    if (RELU) o = __builtin_elementwise_max(o, (v4f){0.f, 0.f, 0.f, 0.f});
+    y[i] = o;
+  }
+}
+
+template <bool RELU, bool RES, bool AFFINE>
+__global__ __launch_bounds__(1024) void frozen_bn_bwd_kernel(const v4f* __restrict__ dy, const v4f* __restrict__ y,
+                                                             const v4f* __restrict__ x, v4f* __restrict__ dx,
+                                                             v4f* __restrict__ dres, BnParams p, int cpt, size_t n4,
+                                                             float* __restrict__ partial) {
+  extern __shared__ float s_red[];   // [blockDim][8] when AFFINE
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int cq = (int)(g % cpt);
+  v4f a, sh, mean, invstd;
+  affine4(p, cq * 4, a, sh, mean, invstd);
+  v4f sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+  auto one = [&](size_t i, const v4f& d, const v4f& yy, const v4f& xx) {
+    v4f gq = d;
+    if (RELU) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) gq[k] = yy[k] > 0.f ? d[k] : 0.f;
+    }
+    dx[i] = gq * a;
+    if (RES) dres[i] = gq;
+    if (AFFINE) {
+      sg += gq;
+      sgx += gq * ((xx - mean) * invstd);
+    }
+  };
+  size_t i = g;
+  for (; i + stride < n4; i += 2 * stride) {
+    v4f d[2], yy[2], xx[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      d[u] = dy[i + u * stride];
+      if (RELU) yy[u] = y[i + u * stride];
+      if (AFFINE) xx[u] = x[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) one(i + u * stride, d[u], yy[u], xx[u]);
+  }
+  for (; i < n4; i += stride) {
+    v4f d = dy[i], yy = d, xx = d;
+    if (RELU) yy = y[i];
+    if (AFFINE) xx = x[i];
+    one(i, d, yy, xx);
+  }
+  if (AFFINE) {
+    float* mine = s_red + (size_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      mine[k] = sg[k];
+      mine[4 + k] = sgx[k];
+    }
+    __syncthreads();
+    // threads 0..cpt-1 own one channel quad each; the others of the workgroup with the same quad sit at
+    // threadIdx + m*cpt (blockDim is a multiple of cpt)
+    if ((int)threadIdx.x < cpt) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int t = threadIdx.x; t < (int)blockDim.x; t += cpt)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] += s_red[(size_t)t * 8 + k];
+      // quad of thread t in this workgroup: (blockIdx*blockDim + t) % cpt == t because blockDim % cpt == 0
+      float* out = partial + (size_t)blockIdx.x * 2 * cpt * 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        out[threadIdx.x * 4 + k] = acc[k];                 // dbeta partials
+        out[cpt * 4 + threadIdx.x * 4 + k] = acc[4 + k];   // dgamma partials
+      }
+    }
+  }
+}
+
+// second stage of the per-channel sums: workgroup = 32 channels x 8 row groups, 4 independent loads in flight per
+// lane, LDS combine in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void frozen_bn_finish_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float s_b[8][32], s_g[8][32];
+  const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lane;
+  float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    int b = rg;
+    for (; b + 24 < nblocks; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        sb[u] += partial[(size_t)(b + 8 * u) * 2 * C + c];
+        sg[u] += partial[(size_t)(b + 8 * u) * 2 * C + C + c];
+      }
+    }
+    for (; b < nblocks; b += 8) {
+      sb[0] += partial[(size_t)b * 2 * C + c];
+      sg[0] += partial[(size_t)b * 2 * C + C + c];
+    }
+  }
+  s_b[rg][lane] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+  s_g[rg][lane] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float tb = 0.f, tg = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      tb += s_b[r][lane];
+      tg += s_g[r][lane];
+    }
+    if (dbeta) dbeta[c] = tb;
+    if (dgamma) dgamma[c] = tg;
+  }
+}
+
+struct Geo {
+  int cpt, block, grid;
+};
+
+int geometry(long P, int C, int max_grid, Geo& g) {
+  if (P < 0 || C <= 0) return JDET_E_BADARG;
+  if (C % 4 != 0) return JDET_E_UNSUPPORTED;
+  g.cpt = C / 4;
+  if (g.cpt > 1024) return JDET_E_UNSUPPORTED;
+  // blockDim: multiple of cpt when cpt <= 256 needs 256 % cpt == 0 (power-of-two channel counts); otherwise one
+  // workgroup = one pixel row of quads
+  if (g.cpt <= 256) {
+    if (256 % g.cpt != 0) return JDET_E_UNSUPPORTED;
+    g.block = 256;
+  } else {
+    g.block = g.cpt;
+  }
+  const size_t n4 = (size_t)P * g.cpt;
+  long want = (long)((n4 + (size_t)g.block * 4 - 1) / ((size_t)g.block * 4));
+  if (want < 1) want = 1;
+  g.grid = (int)(want > max_grid ? max_grid : want);
+  return JDET_OK;
+}
+
+constexpr int kFwdGrid = 4096;
+constexpr int kBwdGrid = 512;    // rows of the partial-sum workspace
+
+}  // namespace
+
+JDET_API int jdet_frozen_bn_act_forward(const float* x_nhwc, const float* residual_nhwc, long P, int C,
+                                        const float* weight, const float* bias, const float* running_mean,
+                                        const float* running_var, float eps, int relu, float* y_nhwc,
+                                        jdet_stream_t stream) {
+  Geo g;
+  int e = geometry(P, C, kFwdGrid, g);
+  if (e) return e;
+  if (P == 0) return JDET_OK;
+  if (!x_nhwc || !y_nhwc || !running_mean || !running_var) return JDET_E_BADARG;
+  BnParams p{weight, bias, running_mean, running_var, eps};
+  const size_t n4 = (size_t)P * g.cpt;
+  hipStream_t st = (hipStream_t)stream;
+  const v4f* x = (const v4f*)x_nhwc;
+  const v4f* r = (const v4f*)residual_nhwc;
+  v4f* y = (v4f*)y_nhwc;
+#define JDET_BN_FWD(RELU, RES) \
+  hipLaunchKernelGGL((frozen_bn_fwd_kernel<RELU, RES>), dim3(g.grid), dim3(g.block), 0, st, x, r, y, p, g.cpt, n4)
+  if (relu && r) JDET_BN_FWD(true, true);
+  else if (relu) JDET_BN_FWD(true, false);
+  else if (r) JDET_BN_FWD(false, true);
+  else JDET_BN_FWD(false, false);
+#undef JDET_BN_FWD
+  return jdet_launch_status();
+}
+
+JDET_API size_t jdet_frozen_bn_act_backward_workspace(long P, int C) {
+  Geo g;
+  if (geometry(P, C, kBwdGrid, g) || P == 0) return 0;
+  return sizeof(float) * (size_t)g.grid * 2 * C;
+}
+
+JDET_API int jdet_frozen_bn_act_backward(const float* grad_y_nhwc, const float* y_nhwc, const float* x_nhwc, long P,
+                                         int C, const float* weight, const float* bias, const float* running_mean,
+                                         const float* running_var, float eps, int relu, float* grad_x_nhwc,
+                                         float* grad_residual_nhwc, float* grad_weight, float* grad_bias,
+                                         void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
+  Geo g;
+  int e = geometry(P, C, kBwdGrid, g);
+  if (e) return e;
+  if (P == 0) return JDET_OK;
+  const bool affine = grad_weight != nullptr || grad_bias != nullptr;
+  if (!grad_y_nhwc || !grad_x_nhwc || !running_mean || !running_var || (relu && !y_nhwc) || (affine && !x_nhwc))
+    return JDET_E_BADARG;
+  if (affine && (!workspace || workspace_bytes < jdet_frozen_bn_act_backward_workspace(P, C))) return JDET_E_WORKSPACE;
+  BnParams p{weight, bias, running_mean, running_var, eps};
+  const size_t n4 = (size_t)P * g.cpt;
+  hipStream_t st = (hipStream_t)stream;
+  const v4f* dy = (const v4f*)grad_y_nhwc;
+  const v4f* y = (const v4f*)y_nhwc;
+  const v4f* x = (const v4f*)x_nhwc;
+  v4f* dx = (v4f*)grad_x_nhwc;
+  v4f* dr = (v4f*)grad_residual_nhwc;
+  float* part = (float*)workspace;
+  const size_t lds = affine ? sizeof(float) * 8 * (size_t)g.block : 0;
+#define JDET_BN_BWD(RELU, RES, AFF)                                                                            \
+  hipLaunchKernelGGL((frozen_bn_bwd_kernel<RELU, RES, AFF>), dim3(g.grid), dim3(g.block), lds, st, dy, y, x, dx, dr, \
+                     p, g.cpt, n4, part)
+  const int key = (relu ? 4 : 0) | (dr ? 2 : 0) | (affine ? 1 : 0);
+  switch (key) {
+    case 0: JDET_BN_BWD(false, false, false); break;
+    case 1: JDET_BN_BWD(false, false, true); break;
+    case 2: JDET_BN_BWD(false, true, false); break;
+    case 3: JDET_BN_BWD(false, true, true); break;
+    case 4: JDET_BN_BWD(true, false, false); break;
+    case 5: JDET_BN_BWD(true, false, true); break;
+    case 6: JDET_BN_BWD(true, true, false); break;
+    default: JDET_BN_BWD(true, true, true); break;
+  }
+#undef JDET_BN_BWD
+  e = jdet_launch_status();
+  if (e || !affine) return e;
+  hipLaunchKernelGGL(frozen_bn_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, g.grid, C, grad_weight,
+                     grad_bias);
+  return jdet_launch_status();
+}

@@ -4,11 +4,14 @@ the 3x3), `ResNet` L95-185 (return_stages, frozen_stages, norm_eval), `Resnet50`
 downsample.0/1) so reference checkpoints map 1:1.
 
 The dense convs are the MFMA part of the path: they run through MIOpen/hipBLASLt in channels-last
-(the layout the RoI / deformable kernels want anyway); no custom conv kernels.
+(the layout the RoI / deformable kernels want anyway); no custom conv kernels.  The
+eval-mode BatchNorm -> (+identity) -> ReLU chains between them are one fused HIP pass each
+(ops/frozen_bn.py) whenever the norm layer is an eval-mode BatchNorm2d on a channels-last fp32 tensor.
 """
 import torch
 from torch import nn
 
+from jdet_amd.ops.frozen_bn import frozen_bn_act
 from jdet_amd.utils.registry import BACKBONES
 
 __all__ = ["ResNet", "Resnet18", "Resnet34", "Resnet50", "Resnet101", "Resnet152"]
@@ -25,6 +28,13 @@ def conv1x1(in_planes, out_planes, stride=1):
     conv = nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
     return conv
+
+
+def _downsample(seq, x):
+    """the (conv1x1, norm) pair of `_make_layer`; other module types run as they are"""
+    if isinstance(seq, nn.Sequential) and len(seq) == 2 and isinstance(seq[1], nn.BatchNorm2d):
+        return frozen_bn_act(seq[0](x), seq[1], relu=False)
+    return seq(x)
 
 
 class BasicBlock(nn.Module):
@@ -48,11 +58,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = frozen_bn_act(self.conv1(x), self.bn1)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = _downsample(self.downsample, x)
+        return frozen_bn_act(self.conv2(out), self.bn2, residual=identity)
 
 
 class Bottleneck(nn.Module):
@@ -75,12 +84,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = frozen_bn_act(self.conv1(x), self.bn1)
+        out = frozen_bn_act(self.conv2(out), self.bn2)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.relu(out + identity)
+            identity = _downsample(self.downsample, x)
+        return frozen_bn_act(self.conv3(out), self.bn3, residual=identity)
 
 
 @BACKBONES.register_module()
@@ -149,7 +157,9 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         outputs = []
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.conv1(x)
+        x = frozen_bn_act(x, self.bn1) if isinstance(self.bn1, nn.BatchNorm2d) else self.relu(self.bn1(x))
+        x = self.maxpool(x)
         for i in range(1, 5):
             name = f"layer{i}"
             x = getattr(self, name)(x)
