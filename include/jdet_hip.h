@@ -151,6 +151,20 @@ int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, 
                             int dil_h, int dil_w, float* grad_x_nhwc, void* workspace,
                             size_t workspace_bytes, jdet_stream_t stream);
 
+/* Sigmoid focal loss, replaces the tensor-op chain of models/losses/focal_loss.py:L5-96 (sigmoid_focal_loss with
+ * binary_cross_entropy_with_logits): logits (M, C) row-major, labels (M) int32 (0 = background, k = class k),
+ * weight (M) or NULL; alpha < 0 disables the alpha term.  *loss_sum = sum over all M*C elements (the caller divides
+ * by avg_factor and applies loss_weight); grad_logits (M, C) = d loss_sum / d logits.  Deterministic. */
+size_t jdet_sigmoid_focal_loss_workspace(void);
+int jdet_sigmoid_focal_loss(const float* logits, const int32_t* labels, const float* weight, long M, int C,
+                            float alpha, float gamma, float* loss_sum, float* grad_logits,
+                            void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
+/* AlignConv.get_offset (models/roi_heads/s2anet_head.py:L676-713): anchors (N, H*W, 5) [xc,yc,w,h,theta] in image
+ * coordinates -> offset (N, 2*k*k, H, W), (dy, dx) per tap of the k x k kernel (k odd). */
+int jdet_align_conv_offset(const float* anchors, int N, int H, int W, float stride, int kernel_size,
+                           float* offset, jdet_stream_t stream);
+
 /* Inference-mode ("frozen statistics") BatchNorm fused with ReLU and the residual add, channels-last.
  * Replaces the nn.BatchNorm (eval) -> (+identity) -> relu chains of the backbone (models/backbones/resnet.py:
  * L33-59 BasicBlock, L61-93 Bottleneck, L177-185 norm_eval) -- framework primitives in the reference, not jt.code.

@@ -1,0 +1,131 @@
+// Two launch-count killers of the single-stage heads.
+//
+// 1. Sigmoid focal loss (models/losses/focal_loss.py:L5-96): BCE-with-logits in the max_val-stable form, one-hot
+//    by (class index + 1) == label, per-row weight, (1 - p_t)^gamma, alpha weighting, summed.  The reference is a
+//    chain of ~15 elementwise tensor ops (and ~20 more in autograd's backward) per level per stage: ~350 launches
+//    per S2ANet step.  Here one pass produces the loss sum (deterministic two-stage reduction) AND d loss / d logit;
+//    the autograd backward is a scale of that buffer.  The log(max(., 1e-10)) floor of the reference can never
+//    trigger (the argument is exp(-m) + exp(-x-m) >= 1), so it is not reproduced.
+// 2. AlignConv.get_offset (models/roi_heads/s2anet_head.py:L676-713): the 3x3 sampling grid of a refined anchor
+//    minus the regular grid, ~25 elementwise ops per level per image there, one thread per (image, location) here,
+//    writing the 2*k*k offset planes (dy, dx per tap) the deformable kernels read.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// rows = anchors, C classes; element (r, c): t = (labels[r] == c + 1)
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits,
+                                                        const int32_t* __restrict__ labels,
+                                                        const float* __restrict__ weight, long M, int C, float alpha,
+                                                        float gamma, float* __restrict__ grad,
+                                                        float* __restrict__ partial) {
+  __shared__ float s_part[4];
+  const long n = M * C;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / C;
+    const int c = (int)(i - r * C);
+    const float x = logits[i];
+    const bool t = labels[r] == c + 1;
+    const float w = weight ? weight[r] : 1.f;
+    // stable BCE with logits: (1 - t) * x + max(-x, 0) + log(exp(-m) + exp(-x - m))
+    const float m = fmaxf(-x, 0.f);
+    const float ce = (t ? 0.f : x) + m + logf(expf(-m) + expf(-x - m));
+    const float p = 1.f / (1.f + expf(-x));
+    const float pt = t ? p : 1.f - p;          // probability of the true outcome
+    const float q = 1.f - pt;
+    const float mod = powf(q, gamma);
+    const float at = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+    acc += at * w * ce * mod;
+    // d/dx [ce * q^gamma]: ce = -log(pt);  d pt/dx = s * pt * q with s = +1 (t) / -1 (!t)
+    //   = s * ( -q^(gamma+1) - gamma * q^gamma * pt * ce )  ... written without the division by q
+    const float s = t ? 1.f : -1.f;
+    const float d = -s * (mod * q + gamma * mod * pt * ce);
+    grad[i] = at * w * d;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n,
+                                                           float* __restrict__ out) {
+  __shared__ float s_part[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+constexpr int kFocalGrid = 1024;
+
+// anchors (N, H*W, 5) image coordinates -> offsets (N, 2*k*k, H, W)
+__global__ __launch_bounds__(256) void align_offset_kernel(const float* __restrict__ anchors, int N, int H, int W,
+                                                           float stride, int ks, float* __restrict__ offset) {
+  const long hw = (long)H * W;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * hw) return;
+  const long n = idx / hw, pos = idx - n * hw;
+  const int yc = (int)(pos / W), xc = (int)(pos - (long)yc * W);
+  const float* a = anchors + idx * 5;
+  const float x_ctr = a[0] / stride, y_ctr = a[1] / stride, w = a[2] / stride, h = a[3] / stride;
+  const float cs = cosf(a[4]), sn = sinf(a[4]);
+  const float dw = w / (float)ks, dh = h / (float)ks;
+  const int pad = (ks - 1) / 2;
+  float* o = offset + n * 2 * ks * ks * hw + pos;
+  for (int i = 0; i < ks; i++)
+    for (int j = 0; j < ks; j++) {
+      const float yy = (float)(i - pad), xx = (float)(j - pad);
+      const float x = dw * xx, y = dh * yy;
+      const float xr = cs * x - sn * y, yr = sn * x + cs * y;
+      const float x_anchor = xr + x_ctr, y_anchor = yr + y_ctr;
+      const float x_conv = (float)xc + xx, y_conv = (float)yc + yy;
+      const int tap = i * ks + j;
+      o[(long)(2 * tap) * hw] = y_anchor - y_conv;
+      o[(long)(2 * tap + 1) * hw] = x_anchor - x_conv;
+    }
+}
+
+}  // namespace
+
+JDET_API size_t jdet_sigmoid_focal_loss_workspace(void) { return sizeof(float) * kFocalGrid; }
+
+JDET_API int jdet_sigmoid_focal_loss(const float* logits, const int32_t* labels, const float* weight, long M, int C,
+                                     float alpha, float gamma, float* loss_sum, float* grad_logits,
+                                     void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
+  if (M < 0 || C <= 0 || !loss_sum) return JDET_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) return jdet_zero_async(loss_sum, sizeof(float), st);
+  if (!logits || !labels || !grad_logits || !workspace) return JDET_E_BADARG;
+  if (workspace_bytes < jdet_sigmoid_focal_loss_workspace()) return JDET_E_WORKSPACE;
+  const long n = M * C;
+  int grid = (int)((n + 1023) / 1024);
+  if (grid > kFocalGrid) grid = kFocalGrid;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, weight, M, C, alpha, gamma,
+                     grad_logits, (float*)workspace);
+  int e = jdet_launch_status();
+  if (e) return e;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, loss_sum);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_align_conv_offset(const float* anchors, int N, int H, int W, float stride, int kernel_size,
+                                    float* offset, jdet_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || kernel_size <= 0 || kernel_size % 2 == 0 || stride <= 0.f) return JDET_E_BADARG;
+  if (N == 0) return JDET_OK;
+  if (!anchors || !offset) return JDET_E_BADARG;
+  const long total = (long)N * H * W;
+  hipLaunchKernelGGL(align_offset_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     anchors, N, H, W, stride, kernel_size, offset);
+  return jdet_launch_status();
+}

@@ -44,6 +44,38 @@ def sigmoid_focal_loss(inputs, targets, weight=None, alpha=-1, gamma=2, reductio
     return loss
 
 
+class _FusedSigmoidFocal(torch.autograd.Function):
+    """sum of the focal loss over all (row, class) elements + its gradient in one launch
+    (csrc/loss_offset.hip); the autograd backward only scales the stored gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight, alpha, gamma):
+        from jdet_amd import _lib as L
+        x = logits.contiguous()
+        M, C = x.shape
+        lab = labels.to(torch.int32).contiguous()
+        w = weight.to(torch.float32).contiguous() if weight is not None else None
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        wsb = L.lib().jdet_sigmoid_focal_loss_workspace()
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+        L.check(L.lib().jdet_sigmoid_focal_loss(L.ptr(x), L.ptr(lab), L.ptr(w), M, C, float(alpha), float(gamma),
+                                                out.data_ptr(), L.ptr(grad), L.ptr(ws), wsb, L.stream_ptr(x)),
+                "jdet_sigmoid_focal_loss")
+        ctx.save_for_backward(grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_out, None, None, None, None
+
+
+def _fusable(pred, target, weight):
+    return (pred.is_cuda and pred.dtype == torch.float32 and pred.dim() == 2 and pred.numel() > 0 and
+            target.dim() == 1 and (weight is None or weight.dim() == 1) and not torch.is_autocast_enabled())
+
+
 @LOSSES.register_module()
 class FocalLoss(nn.Module):
     def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0):
@@ -58,6 +90,11 @@ class FocalLoss(nn.Module):
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         assert reduction_override in (None, "none", "mean", "sum")
         reduction = reduction_override if reduction_override else self.reduction
+        if reduction in ("mean", "sum") and _fusable(pred, target, weight):
+            total = _FusedSigmoidFocal.apply(pred, target, weight, self.alpha, self.gamma)
+            if reduction == "mean":
+                total = total / (avg_factor if avg_factor is not None else pred.numel())
+            return self.loss_weight * total
         return self.loss_weight * sigmoid_focal_loss(pred, target, weight, gamma=self.gamma, alpha=self.alpha,
                                                      reduction=reduction, avg_factor=avg_factor)
 

@@ -277,6 +277,14 @@ class AlignConv(nn.Module):
         refined anchor minus the regular conv grid (s2anet_head.py:L676-713), batched over images."""
         dtype, device = anchors.dtype, anchors.device
         feat_h, feat_w = featmap_size
+        if anchors.is_cuda and dtype == torch.float32:   # one fused launch (csrc/loss_offset.hip)
+            from jdet_amd import _lib as L
+            a = anchors.contiguous()
+            n = a.shape[0]
+            out = torch.empty((n, 2 * self.kernel_size ** 2, feat_h, feat_w), dtype=dtype, device=device)
+            L.check(L.lib().jdet_align_conv_offset(L.ptr(a), n, feat_h, feat_w, float(stride), self.kernel_size,
+                                                   L.ptr(out), L.stream_ptr(a)), "jdet_align_conv_offset")
+            return out
         pad = (self.kernel_size - 1) // 2
         idx = torch.arange(-pad, pad + 1, dtype=dtype, device=device)
         yy, xx = torch.meshgrid(idx, idx, indexing="ij")

@@ -180,3 +180,45 @@ def test_dense_anchor_targets_equal_index_path(dev):
         for lv in range(3):
             assert d[k][lv].shape == s[k][lv].shape
             assert torch.equal(d[k][lv].float(), s[k][lv].float()), (k, lv)
+
+
+def test_fused_focal_loss_matches_tensor_program(dev):
+    """fused sigmoid focal loss (value and gradient) == the reference-shaped tensor-op chain"""
+    from jdet_amd.models.losses.focal_loss import FocalLoss, sigmoid_focal_loss
+    rng = np.random.default_rng(2)
+    for M, C in ((1000, 15), (37, 1), (4096, 15)):
+        x = torch.from_numpy((rng.standard_normal((M, C)) * 3).astype(np.float32)).to(dev)
+        x[0, 0], x[1, 0] = 40.0, -40.0     # saturated logits
+        lab = torch.from_numpy(rng.integers(0, C + 1, M).astype(np.int32)).to(dev)
+        w = torch.from_numpy((rng.uniform(0, 1, M) > 0.2).astype(np.float32)).to(dev)
+        x1 = x.clone().requires_grad_(True)
+        x2 = x.clone().requires_grad_(True)
+        avg = torch.tensor(17.0, device=dev)
+        l1 = FocalLoss(loss_weight=0.7)(x1, lab, w, avg_factor=avg)
+        l2 = 0.7 * sigmoid_focal_loss(x2, lab, w, gamma=2.0, alpha=0.25, reduction="mean", avg_factor=avg)
+        assert l1.dim() == 0
+        torch.testing.assert_close(l1, l2, rtol=2e-5, atol=1e-6)
+        l1.backward()
+        l2.backward()
+        torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-7)
+    assert torch.isfinite(x1.grad).all()
+
+
+def test_fused_align_conv_offset_matches_restatement(dev):
+    from jdet_amd.models.roi_heads.s2anet_head import AlignConv
+    from oracle import box_oracle as B
+    rng = np.random.default_rng(4)
+    H, W, stride = 9, 13, 16
+    anchors = np.concatenate([rng.uniform(0, 200, (2, H * W, 2)), np.exp(rng.uniform(np.log(8), np.log(200), (2, H * W, 2))),
+                              rng.uniform(-1.6, 1.6, (2, H * W, 1))], -1).astype(np.float32)
+    ac = AlignConv(8, 8, 3).to(dev)
+    got = ac.get_offset(torch.from_numpy(anchors).to(dev), (H, W), stride).cpu().numpy()
+    assert got.shape == (2, 18, H, W)
+    for n in range(2):
+        np.testing.assert_allclose(got[n], B.align_conv_offsets(anchors[n], (H, W), stride), rtol=1e-5, atol=2e-5)
+    # an axis-aligned anchor of size 3*stride centred on the pixel samples the regular grid: zero offsets
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    reg = np.stack([xx.ravel() * stride, yy.ravel() * stride, np.full(H * W, 3.0 * stride), np.full(H * W, 3.0 * stride),
+                    np.zeros(H * W)], 1).astype(np.float32)[None]
+    z = ac.get_offset(torch.from_numpy(reg).to(dev), (H, W), stride)
+    assert float(z.abs().max()) < 1e-5
