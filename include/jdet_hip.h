@@ -113,10 +113,12 @@ int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n
 
 /* Rotated NMS.  Replaces nms_rotated.py:L497-503 (nms_rotated_cpu) / L506-513 (cuda).
  *   dets (n, box_len) box_len 5, or 6 with a label in column 5 (cross-label IoU := 0, L283-286)
- *   order: int32 indices by descending score (the caller's argsort, nms_rotated.py:L519,L532)
+ *   order: int32 visiting order = indices by descending score (the caller's argsort, nms_rotated.py:L519,L532).
+ *          With labels (box_len 6) any order that is descending in score INSIDE each label gives the same keep
+ *          set; visiting class by class lets the kernel skip every 64x64 tile whose label ranges are disjoint.
  *   cmp_ge 1: suppress when iou >= thr (reference CPU rule L444); 0: iou > thr (CUDA rule L403)
  *   keep : n bytes, 1 = kept, indexed by ORIGINAL detection index
- * Entirely on device: tile bitmask kernel + single-wave scan, no host synchronisation. */
+ * Entirely on device: zero fill + tile bitmask kernel + one-workgroup greedy scan, no host synchronisation. */
 size_t jdet_nms_rotated_workspace(int n);
 int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
                      float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,

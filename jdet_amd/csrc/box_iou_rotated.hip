@@ -281,20 +281,45 @@ __global__ __launch_bounds__(kIouBlock) void box_iou_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 // NMS: tile mask kernel (one wave per 64x64 tile) + on-device greedy scan
 // ---------------------------------------------------------------------------------------------
+// min / max label of the 64 boxes of tile `blk` (box_len == 6)
+__device__ __forceinline__ void tile_label_range(const float* __restrict__ dets, const int32_t* __restrict__ order,
+                                                 int n, int blk, int lane, float& lo, float& hi) {
+  const int pos = blk * 64 + lane;
+  const float l = pos < n ? dets[(size_t)order[pos] * 6 + 5] : 0.f;
+  lo = pos < n ? l : INFINITY;
+  hi = pos < n ? l : -INFINITY;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, off, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+  }
+}
+
+// `mask` and `tile_jmax` arrive zeroed.  Tiles whose label ranges are disjoint (ml_nms with the boxes visited
+// class by class: almost all of them) return at once; tile_jmax[r] = last column block of row block r that can hold
+// a set bit, so that the scan reads only those.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ dets, int n, int box_len,
                                                       const int32_t* __restrict__ order, float thr,
                                                       int cmp_ge, int sort_mode,
-                                                      unsigned long long* __restrict__ mask) {
+                                                      unsigned long long* __restrict__ mask,
+                                                      int* __restrict__ tile_jmax) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (col_blk < row_blk) return;  // only the upper triangle is ever read by the scan
+  const int lane = threadIdx.x;
+  if (box_len == 6 && col_blk != row_blk) {
+    float rlo, rhi, clo, chi;
+    tile_label_range(dets, order, n, row_blk, lane, rlo, rhi);
+    tile_label_range(dets, order, n, col_blk, lane, clo, chi);
+    if (rhi < clo || chi < rlo) return;   // no pair of equal labels in this tile
+  }
+  if (lane == 0) atomicMax(&tile_jmax[row_blk], col_blk);
   __shared__ float s_x[24 * 64];
   __shared__ float s_y[24 * 64];
   LanePts<64> q;
-  const int lane = threadIdx.x;
   q.x = s_x + lane;
   q.y = s_y + lane;
   const int col_blocks = (n + 63) >> 6;
-  const int col = col_blk * 64 + lane;  // position in score order
+  const int col = col_blk * 64 + lane;  // position in visiting order
   const bool col_ok = col < n;
   float cb[6] = {0, 0, 0, 0, 0, 0};
   if (col_ok) {
@@ -314,25 +339,31 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     bool hit = false;
     if (col_ok && col > row) {
       // ml_nms: different labels -> IoU 0 (nms_rotated.py:L283-286); argument order is
-      // (higher score, lower score) as in the CPU loop L443
+      // (earlier, later) as in the CPU loop L443
       float ovr = 0.f;
       if (!(box_len == 6 && rb[5] != cb[5])) ovr = iou_dispatch<64>(rb, cb, 0, sort_mode, q);
       hit = cmp_ge ? (ovr >= thr) : (ovr > thr);
     }
     const unsigned long long word = __ballot(hit);
-    if (lane == 0) mask[(size_t)row * col_blocks + col_blk] = word;
+    if (lane == 0 && word) mask[(size_t)row * col_blocks + col_blk] = word;
   }
 }
 
-constexpr int kScanBlock = 256;
+constexpr int kScanBlock = 1024;
 constexpr int kScanMaxWords = 8192;  // n <= 524288
 
+// Greedy scan, one workgroup.  Per 64-row block: wave 0 resolves the diagonal tile (readlane chain), then all 16
+// waves OR the rows of the kept boxes into the running `removed` words of the column blocks that can be affected
+// (<= tile_jmax): the (kept row, column) pairs are flattened over the 1024 threads, 8 independent loads in flight
+// per thread.
 __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                               int n, const int32_t* __restrict__ order,
+                                                              const int* __restrict__ tile_jmax,
                                                               uint8_t* __restrict__ keep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // col_blocks (+1)
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // col_blocks words
+  __shared__ int s_rows[64];
+  __shared__ int s_nkept;
   const int col_blocks = (n + 63) >> 6;
-  unsigned long long* s_keepbits = s_remv + col_blocks;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int j = threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
   __syncthreads();
@@ -355,21 +386,31 @@ __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned lon
           removed |= di;
         }
       }
-      if (lane < rows) keep[order[row]] = (uint8_t)((keepbits >> lane) & 1ull);
-      if (lane == 0) *s_keepbits = keepbits;
+      const bool mine = (keepbits >> lane) & 1ull;
+      if (lane < rows) keep[order[row]] = (uint8_t)mine;
+      if (mine) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;   // k-th kept row of the block
+      if (lane == 0) s_nkept = __popcll(keepbits);
     }
     __syncthreads();
-    const unsigned long long kb = *s_keepbits;
-    // OR the rows of kept boxes into the remaining column words; waves split the kept rows
-    int idx = 0;
-    for (unsigned long long bits = kb; bits; bits &= bits - 1ull, idx++) {
-      if ((idx & 3) != wave) continue;
-      const int i = __builtin_ctzll(bits);
-      const unsigned long long* rowp = mask + (size_t)(c * 64 + i) * col_blocks;
-      for (int j = c + 1 + lane; j < col_blocks; j += 64) {
-        const unsigned long long w = rowp[j];
-        if (w) atomicOr(&s_remv[j], w);
+    const int ncols = tile_jmax[c] - c;          // column blocks c+1 .. tile_jmax[c]
+    const int items = s_nkept * ncols;
+    for (int it0 = threadIdx.x; it0 < items; it0 += kScanBlock * 8) {
+      unsigned long long w[8];
+      int jj[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int it = it0 + u * kScanBlock;
+        w[u] = 0ull;
+        jj[u] = 0;
+        if (it < items) {
+          const int ri = it / ncols;
+          jj[u] = c + 1 + (it - ri * ncols);
+          w[u] = mask[(size_t)(c * 64 + s_rows[ri]) * col_blocks + jj[u]];
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (w[u]) atomicOr(&s_remv[jj[u]], w[u]);
     }
     __syncthreads();
   }
@@ -392,10 +433,15 @@ JDET_API int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxe
   return jdet_launch_status();
 }
 
+static size_t nms_mask_bytes(int n) {
+  const size_t col_blocks = ((size_t)n + 63) >> 6;
+  return (((size_t)n * col_blocks * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+}
+
 JDET_API size_t jdet_nms_rotated_workspace(int n) {
   if (n <= 0) return 0;
   const size_t col_blocks = ((size_t)n + 63) >> 6;
-  return (size_t)n * col_blocks * sizeof(unsigned long long);
+  return nms_mask_bytes(n) + ((col_blocks * sizeof(int) + 255) & ~(size_t)255);
 }
 
 JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
@@ -409,11 +455,14 @@ JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32
   if (col_blocks > kScanMaxWords) return JDET_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* mask = (unsigned long long*)workspace;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
-                     order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask);
-  int e = jdet_launch_status();
+  int* tile_jmax = (int*)((char*)workspace + nms_mask_bytes(n));
+  int e = jdet_zero_async(workspace, jdet_nms_rotated_workspace(n), st);
   if (e) return e;
-  const size_t lds = ((size_t)col_blocks + 1) * sizeof(unsigned long long);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanBlock), lds, st, mask, n, order, keep);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
+                     order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask, tile_jmax);
+  e = jdet_launch_status();
+  if (e) return e;
+  const size_t lds = (size_t)col_blocks * sizeof(unsigned long long);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanBlock), lds, st, mask, n, order, tile_jmax, keep);
   return jdet_launch_status();
 }

@@ -17,8 +17,8 @@ REFERENCE_RULE = "cpu"
 
 
 def nms_rotated_keep_mask(dets, order, iou_threshold):
-    """dets (n,5|6) fp32, order (n,) indices by descending score -> bool keep mask over original
-    indices.  Device-only, fixed shapes (graph-capturable)."""
+    """dets (n,5|6) fp32, order (n,) visiting order (descending score; for 6-column dets any order that is
+    descending in score inside each label) -> bool keep mask over original indices.  Device-only, fixed shapes."""
     L.need_device(dets, order)
     d = L.f32c(dets)
     n, bl = d.shape
@@ -42,7 +42,12 @@ def ml_nms_rotated(dets, scores, labels, iou_threshold):
     assert dets.numel() > 0 and dets.dim() == 2
     assert dets.dtype == scores.dtype
     dets6 = torch.cat([dets, labels.to(dets.dtype).unsqueeze(1)], dim=1)
-    keep = nms_rotated_keep_mask(dets6, _order(scores), iou_threshold)
+    # boxes of different labels never suppress each other (nms_rotated.py:L283-286), so visiting them class by
+    # class (descending score inside a class) keeps exactly the same set as the reference's global score order,
+    # and makes the 64x64 tiles label-homogeneous: the kernel skips every tile whose label ranges are disjoint
+    order = _order(scores)
+    order = order[torch.argsort(labels[order], stable=True)]
+    keep = nms_rotated_keep_mask(dets6, order, iou_threshold)
     return torch.nonzero(keep)[:, 0]
 
 
