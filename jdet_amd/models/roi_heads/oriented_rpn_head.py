@@ -106,11 +106,10 @@ class OrientedRPNHead(nn.Module):
             valid_mask = (w > self.min_bbox_size) & (h > self.min_bbox_size)
             if not bool(valid_mask.all()):
                 proposals, scores, ids = proposals[valid_mask], scores[valid_mask], ids[valid_mask]
+        # per-level NMS: the reference shifts each level by level_id * (max_coordinate + 1) and runs one plain NMS
+        # (L214-219); the level id goes in as a label here -- same keep set, cross-level tiles skipped
         hproposals = obb2hbb(proposals)
-        max_coordinate = hproposals.max() - hproposals.min()
-        offsets = ids.to(hproposals.dtype) * (max_coordinate + 1)   # per-level NMS via coordinate offsets
-        hproposals = hproposals + offsets[:, None]
-        keep = nms_dets(torch.cat([hproposals, scores.unsqueeze(1)], dim=1), self.nms_thresh)
+        keep = nms_dets(torch.cat([hproposals, scores.unsqueeze(1)], dim=1), self.nms_thresh, labels=ids)
         dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[keep, :]
         return dets[:self.nms_post]
 

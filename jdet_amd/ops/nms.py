@@ -10,7 +10,11 @@ import torch
 from .. import _lib as L
 
 
-def nms(boxes, scores, thresh):
+def nms(boxes, scores, thresh, labels=None):
+    """`labels` (optional, e.g. FPN level ids): boxes with different labels never suppress each other -- the
+    effect of the reference's "add level_id * (max_coordinate + 1) to the boxes" trick
+    (oriented_rpn_head.py:L214-219), obtained by skipping the cross-label 64x64 tiles instead of computing their
+    zero IoUs."""
     assert boxes.shape[-1] == 4 and len(scores) == len(boxes)
     if scores.dim() == 2:
         scores = scores[:, 0]
@@ -19,18 +23,23 @@ def nms(boxes, scores, thresh):
         return torch.zeros((0,), dtype=torch.long, device=boxes.device)
     L.need_device(boxes, scores)
     b = boxes.float()
-    obb = torch.stack([(b[:, 0] + b[:, 2]) * 0.5, (b[:, 1] + b[:, 3]) * 0.5, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
-                       torch.zeros_like(b[:, 0])], dim=1).contiguous()
+    cols = [(b[:, 0] + b[:, 2]) * 0.5, (b[:, 1] + b[:, 3]) * 0.5, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+            torch.zeros_like(b[:, 0])]
     order = torch.argsort(scores.float(), descending=True, stable=True)
-    o32 = order.to(torch.int32).contiguous()
+    visit = order
+    if labels is not None:
+        cols.append(labels.to(b.dtype))
+        visit = order[torch.argsort(labels[order], stable=True)]   # class by class, descending score inside
+    obb = torch.stack(cols, dim=1).contiguous()
+    o32 = visit.to(torch.int32).contiguous()
     keep = torch.empty((n,), dtype=torch.uint8, device=b.device)
     wsb = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=b.device)
-    L.check(L.lib().jdet_nms_rotated(L.ptr(obb), n, 5, L.ptr(o32), float(thresh), 0, 0, L.ptr(keep), L.ptr(ws), wsb,
+    L.check(L.lib().jdet_nms_rotated(L.ptr(obb), n, obb.shape[1], L.ptr(o32), float(thresh), 0, 0, L.ptr(keep), L.ptr(ws), wsb,
                                      L.stream_ptr(b)), "jdet_nms_rotated (horizontal)")
     return order[keep[order].bool()]
 
 
-def nms_dets(dets, thresh):
+def nms_dets(dets, thresh, labels=None):
     """`jt.nms(dets (n,5) [x1,y1,x2,y2,score], thresh)`"""
-    return nms(dets[:, :4], dets[:, 4], thresh)
+    return nms(dets[:, :4], dets[:, 4], thresh, labels)

@@ -119,3 +119,20 @@ def test_oriented_rcnn_train_step_and_inference(dev):
     assert len(res) == 2
     for polys, scores, labels in res:
         assert polys.shape[1] == 8 and polys.shape[0] == scores.shape[0] == labels.shape[0]
+
+
+def test_level_labels_equal_the_coordinate_offset_trick(dev):
+    """nms(labels=level ids) keeps exactly what the reference's per-level coordinate offsets keep
+    (oriented_rpn_head.py:L214-219)"""
+    from jdet_amd.ops.nms import nms
+    rng = np.random.default_rng(8)
+    n = 3000
+    c = rng.uniform(0, 300, (n, 2))
+    wh = rng.uniform(10, 80, (n, 2))
+    boxes = torch.from_numpy(np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)).to(dev)
+    scores = torch.from_numpy((rng.uniform(0, 1, n) + np.arange(n) * 1e-7).astype(np.float32)).to(dev)
+    ids = torch.from_numpy(rng.integers(0, 5, n)).to(dev)
+    off = ids.to(boxes.dtype) * (boxes.max() - boxes.min() + 1)
+    a = nms(boxes + off[:, None], scores, 0.7)
+    b = nms(boxes, scores, 0.7, labels=ids)
+    assert torch.equal(a, b) and 0 < a.numel() < n
