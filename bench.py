@@ -162,7 +162,8 @@ def make_train(a, rank, dev):
     torch.manual_seed(1234)  # identical replicas
     amp = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.amp]
     runner = Runner(TRAIN_WORKLOADS[a.workload][0](), device=dev, amp_dtype=amp,
-                    conv_autotune=os.environ.get("JDET_CUDNN_BENCHMARK", "1") == "1")
+                    conv_autotune=os.environ.get("JDET_CUDNN_BENCHMARK", "1") == "1",
+                    ddp=True if os.environ.get("JDET_BENCH_FORCE_DIST", "0") == "1" else None)
     images, targets = synthetic_batch(a.batch, a.size, dev, seed=2 + rank)
     images = images.contiguous(memory_format=torch.channels_last)
 
@@ -310,7 +311,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("JDET_BENCH_FORCE_DIST", "0") == "1"   # exercise the RCCL / DDP path on 1 GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 

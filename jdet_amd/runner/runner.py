@@ -65,7 +65,9 @@ class Runner:
             # 4-D conv weights only (ORConv2d keeps a 5-D ARF weight; nn.Module.to(memory_format=) would
             # try to convert it as a 3-D-conv weight and fail)
             for p in self.model.parameters():
-                if p.dim() == 4:
+                # 1x1 kernels are already both layouts; leaving their strides alone keeps them equal to the
+                # strides of the gradients MIOpen returns (DDP's bucket views otherwise copy)
+                if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
                     p.data = p.data.contiguous(memory_format=torch.channels_last)
         self.channels_last = channels_last
         self.amp_dtype = amp_dtype
