@@ -103,7 +103,7 @@ def make_step(workload, d):
                                                o0 if use_order else None, op, st), "fwd")
         d["out"] = out
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
-        return step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_kernel<ROTATED,vec4>", "f32"
+        return step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves>", "f32"
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]
