@@ -363,7 +363,16 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
   const int total = cc * nbins;
   const float4* s4 = reinterpret_cast<const float4*>(s_out);
   float4* d4 = reinterpret_cast<float4*>(dst);
-  for (int i = threadIdx.x; i < (total >> 2); i += NW * 64) d4[i] = s4[i];
+  if (ABL & 8) {
+    for (int i = threadIdx.x; i < (total >> 2); i += NW * 64) d4[i] = s4[i];
+  } else {
+    // write-once output: non-temporal stores keep the 100 MB result stream from evicting map lines out of L2
+    // (67.5 -> 64.6 us/step)
+    typedef float v4s __attribute__((ext_vector_type(4)));
+    const v4s* sv = reinterpret_cast<const v4s*>(s_out);
+    v4s* dv = reinterpret_cast<v4s*>(dst);
+    for (int i = threadIdx.x; i < (total >> 2); i += NW * 64) __builtin_nontemporal_store(sv[i], &dv[i]);
+  }
 }
 
 // ---- LDS pixel-cache path ------------------------------------------------------------------
@@ -981,6 +990,9 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
                          PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
     else if (abl == 4)
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 4>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (abl == 8)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 8>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
                          PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
     else if (abl == 5)
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 5>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
