@@ -231,8 +231,13 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
   constexpr bool kRot = ROI_COLS == 6;
   const float* roi = rois + (size_t)r * ROI_COLS;
   if (kRot && wave == 0 && lane == 0) {
-    s_trig[0] = (float)cos((double)roi[5]);
-    s_trig[1] = (float)sin((double)roi[5]);
+    if (ABL & 16) {   // profiling builds: how much of the workgroup's start-up is the double-precision trig
+      s_trig[0] = cosf(roi[5]);
+      s_trig[1] = sinf(roi[5]);
+    } else {
+      s_trig[0] = (float)cos((double)roi[5]);
+      s_trig[1] = (float)sin((double)roi[5]);
+    }
   }
   __amdgpu_buffer_rsrc_t rsrc;
   RoiGeom g = vec_prologue<VARIANT, false>(feat, rois, r, C, H, W, PH, PW, spatial_scale, 2, rsrc);
@@ -990,6 +995,9 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
                          PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
     else if (abl == 4)
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 4>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
+                         PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
+    else if (abl == 16)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 16>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,
                          PH, PW, scale, order, env_int("JDET_ROI_ABL_MASK", 63));
     else if (abl == 8)
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 8>), grid, dim3(256), lds, st, feat, rois, out, C, H, W,

@@ -87,7 +87,8 @@ class Runner:
         if use_ddp:
             self.train_model = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
-                bucket_cap_mb=int(os.environ.get("JDET_DDP_BUCKET_MB", "64")), gradient_as_bucket_view=True)
+                bucket_cap_mb=int(os.environ.get("JDET_DDP_BUCKET_MB", "64")), gradient_as_bucket_view=True,
+                static_graph=os.environ.get("JDET_DDP_STATIC_GRAPH", "1") == "1")
         self.iter = 0
         self.epoch = 0
 
