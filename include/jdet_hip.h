@@ -162,6 +162,13 @@ int jdet_sigmoid_focal_loss(const float* logits, const int32_t* labels, const fl
                             float alpha, float gamma, float* loss_sum, float* grad_logits,
                             void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
+/* Weighted smooth-L1 / L1 (models/losses/smooth_l1_loss.py:L5-27, l1_loss.py): element-wise over n values,
+ * weight same shape or NULL, beta = 0 -> L1.  *loss_sum = sum; grad_pred = d loss_sum / d pred.  Workspace: the
+ * focal-loss query.  Deterministic. */
+int jdet_smooth_l1_loss(const float* pred, const float* target, const float* weight, long n, float beta,
+                        float* loss_sum, float* grad_pred, void* workspace, size_t workspace_bytes,
+                        jdet_stream_t stream);
+
 /* AlignConv.get_offset (models/roi_heads/s2anet_head.py:L676-713): anchors (N, H*W, 5) [xc,yc,w,h,theta] in image
  * coordinates -> offset (N, 2*k*k, H, W), (dy, dx) per tap of the k x k kernel (k odd). */
 int jdet_align_conv_offset(const float* anchors, int N, int H, int W, float stride, int kernel_size,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "jdet_deform_col2im_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p, _sz, _p]),
     "jdet_sigmoid_focal_loss_workspace": (_sz, []),
     "jdet_sigmoid_focal_loss": (_i, [_p, _p, _p, _l, _i, _f, _f, _p, _p, _p, _sz, _p]),
+    "jdet_smooth_l1_loss": (_i, [_p, _p, _p, _l, _f, _p, _p, _p, _sz, _p]),
     "jdet_align_conv_offset": (_i, [_p, _i, _i, _i, _f, _i, _p, _p]),
     "jdet_frozen_bn_act_forward": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
     "jdet_frozen_bn_act_backward_workspace": (_sz, [_l, _i]),

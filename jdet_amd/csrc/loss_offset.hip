@@ -68,6 +68,35 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 constexpr int kFocalGrid = 1024;
 
+// weighted smooth-L1 (models/losses/smooth_l1_loss.py:L5-27): per element w * (|d| < beta ? 0.5 d^2 / beta
+// : |d| - 0.5 beta), d = pred - target; beta == 0 -> plain L1.  Sum + d/d pred in one pass.
+__global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ target,
+                                                            const float* __restrict__ weight, long n, float beta,
+                                                            float* __restrict__ grad, float* __restrict__ partial) {
+  __shared__ float s_part[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = pred[i] - target[i];
+    const float w = weight ? weight[i] : 1.f;
+    const float ad = fabsf(d);
+    float l, g;
+    if (beta != 0.f && ad < beta) {
+      l = 0.5f * d * d / beta;
+      g = d / beta;
+    } else {
+      l = beta != 0.f ? ad - 0.5f * beta : ad;
+      g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    }
+    acc += l * w;
+    grad[i] = g * w;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
 // anchors (N, H*W, 5) image coordinates -> offsets (N, 2*k*k, H, W)
 __global__ __launch_bounds__(256) void align_offset_kernel(const float* __restrict__ anchors, int N, int H, int W,
                                                            float stride, int ks, float* __restrict__ offset) {
@@ -113,6 +142,24 @@ JDET_API int jdet_sigmoid_focal_loss(const float* logits, const int32_t* labels,
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, weight, M, C, alpha, gamma,
                      grad_logits, (float*)workspace);
+  int e = jdet_launch_status();
+  if (e) return e;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, loss_sum);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_smooth_l1_loss(const float* pred, const float* target, const float* weight, long n, float beta,
+                                 float* loss_sum, float* grad_pred, void* workspace, size_t workspace_bytes,
+                                 jdet_stream_t stream) {
+  if (n < 0 || beta < 0.f || !loss_sum) return JDET_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return jdet_zero_async(loss_sum, sizeof(float), st);
+  if (!pred || !target || !grad_pred || !workspace) return JDET_E_BADARG;
+  if (workspace_bytes < jdet_sigmoid_focal_loss_workspace()) return JDET_E_WORKSPACE;
+  int grid = (int)((n + 1023) / 1024);
+  if (grid > kFocalGrid) grid = kFocalGrid;
+  hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(grid), dim3(256), 0, st, pred, target, weight, n, beta, grad_pred,
+                     (float*)workspace);
   int e = jdet_launch_status();
   if (e) return e;
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, grid, loss_sum);

@@ -40,6 +40,48 @@ def l1_loss(pred, target, weight=None, avg_factor=None, reduction="mean"):
     return loss
 
 
+class _FusedSmoothL1(torch.autograd.Function):
+    """sum of the weighted smooth-L1 (beta = 0: L1) + its gradient in one launch (csrc/loss_offset.hip)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, beta):
+        from jdet_amd import _lib as L
+        p, t = pred.contiguous(), target.to(torch.float32).contiguous()
+        w = None
+        if weight is not None:
+            w = weight.to(torch.float32)
+            if w.dim() == 1 and p.dim() == 2:
+                w = w[:, None].expand_as(p)
+            w = w.contiguous()
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        grad = torch.empty_like(p)
+        wsb = L.lib().jdet_sigmoid_focal_loss_workspace()
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=p.device)
+        L.check(L.lib().jdet_smooth_l1_loss(L.ptr(p), L.ptr(t), L.ptr(w), p.numel(), float(beta), out.data_ptr(),
+                                            L.ptr(grad), L.ptr(ws), wsb, L.stream_ptr(p)), "jdet_smooth_l1_loss")
+        ctx.save_for_backward(grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_out, None, None, None
+
+
+def _fusable(pred, target, weight):
+    return (pred.is_cuda and pred.dtype == torch.float32 and pred.numel() > 0 and pred.shape == target.shape and
+            not target.requires_grad and not torch.is_autocast_enabled() and
+            (weight is None or weight.shape == pred.shape or (weight.dim() == 1 and pred.dim() == 2 and
+                                                              weight.shape[0] == pred.shape[0])))
+
+
+def _fused_loss(pred, target, weight, beta, reduction, avg_factor):
+    total = _FusedSmoothL1.apply(pred, target, weight, beta)
+    if reduction == "mean":
+        total = total / (avg_factor if avg_factor is not None else max(pred.shape[0], 1))
+    return total
+
+
 @LOSSES.register_module()
 class SmoothL1Loss(nn.Module):
     def __init__(self, beta=1.0, reduction="mean", loss_weight=1.0):
@@ -51,6 +93,8 @@ class SmoothL1Loss(nn.Module):
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         assert reduction_override in (None, "none", "mean", "sum")
         reduction = reduction_override if reduction_override else self.reduction
+        if reduction in ("mean", "sum") and _fusable(pred, target, weight):
+            return self.loss_weight * _fused_loss(pred, target, weight, self.beta, reduction, avg_factor)
         return self.loss_weight * smooth_l1_loss(pred, target, weight, beta=self.beta, reduction=reduction,
                                                  avg_factor=avg_factor)
 
@@ -67,6 +111,8 @@ class L1Loss(nn.Module):
     def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None):
         assert reduction_override in (None, "none", "mean", "sum")
         reduction = reduction_override if reduction_override else self.reduction
+        if reduction in ("mean", "sum") and _fusable(pred, target, weight):
+            return self.loss_weight * _fused_loss(pred, target, weight, 0.0, reduction, avg_factor)
         return self.loss_weight * l1_loss(pred, target, weight, reduction=reduction, avg_factor=avg_factor)
 
     execute = forward

@@ -222,3 +222,30 @@ def test_fused_align_conv_offset_matches_restatement(dev):
                     np.zeros(H * W)], 1).astype(np.float32)[None]
     z = ac.get_offset(torch.from_numpy(reg).to(dev), (H, W), stride)
     assert float(z.abs().max()) < 1e-5
+
+
+def test_fused_smooth_l1_matches_tensor_program(dev):
+    from jdet_amd.models.losses.smooth_l1_loss import L1Loss, SmoothL1Loss, l1_loss, smooth_l1_loss
+    rng = np.random.default_rng(6)
+    for M, D, beta in ((5000, 5, 1.0 / 9.0), (300, 4, 1.0), (64, 5, 0.0)):
+        p = torch.from_numpy(rng.standard_normal((M, D)).astype(np.float32)).to(dev)
+        t = torch.from_numpy((rng.standard_normal((M, D)) * 0.5).astype(np.float32)).to(dev)
+        p[0, 0] = t[0, 0]                                   # zero difference: sign(0) = 0
+        w = torch.from_numpy((rng.uniform(0, 1, (M, D)) > 0.7).astype(np.float32)).to(dev)
+        for weight in (w, w[:, 0].contiguous(), None):
+            p1, p2 = p.clone().requires_grad_(True), p.clone().requires_grad_(True)
+            avg = torch.tensor(23.0, device=dev)
+            if beta == 0.0:
+                l1 = L1Loss(loss_weight=1.3)(p1, t, weight, avg_factor=avg)
+                l2 = 1.3 * l1_loss(p2, t, weight, avg_factor=avg)
+            else:
+                l1 = SmoothL1Loss(beta=beta, loss_weight=1.3)(p1, t, weight, avg_factor=avg)
+                l2 = 1.3 * smooth_l1_loss(p2, t, weight, beta=beta, avg_factor=avg)
+            torch.testing.assert_close(l1, l2, rtol=2e-5, atol=1e-6)
+            l1.backward()
+            l2.backward()
+            torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-5, atol=1e-7)
+    # default normaliser (no avg_factor) = number of rows
+    q = torch.randn(10, 5, device=dev, requires_grad=True)
+    a = SmoothL1Loss(beta=1.0)(q, torch.zeros(10, 5, device=dev))
+    torch.testing.assert_close(a, smooth_l1_loss(q.detach(), torch.zeros(10, 5, device=dev), beta=1.0), rtol=1e-5, atol=1e-6)
