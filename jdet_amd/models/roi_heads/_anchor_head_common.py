@@ -20,21 +20,27 @@ class RotatedAnchorHeadMixin:
 
     def _valid_flags(self, featmap_sizes, img_metas, device):
         valid_flag_list = []
+        cache = self.__dict__.setdefault("_valid_flag_cache", {})
         for img_meta in img_metas:
-            multi_level_flags = []
-            all_valid = True
-            for i in range(len(featmap_sizes)):
-                anchor_stride = self.anchor_strides[i]
-                feat_h, feat_w = featmap_sizes[i]
-                w, h = img_meta["pad_shape"][:2]
-                valid_feat_h = min(int(np.ceil(h / anchor_stride)), feat_h)
-                valid_feat_w = min(int(np.ceil(w / anchor_stride)), feat_w)
-                all_valid = all_valid and valid_feat_h == feat_h and valid_feat_w == feat_w
-                multi_level_flags.append(self.anchor_generators[i].valid_flags(
-                    (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
+            # the flags depend on (level sizes, pad_shape) only: DOTA tiles have one shape, so they are built once
+            key = (tuple(featmap_sizes), tuple(img_meta["pad_shape"][:2]), str(device))
+            if key not in cache:
+                multi_level_flags = []
+                all_valid = True
+                for i in range(len(featmap_sizes)):
+                    anchor_stride = self.anchor_strides[i]
+                    feat_h, feat_w = featmap_sizes[i]
+                    w, h = img_meta["pad_shape"][:2]
+                    valid_feat_h = min(int(np.ceil(h / anchor_stride)), feat_h)
+                    valid_feat_w = min(int(np.ceil(w / anchor_stride)), feat_w)
+                    all_valid = all_valid and valid_feat_h == feat_h and valid_feat_w == feat_w
+                    multi_level_flags.append(self.anchor_generators[i].valid_flags(
+                        (feat_h, feat_w), (valid_feat_h, valid_feat_w), device=device))
+                cache[key] = (multi_level_flags, all_valid)
+            multi_level_flags, all_valid = cache[key]
             # host-side fact (no device sync): every anchor is valid -> anchor_target skips the mask gather
             img_meta["_all_valid"] = all_valid
-            valid_flag_list.append(multi_level_flags)
+            valid_flag_list.append(list(multi_level_flags))
         return valid_flag_list
 
     def get_init_anchors(self, featmap_sizes, img_metas, device):

@@ -176,8 +176,12 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         device = odm_cls_scores[0].device
         anchor_list, valid_flag_list = self.get_init_anchors(featmap_sizes, img_metas, device)
         num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
-        concat_anchor_list = [torch.cat(anchor_list[i]) for i in range(len(anchor_list))]
-        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
+        # per-level anchors are only read by the loss when it regresses decoded boxes
+        need_anchors = cfg.fam_cfg.get("reg_decoded_bbox", False) or cfg.odm_cfg.get("reg_decoded_bbox", False)
+        all_anchor_list = [None] * len(num_level_anchors)
+        if need_anchors:
+            concat_anchor_list = [torch.cat(anchor_list[i]) for i in range(len(anchor_list))]
+            all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
 
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
         cls_reg_targets = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas, self.target_means,
@@ -196,8 +200,10 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         refine_anchors_list, valid_flag_list = self.get_refine_anchors(featmap_sizes, refine_anchors, img_metas,
                                                                        device=device)
         num_level_anchors = [anchors.size(0) for anchors in refine_anchors_list[0]]
-        concat_anchor_list = [torch.cat(refine_anchors_list[i]) for i in range(len(refine_anchors_list))]
-        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
+        all_anchor_list = [None] * len(num_level_anchors)
+        if need_anchors:
+            concat_anchor_list = [torch.cat(refine_anchors_list[i]) for i in range(len(refine_anchors_list))]
+            all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
         cls_reg_targets = anchor_target(refine_anchors_list, valid_flag_list, gt_bboxes, img_metas, self.target_means,
                                         self.target_stds, cfg.odm_cfg, gt_bboxes_ignore_list=gt_bboxes_ignore,
                                         gt_labels_list=gt_labels, label_channels=label_channels,

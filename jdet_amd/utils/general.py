@@ -28,7 +28,10 @@ def parse_losses(losses):
         if isinstance(loss_value, torch.Tensor):
             _losses[loss_name] = loss_value.mean()
         elif isinstance(loss_value, list):
-            _losses[loss_name] = sum(_loss.mean() for _loss in loss_value)
+            if all(_loss.dim() == 0 for _loss in loss_value):   # per-level scalars: one stack + one sum
+                _losses[loss_name] = torch.stack(loss_value).sum()
+            else:
+                _losses[loss_name] = sum(_loss.mean() for _loss in loss_value)
         else:
             raise TypeError("{} is not a tensor or list of tensors".format(loss_name))
     total_loss = sum(_value for _key, _value in _losses.items() if "loss" in _key)
