@@ -380,193 +380,11 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
   }
 }
 
-// ---- LDS pixel-cache path ------------------------------------------------------------------
-// The vector-memory (TA/L1) path moves 64 B/clk/CU; a 7x7x(2x2) RoI issues 784 taps of 1 KiB
-// through it although it touches far fewer distinct pixels when it is small (bench RoIs: 30 % of
-// the taps are distinct).  This kernel dedups the taps of a RoI exactly:
-//   1. sample table in LDS (4 weights + 4 pixel offsets per sample, computed once per RoI);
-//   2. bitmap over the RoI's bounding box (LDS atomicOr), popcount prefix -> dense slot of every
-//      touched pixel, D = number of distinct pixels;
-//   3. if D <= kCachePix: per 64-channel pass, each distinct pixel's 256 B are fetched ONCE
-//      (buffer_load_dwordx4, 4 pixels per wave instruction) into LDS; the 16 taps per bin are
-//      then ds_read_b128 (256 B/clk/CU, a separate path from TA).  Lane = (bin-in-group, channel
-//      quad): a wave works on 4 bins at once, each lane accumulating its bin's samples in the
-//      reference order -> still bit-identical to the oracle.
-//      Otherwise (large RoI, no reuse to harvest): the direct path above.
-constexpr int kCC = 64;            // channels per cached pass (256 B per pixel)
-constexpr int kCachePix = 196;     // distinct pixels cacheable: 196 * 256 B = 50,176 B = [256][49] floats
-constexpr int kMaxSamples = 256;   // sample-table capacity (7*7*2*2 = 196)
-constexpr int kBitWords = 256;     // bounding boxes up to 8192 pixels
+// (An LDS pixel-cache variant -- per-RoI bitmap + rank dedup, distinct pixels staged once per 64-channel pass, taps
+// served by ds_read_b128 -- was built and measured at 155 us against 69 us for the direct path at the time: four
+// channel passes with two barriers each and 2 workgroups per CU leave the vector-memory path idle most of the time.
+// Removed; DESIGN.md 3.1 / 7 describe what would have to be different.)
 
-template <int VARIANT>
-__global__ __launch_bounds__(256) void roi_align_fwd_cached_kernel(
-    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-    int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
-    const int32_t* __restrict__ order, int cache_floats) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nbins = PH * PW;
-  float* s_cache = smem;                                   // [kCachePix][64]  (direct path: [256][nbins])
-  float* s_outc = s_cache + cache_floats;                  // [64][nbins]
-  float4* s_w = reinterpret_cast<float4*>(s_outc + ((kCC * nbins + 3) & ~3));  // [kMaxSamples]
-  int4* s_tap = reinterpret_cast<int4*>(s_w + kMaxSamples);            // pixel offsets, then slots
-  unsigned* s_bits = reinterpret_cast<unsigned*>(s_tap + kMaxSamples);  // [kBitWords]
-  int* s_rank = reinterpret_cast<int*>(s_bits + kBitWords);            // [kBitWords]
-  int* s_pix = s_rank + kBitWords;                                     // [kCachePix] pixel byte offsets
-  int* s_misc = s_pix + ((kCachePix + 3) & ~3);                        // bbox x0,y0,x1,y1, wave sums[4]
-
-  const int r = order ? order[blockIdx.x] : blockIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int tid = threadIdx.x;
-  __amdgpu_buffer_rsrc_t rsrc;
-  const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc);
-  if (g.batch < 0) return;  // masked RoI
-  const int spb = g.grid_h * g.grid_w;
-  const int S = nbins * spb;
-  const int pix_bytes = C * 4;
-
-  // ---- 1. sample table + bounding box
-  if (tid < 4) s_misc[tid] = tid < 2 ? 0x7fffffff : -1;
-  __syncthreads();
-  Sample mine;
-  mine.valid = 0;
-  if (tid < S) {
-    const int bin = tid / spb, rr = tid % spb;
-    mine = make_sample<VARIANT>(g, bin / PW, bin % PW, rr / g.grid_w, rr % g.grid_w, H, W);
-    s_w[tid] = make_float4(mine.w1, mine.w2, mine.w3, mine.w4);
-    if (mine.valid) {
-      const int yl = mine.o1 / W, xl = mine.o1 - yl * W;
-      const int yh = mine.o4 / W, xh = mine.o4 - yh * W;
-      atomicMin(&s_misc[0], xl);
-      atomicMin(&s_misc[1], yl);
-      atomicMax(&s_misc[2], xh);
-      atomicMax(&s_misc[3], yh);
-    }
-  }
-  for (int i = tid; i < kBitWords; i += 256) s_bits[i] = 0u;
-  __syncthreads();
-  const int x0 = __builtin_amdgcn_readfirstlane(s_misc[0]), y0 = __builtin_amdgcn_readfirstlane(s_misc[1]);
-  const int x1 = __builtin_amdgcn_readfirstlane(s_misc[2]), y1 = __builtin_amdgcn_readfirstlane(s_misc[3]);
-  const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-  bool cached = x1 >= 0 && (long)bw * bh <= kBitWords * 32;
-
-  // ---- 2. bitmap of touched pixels -> dense slots
-  int idx[4] = {0, 0, 0, 0};
-  int D = 0;
-  if (cached) {
-    if (mine.valid) {
-      const int o[4] = {mine.o1, mine.o2, mine.o3, mine.o4};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int y = o[k] / W, x = o[k] - y * W;
-        idx[k] = (y - y0) * bw + (x - x0);
-        atomicOr(&s_bits[idx[k] >> 5], 1u << (idx[k] & 31));
-      }
-    }
-    __syncthreads();
-    // exclusive popcount prefix over the 256 bitmap words (one word per thread)
-    const unsigned word = s_bits[tid];
-    const int c = __popc(word);
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) s_misc[4 + wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; w++) base += s_misc[4 + w];
-    D = s_misc[4] + s_misc[5] + s_misc[6] + s_misc[7];
-    D = __builtin_amdgcn_readfirstlane(D);
-    const int excl = base + incl - c;
-    s_rank[tid] = excl;
-    cached = D <= kCachePix;
-    if (cached) {
-      // pixel list: byte offset of every touched pixel, in slot order
-      unsigned wbits = word;
-      int slot = excl;
-      while (wbits) {
-        const int b = __builtin_ctz(wbits);
-        const int id = tid * 32 + b;
-        const int py = y0 + id / bw, px = x0 + id % bw;
-        s_pix[slot++] = (py * W + px) * pix_bytes;
-        wbits &= wbits - 1;
-      }
-    }
-    __syncthreads();
-    if (cached && tid < S) {
-      int4 sl = make_int4(-1, -1, -1, -1);
-      if (mine.valid) {
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          v[k] = s_rank[idx[k] >> 5] + __popc(s_bits[idx[k] >> 5] & ((1u << (idx[k] & 31)) - 1u));
-        sl = make_int4(v[0], v[1], v[2], v[3]);
-      }
-      s_tap[tid] = sl;
-    }
-    __syncthreads();
-  }
-
-  if (cached) {
-    // ---- 3. cached passes over 64-channel chunks
-    const int bsub = lane >> 4, c4 = lane & 15;
-    for (int ch0 = 0; ch0 < C; ch0 += kCC) {
-      // 3a. fetch every distinct pixel once: item = (slot, channel quad); 4 pixels per wave instr
-      for (int i = tid; i < D * 16; i += 256) {
-        const int slot = i >> 4, q = i & 15;
-        const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, s_pix[slot] + (ch0 + q * 4) * 4, 0, 0);
-        *reinterpret_cast<v4u*>(s_cache + slot * kCC + q * 4) = v;
-      }
-      __syncthreads();
-      // 3b. taps from LDS; a wave handles 4 bins at once (lane = bin-in-group x channel quad)
-      for (int q = wave; q * 4 < nbins; q += 4) {
-        const int bin = q * 4 + bsub;
-        if (bin < nbins) {
-          float acc[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int j = 0; j < spb; j++) {
-            const int t = bin * spb + j;
-            const int4 sl = s_tap[t];
-            if (sl.x >= 0) {
-              const float4 w = s_w[t];
-              const v4f lt = *reinterpret_cast<const v4f*>(s_cache + sl.x * kCC + c4 * 4);
-              const v4f rt = *reinterpret_cast<const v4f*>(s_cache + sl.y * kCC + c4 * 4);
-              const v4f lb = *reinterpret_cast<const v4f*>(s_cache + sl.z * kCC + c4 * 4);
-              const v4f rb = *reinterpret_cast<const v4f*>(s_cache + sl.w * kCC + c4 * 4);
-              acc_sample4(acc, w.x, w.y, w.z, w.w, lt, rt, lb, rb);
-            }
-          }
-#pragma unroll
-          for (int k = 0; k < 4; k++) s_outc[(c4 * 4 + k) * nbins + bin] = acc[k] / g.count;
-        }
-      }
-      __syncthreads();
-      // 3c. this chunk's [64][nbins] block is contiguous in the (R,C,PH,PW) output
-      float* __restrict__ dst = out + ((size_t)r * C + ch0) * nbins;
-      const int total = kCC * nbins;
-      const float4* s4 = reinterpret_cast<const float4*>(s_outc);
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      for (int i = tid; i < (total >> 2); i += 256) d4[i] = s4[i];
-      // (the barrier after the next chunk's fetch orders these reads before s_outc is rewritten)
-    }
-  } else {
-    // ---- direct path, 256 channels at a time, s_cache reused as the [256][nbins] staging block
-    for (int c0 = 0; c0 < C; c0 += kChunkC) {
-      const int cc = min(kChunkC, C - c0);
-      direct_chunk<VARIANT, 4, 4, 0>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_cache);
-      __syncthreads();
-      float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
-      const int total = cc * nbins;
-      const float4* s4 = reinterpret_cast<const float4*>(s_cache);
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      for (int i = tid; i < (total >> 2); i += 256) d4[i] = s4[i];
-      __syncthreads();
-    }
-  }
-}
-
-// ---- generic path: any C, RiRoI (two source planes per output channel), huge maps -------------
 template <int VARIANT, int CHMAP>
 __global__ __launch_bounds__(kBlock) void roi_align_fwd_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
@@ -965,28 +783,7 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
   dim3 grid(R, chunks);
   const bool vec = (C % 4 == 0) && VARIANT != JDET_ROI_RIROI && (size_t)H * W * C * 4 < (1ull << 31);
   const int nbins = PH * PW;
-  static const int use_cache = env_int("JDET_ROI_FWD_CACHE", 0);  // experimental, see DESIGN.md 3.1
-  const bool cacheable = vec && use_cache && C % kCC == 0 && sample_num > 0 &&
-                         nbins * sample_num * sample_num <= kMaxSamples && (nbins * kCC) % 4 == 0 &&
-                         (C <= kChunkC || (kChunkC * nbins) % 4 == 0);
-  if (cacheable) {
-    constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
-    // cache region doubles as the direct path's [min(C,256)][nbins] staging block
-    int cache_floats = kCachePix * kCC;
-    if (min(C, kChunkC) * nbins > cache_floats) cache_floats = min(C, kChunkC) * nbins;
-    cache_floats = (cache_floats + 3) & ~3;
-    const size_t lds_c = sizeof(float) * ((size_t)cache_floats + ((kCC * nbins + 3) & ~3)) +
-                         kMaxSamples * 32 + kBitWords * 8 + ((kCachePix + 3) & ~3) * 4 + 64;
-    static bool attr_set = false;  // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_set) {
-      hipError_t he = hipFuncSetAttribute(reinterpret_cast<const void*>(&roi_align_fwd_cached_kernel<V>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (he != hipSuccess) return (int)he;
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((roi_align_fwd_cached_kernel<V>), dim3(R), dim3(256), lds_c, st, feat, rois, out,
-                       C, H, W, PH, PW, scale, sample_num, order, cache_floats);
-  } else if (vec && sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && lds >= 8 * 2048) {
+  if (vec && sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && lds >= 8 * 2048) {
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     static const int nw = env_int("JDET_ROI_FWD_WAVES", 4);
     static const int abl = env_int("JDET_ROI_ABLATE", 0);  // profiling builds only
