@@ -238,12 +238,29 @@ def cpu_baseline(workload, d, R):
         t /= reps
         full = t * R / rs
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
-        return {"value": nbytes / 1e9 / full, "unit": "GB/s", "cores": cores_used, "kind": "port",
-                "sample": "first %d of %d RoIs of the same map, mean of %d runs (%.3f s each), extrapolated "
-                          "linearly in RoIs; algorithmic bytes of the full workload / extrapolated time"
-                          % (rs, R, reps, t)}
+        out = {"value": nbytes / 1e9 / full, "unit": "GB/s", "cores": cores_used, "kind": "port",
+               "sample": "first %d of %d RoIs of the same map, mean of %d runs (%.3f s each), extrapolated "
+                         "linearly in RoIs; algorithmic bytes of the full workload / extrapolated time"
+                         % (rs, R, reps, t)}
+        if not bwd and O.have_ref():
+            # the reference's own kernel text (CUDA-only there: host-compiled single-thread build, oracle/_ref)
+            rr = min(R, 512)
+            t0 = time.perf_counter()
+            O.ref_roi_align_forward(O.V_ROT, feat, d["rois_np"][:rr], (7, 7), 0.25, 2)
+            tr = (time.perf_counter() - t0) * R / rr
+            out["reference_text"] = {"value": nbytes / 1e9 / tr, "unit": "GB/s", "cores": 1, "kind": "reference",
+                                     "sample": "first %d of %d RoIs through the reference's ROIAlignRotatedForward "
+                                               "text (roi_align_rotated.py:L61-127) compiled for the host, one "
+                                               "thread, NCHW map; extrapolated linearly in RoIs" % (rr, R)}
+        return out
     if workload == "box_iou_rotated":
         b1, b2 = d["b1_np"][:16], d["b2_np"]
+        if O.have_ref():   # the reference's true CPU source (box_iou_rotated.py:L312-326, L487-500), one thread
+            t0 = time.perf_counter()
+            O.ref_box_iou_rotated(b1, b2)
+            t = time.perf_counter() - t0
+            return {"value": b1.shape[0] * b2.shape[0] / 1e6 / t, "unit": "Mpair/s", "cores": 1, "kind": "reference",
+                    "sample": "16 of 64 gt rows x 21824 anchors through the reference's CPU text (%.2f s)" % t}
         t0 = time.perf_counter()
         O.box_iou_rotated(b1, b2)
         t = time.perf_counter() - t0
@@ -252,11 +269,12 @@ def cpu_baseline(workload, d, R):
     if workload == "nms_rotated":
         dets, scores = d["dets_np"], d["scores_np"]
         order = np.argsort(-scores, kind="stable").astype(np.int32)
+        kind = "reference" if O.have_ref() else "port"   # reference: nms_rotated.py:L314-328, L414-449 CPU text
         t0 = time.perf_counter()
-        O.nms_rotated_keep(dets, order, 0.1)
+        (O.ref_nms_rotated_keep if kind == "reference" else O.nms_rotated_keep)(dets, order, 0.1)
         t = time.perf_counter() - t0
         n = dets.shape[0]
-        return {"value": n * (n - 1) / 2 / 1e6 / t, "unit": "Mpair/s", "cores": 1, "kind": "port",
+        return {"value": n * (n - 1) / 2 / 1e6 / t, "unit": "Mpair/s", "cores": 1, "kind": kind,
                 "sample": "full n=%d greedy NMS, single thread as in the reference (%.1f s); upper-triangle "
                           "pairs / time (the greedy loop skips suppressed rows)" % (n, t)}
     return None

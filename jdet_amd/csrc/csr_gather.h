@@ -50,7 +50,7 @@ static __global__ __launch_bounds__(256) void csr_scan_local_kernel(const int* _
 }
 
 static __global__ __launch_bounds__(256) void csr_scan_add_kernel(int n, int ntiles, const int* __restrict__ tile_sum,
-                                                          int* __restrict__ offsets, int* __restrict__ cursor) {
+                                                          int* __restrict__ offsets) {
   __shared__ int s_part[4];
   int part = 0;
   for (int t = threadIdx.x; t < (int)blockIdx.x; t += 256) part += tile_sum[t];
@@ -62,25 +62,24 @@ static __global__ __launch_bounds__(256) void csr_scan_add_kernel(int n, int nti
   const int lo = blockIdx.x * kScanTile + threadIdx.x * 8;
 #pragma unroll
   for (int i = 0; i < 8; i++)
-    if (lo + i < n) {
-      offsets[lo + i] += base;
-      cursor[lo + i] = 0;
-    }
+    if (lo + i < n) offsets[lo + i] += base;
   if (blockIdx.x == ntiles - 1 && threadIdx.x == 0) {
     // total = base + this tile's total -> offsets[n]
     offsets[n] = base + tile_sum[ntiles - 1];
   }
 }
 
+// tap_pos[e] = the value the tap's atomicAdd on counts[key] returned when the row lengths were counted: its place
+// inside the row.  No second round of atomics here.
 static __global__ __launch_bounds__(256) void csr_fill_kernel(const int* __restrict__ tap_key,
+                                                      const int* __restrict__ tap_pos,
                                                       const float* __restrict__ tap_w, long ntaps, int spb4,
-                                                      const int* __restrict__ offsets, int* __restrict__ cursor,
-                                                      Entry* __restrict__ entries) {
+                                                      const int* __restrict__ offsets, Entry* __restrict__ entries) {
   const long e = (long)blockIdx.x * 256 + threadIdx.x;
   if (e >= ntaps) return;
   const int key = tap_key[e];
   if (key < 0) return;
-  const int pos = offsets[key] + atomicAdd(&cursor[key], 1);
+  const int pos = offsets[key] + tap_pos[e];
   Entry en;
   en.src = (int)(e / spb4);  // (roi * nbins + bin): taps are ordered roi, bin, sample, tap
   en.w = tap_w[e];
@@ -130,9 +129,9 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct CsrWs {
   int* counts;
   int* offsets;
-  int* cursor;
   int* tile_sum;
   int* tap_key;
+  int* tap_pos;
   float* tap_w;
   Entry* entries;
   size_t bytes;
@@ -144,25 +143,25 @@ inline CsrWs csr_carve(void* ws, long nkeys, long ntaps) {
   size_t off = 0;
   w.counts = (int*)(p + off);   off += align256(sizeof(int) * nkeys);
   w.offsets = (int*)(p + off);  off += align256(sizeof(int) * (nkeys + 1));
-  w.cursor = (int*)(p + off);   off += align256(sizeof(int) * nkeys);
   w.tile_sum = (int*)(p + off); off += align256(sizeof(int) * ((nkeys + kScanTile - 1) / kScanTile + 1));
   w.tap_key = (int*)(p + off);  off += align256(sizeof(int) * ntaps);
+  w.tap_pos = (int*)(p + off);  off += align256(sizeof(int) * ntaps);
   w.tap_w = (float*)(p + off);  off += align256(sizeof(float) * ntaps);
   w.entries = (Entry*)(p + off); off += align256(sizeof(Entry) * ntaps);
   w.bytes = off;
   return w;
 }
 
-// counts[] must already hold the row lengths and tap_key / tap_w the taps (key < 0 = dropped tap).
+// counts[] must already hold the row lengths and tap_key / tap_pos / tap_w the taps (key < 0 = dropped tap;
+// tap_pos = return value of the atomicAdd that counted it).
 // taps_per_src consecutive taps share one source row (entry.src = tap index / taps_per_src).
 inline int csr_finish_and_gather(const CsrWs& w, long nkeys, long ntaps, int taps_per_src, const float* src, int C,
                                  float* dst, hipStream_t st) {
   const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
   hipLaunchKernelGGL(csr_scan_local_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, w.offsets, w.tile_sum);
-  hipLaunchKernelGGL(csr_scan_add_kernel, dim3(ntiles), dim3(256), 0, st, (int)nkeys, ntiles, w.tile_sum, w.offsets,
-                     w.cursor);
-  hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((ntaps + 255) / 256)), dim3(256), 0, st, w.tap_key, w.tap_w,
-                     ntaps, taps_per_src, w.offsets, w.cursor, w.entries);
+  hipLaunchKernelGGL(csr_scan_add_kernel, dim3(ntiles), dim3(256), 0, st, (int)nkeys, ntiles, w.tile_sum, w.offsets);
+  hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((ntaps + 255) / 256)), dim3(256), 0, st, w.tap_key, w.tap_pos,
+                     w.tap_w, ntaps, taps_per_src, w.offsets, w.entries);
   hipLaunchKernelGGL((csr_gather_kernel<4>), dim3((unsigned)((nkeys + 3) / 4)), dim3(256), 0, st, src, w.offsets,
                      w.entries, (int)nkeys, C, dst);
   return jdet_launch_status();

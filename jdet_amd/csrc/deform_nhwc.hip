@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void deform_im2col_nhwc_kernel(const float* __
 
 // taps of the input gradient: one lane per (pos, tap) -> 4 (pixel, weight) pairs (get_gradient_weight)
 __global__ __launch_bounds__(256) void deform_taps_kernel(const float* __restrict__ offset, DcnN p, long nitems,
-                                                         int* __restrict__ tap_key, float* __restrict__ tap_w,
-                                                         int* __restrict__ counts) {
+                                                         int* __restrict__ tap_key, int* __restrict__ tap_pos,
+                                                         float* __restrict__ tap_w, int* __restrict__ counts) {
   const long it = (long)blockIdx.x * 256 + threadIdx.x;
   if (it >= nitems) return;
   const int kk = p.kh * p.kw;
@@ -102,12 +102,13 @@ __global__ __launch_bounds__(256) void deform_taps_kernel(const float* __restric
                         (s.h + 1 - (s.hl + 1)) * (s.wl + 1 - s.w), (s.h + 1 - (s.hl + 1)) * (s.w + 1 - (s.wl + 1))};
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    int key = -1;
+    int key = -1, pos = 0;
     if (s.inside && hs[k] >= 0 && hs[k] < p.H && ws[k] >= 0 && ws[k] < p.W && wts[k] != 0.f) {
       key = (b * p.H + hs[k]) * p.W + ws[k];
-      atomicAdd(&counts[key], 1);
+      pos = atomicAdd(&counts[key], 1);
     }
     tap_key[it * 4 + k] = key;
+    tap_pos[it * 4 + k] = pos;
     tap_w[it * 4 + k] = wts[k];
   }
 }
@@ -168,6 +169,6 @@ JDET_API int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset
   int he = jdet_zero_async(w.counts, sizeof(int) * npix, st);
   if (he) return he;
   hipLaunchKernelGGL(deform_taps_kernel, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, st, offset, p, nitems,
-                     w.tap_key, w.tap_w, w.counts);
+                     w.tap_key, w.tap_pos, w.tap_w, w.counts);
   return csr_finish_and_gather(w, npix, ntaps, 4, grad_cols, C, grad_x_nhwc, st);
 }
