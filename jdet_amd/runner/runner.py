@@ -221,6 +221,58 @@ class Runner:
         self.iter += 1
         return all_loss.detach(), {k: v.detach() for k, v in losses.items()}
 
+    # ------------------------------------------------------------------ checkpoints
+    # runner.py:L223-262.  `jt.save` of a `.pkl` is a pickle of plain python containers with every Var turned into
+    # a numpy array, so reference checkpoints load without Jittor and ours load there: {"meta", "model" (parameter
+    # name -> array, same names as the reference's modules), "scheduler", "optimizer"}.
+    def save(self, path):
+        import pickle
+        if self.rank != 0:
+            return None
+        data = {
+            "meta": {"jdet_version": "jdet_amd", "epoch": self.epoch, "iter": self.iter,
+                     "save_time": time.strftime("%Y-%m-%d %H:%M:%S")},
+            "model": {k: v.detach().cpu().numpy() for k, v in self.model.state_dict().items()},
+            "scheduler": self.scheduler.parameters() if self.scheduler is not None and
+            hasattr(self.scheduler, "parameters") else {},
+            "optimizer": {"lr": self.optimizer.cur_lr()},
+        }
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "wb") as f:
+            pickle.dump(data, f)
+        return path
+
+    def load(self, path, model_only=False):
+        """returns (missing, unexpected, mismatched) parameter names; like `load_parameters` in the reference, names
+        that do not line up are reported, not fatal"""
+        import pickle
+        with open(path, "rb") as f:
+            data = pickle.load(f)
+        if not model_only and isinstance(data, dict):
+            meta = data.get("meta", {})
+            self.epoch = meta.get("epoch", self.epoch)
+            self.iter = meta.get("iter", self.iter)
+        if isinstance(data, dict) and "model" in data:
+            params = data["model"]
+        elif isinstance(data, dict) and "state_dict" in data:
+            params = data["state_dict"]
+        else:
+            params = data
+        own = self.model.state_dict()
+        missing = [k for k in own if k not in params and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in params if k not in own]
+        mismatched = []
+        with torch.no_grad():
+            for k, v in params.items():
+                if k not in own:
+                    continue
+                t = torch.as_tensor(np.asarray(v))
+                if tuple(t.shape) != tuple(own[k].shape):
+                    mismatched.append(k)
+                    continue
+                own[k].copy_(t.to(own[k].dtype))      # keeps the parameter's own memory format
+        return missing, unexpected, mismatched
+
     def test_time(self, images, targets, warmup=10, iters=100):
         """the reference's own throughput definition (runner.py:L91-115): FPS = batch*world*iters/wall"""
         for _ in range(warmup):

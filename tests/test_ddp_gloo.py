@@ -120,3 +120,33 @@ def test_bench_takes_max_over_ranks(tmp_path):
     out = str(tmp_path / "t.pt")
     mp.spawn(_timing_worker, args=(2, port, out), nprocs=2, join=True)
     assert abs(torch.load(out) - 0.20) < 1e-9
+
+
+def test_checkpoint_round_trip_and_reference_style_pickle(tmp_path):
+    """Runner.save / load use the reference's checkpoint layout (runner.py:L223-262): a pickle of
+    {"meta", "model": name -> numpy array, ...}; a bare name -> array dict (what `jt.save(model.state_dict())` gives)
+    loads too; unknown / mis-shaped entries are reported, not fatal."""
+    import pickle
+    import numpy as np
+    from jdet_amd.runner import Runner
+    torch.manual_seed(0)
+    a = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    a.iter, a.epoch = 37, 2
+    path = a.save(str(tmp_path / "ckpt_2.pkl"))
+    raw = pickle.load(open(path, "rb"))
+    assert set(raw) >= {"meta", "model", "scheduler", "optimizer"}
+    assert all(isinstance(v, np.ndarray) for v in raw["model"].values())
+    torch.manual_seed(1)
+    b = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    missing, unexpected, mismatched = b.load(path)
+    assert not missing and not unexpected and not mismatched
+    assert (b.iter, b.epoch) == (37, 2)
+    for (k, v), (_, w) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(v, w), k
+    bare = dict(raw["model"])
+    first = next(iter(bare))
+    bare["not.a.parameter"] = np.zeros(3, np.float32)
+    bare[first] = np.zeros((1, 2, 3), np.float32)
+    pickle.dump(bare, open(tmp_path / "bare.pkl", "wb"))
+    missing, unexpected, mismatched = b.load(str(tmp_path / "bare.pkl"), model_only=True)
+    assert unexpected == ["not.a.parameter"] and mismatched == [first] and not missing
