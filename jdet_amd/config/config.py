@@ -1,12 +1,16 @@
-"""Config loader.  Mirrors python/jdet/config/config.py:L16-165: `.py` / `.yaml` files, `_base_`
-inheritance (str or list, relative to the including file), `_cover_` to replace instead of merge,
-attribute access returning None for missing keys, `name` / `work_dir` defaults."""
+"""Config files of the reference, loaded unchanged.
+
+Contract of python/jdet/config/config.py:L16-165: `.py` and `.yaml` files; `_base_` (a path or a list of paths,
+relative to the including file) is loaded first and the including file merged over it, dict by dict; a dict carrying
+`_cover_: True` replaces instead of merging; nested dicts become `Config` objects whose missing attributes read as
+None; `name` defaults to the file stem and `work_dir` to `work_dirs/<name>`; one process-wide instance behind
+`init_cfg` / `get_cfg` / `update_cfg` / `save_cfg` / `print_cfg`.
+"""
 import copy
-import inspect
 import os
-import sys
+import runpy
+import types
 from collections import OrderedDict
-from importlib import import_module
 
 import yaml
 
@@ -15,116 +19,95 @@ BASE_KEY = "_base_"
 COVER_KEY = "_cover_"
 
 
+def _read_file(path):
+    """one file -> plain dict (python configs: the module namespace without dunders and imported modules)"""
+    assert os.path.isfile(path), path
+    ext = os.path.splitext(path)[1]
+    if ext == ".yaml":
+        with open(path, "r") as f:
+            return yaml.safe_load(f.read())
+    assert ext == ".py", "unsupported config type."
+    ns = runpy.run_path(os.path.abspath(path))
+    return {k: v for k, v in ns.items() if not k.startswith("__") and not isinstance(v, types.ModuleType)}
+
+
+def _without_cover_marks(value):
+    if not isinstance(value, dict):
+        return copy.deepcopy(value)
+    return {k: _without_cover_marks(v) for k, v in value.items() if k != COVER_KEY}
+
+
+def _merge(dst, src):
+    """src over dst, in place.  A dict marked `_cover_` replaces; dicts merge recursively; anything else overwrites."""
+    assert isinstance(dst, dict) and isinstance(src, dict)
+    if COVER_KEY in src:
+        dst.clear()
+        dst.update(_without_cover_marks(src))
+        return dst
+    for key, value in src.items():
+        both_dicts = isinstance(value, dict) and isinstance(dst.get(key), dict)
+        if both_dicts and not value.get(COVER_KEY, False):
+            _merge(dst[key], value)
+        else:
+            dst[key] = _without_cover_marks(value)
+    return dst
+
+
+def _load_with_bases(path):
+    own = _read_file(path)
+    bases = own.pop(BASE_KEY, None)
+    if bases is None:
+        return own
+    if isinstance(bases, str):
+        bases = [bases]
+    assert isinstance(bases, list)
+    merged = {}
+    for rel in bases:
+        _merge(merged, _load_with_bases(os.path.join(os.path.dirname(path), rel)))
+    return _merge(merged, own)
+
+
 class Config(OrderedDict):
     def __init__(self, *args):
         super().__init__()
-        if len(args) == 1:
+        assert len(args) <= 1
+        if args:
             self.load_from_file(args[0])
-        else:
-            assert len(args) == 0
 
     def __getattr__(self, name):
-        if name in self:
-            return self[name]
-        return None
+        return self[name] if name in self else None
 
     def __setattr__(self, name, value):
         self[name] = value
 
-    @staticmethod
-    def _load_dict_from_file_no_base(filename):
-        assert os.path.isfile(filename), filename
-        if filename.endswith(".yaml"):
-            with open(filename, "r") as f:
-                cfg = yaml.safe_load(f.read())
-        elif filename.endswith(".py"):
-            f_dir = os.path.dirname(os.path.abspath(filename))
-            module_name = os.path.basename(filename)[:-3]
-            sys.path.insert(0, f_dir)
-            try:
-                sys.modules.pop(module_name, None)
-                mod = import_module(module_name)
-            finally:
-                sys.path.pop(0)
-            cfg = {name: value for name, value in mod.__dict__.items() if not name.startswith("__")}
-            del sys.modules[module_name]
-        else:
-            assert False, "unsupported config type."
-        return cfg
-
-    @staticmethod
-    def _load_dict_from_file(filename):
-        cfg = Config._load_dict_from_file_no_base(filename)
-        cfg_dir = os.path.dirname(filename)
-        if BASE_KEY in cfg:
-            if isinstance(cfg[BASE_KEY], list):
-                base_filenames = cfg[BASE_KEY]
-            else:
-                assert isinstance(cfg[BASE_KEY], str)
-                base_filenames = [cfg[BASE_KEY]]
-            cfg_base = {}
-            for bfn in base_filenames:
-                Config.merge_dict_b2a(cfg_base, Config._load_dict_from_file(os.path.join(cfg_dir, bfn)))
-            cfg.pop(BASE_KEY)
-            Config.merge_dict_b2a(cfg_base, cfg)
-            cfg = cfg_base
-        return cfg
-
-    @staticmethod
-    def merge_dict_b2a(a, b):
-        def clear_cover_key(x):
-            if not isinstance(x, dict):
-                return x
-            out = copy.deepcopy(x)
-            if COVER_KEY in out:
-                out.pop(COVER_KEY)
-            for k, v in out.items():
-                out[k] = clear_cover_key(v)
-            return out
-
-        assert isinstance(a, dict) and isinstance(b, dict)
-        if COVER_KEY in b:
-            a.clear()
-            a.update(clear_cover_key(copy.deepcopy(b)))
-            return
-        for k, v in b.items():
-            if (k not in a) or (isinstance(v, dict) and v.get(COVER_KEY, False)) or (not isinstance(v, dict)) or (
-                    not isinstance(a[k], dict)):
-                a[k] = clear_cover_key(copy.deepcopy(v))
-            else:
-                Config.merge_dict_b2a(a[k], v)
+    @classmethod
+    def _wrap(cls, value):
+        if isinstance(value, dict):
+            node = cls()
+            for k, v in value.items():
+                node[k] = cls._wrap(v)
+            return node
+        if isinstance(value, list):
+            return [cls._wrap(v) for v in value]
+        return copy.deepcopy(value)
 
     def load_from_file(self, filename):
-        cfg = Config._load_dict_from_file(filename)
+        tree = self._wrap(_load_with_bases(filename))
         self.clear()
-        self.update(self.dfs(cfg))
+        self.update(tree)
         if self.name is None:
             self.name = os.path.splitext(os.path.basename(filename))[0]
         if self.work_dir is None:
             self.work_dir = f"work_dirs/{self.name}"
 
-    def dfs(self, cfg_other):
-        if isinstance(cfg_other, dict):
-            now_cfg = Config()
-            for k, d in cfg_other.items():
-                if inspect.ismodule(d):
-                    continue
-                now_cfg[k] = self.dfs(d)
-        elif isinstance(cfg_other, list):
-            now_cfg = [self.dfs(d) for d in cfg_other if not inspect.ismodule(d)]
-        else:
-            now_cfg = copy.deepcopy(cfg_other)
-        return now_cfg
-
     def dump(self):
-        now = dict()
-        for k, d in self.items():
-            if isinstance(d, Config):
-                d = d.dump()
-            if isinstance(d, list):
-                d = [dd.dump() if isinstance(dd, Config) else dd for dd in d]
-            now[k] = d
-        return now
+        def plain(v):
+            if isinstance(v, Config):
+                return {k: plain(x) for k, x in v.items()}
+            if isinstance(v, list):
+                return [plain(x) for x in v]
+            return v
+        return plain(self)
 
 
 _cfg = Config()

@@ -1,24 +1,34 @@
-"""Registries + build_from_cfg.  Mirrors python/jdet/utils/registry.py:L1-63 (same registry names,
-same accepted cfg forms: str | dict with `type` | list -> Sequential | None)."""
+"""Name -> class tables and the config-driven constructor.
+
+Same contract as python/jdet/utils/registry.py:L1-63: the fourteen registry objects by the same names,
+`@REG.register_module()` / `@REG.register_module(name)` / `REG.register_module(module=cls)`, and
+`build_from_cfg(cfg, registry, **kw)` accepting a type string, a dict with a `type` key (remaining keys become
+constructor arguments, `kw` wins), a list (-> nn.Sequential of the built items) or None (-> None).  Duplicate and
+unknown names fail with AssertionError, a bad constructor call with a TypeError naming the class, as there.
+"""
 from torch import nn
+
+_REGISTRY_NAMES = ("DATASETS", "TRANSFORMS", "MODELS", "BACKBONES", "HEADS", "LOSSES", "OPTIMS", "BRICKS", "NECKS",
+                   "SCHEDULERS", "BOXES", "HOOKS", "ROI_EXTRACTORS", "SHARED_HEADS")
 
 
 class Registry:
-    def __init__(self):
+    """a dict of constructors with decorator-style registration"""
+
+    def __init__(self, label=""):
+        self.label = label
         self._modules = {}
 
-    def register_module(self, name=None, module=None):
-        def _register_module(module):
-            key = name
-            if key is None:
-                key = module.__name__
-            assert key not in self._modules, f"{key} is already registered."
-            self._modules[key] = module
-            return module
+    def _add(self, obj, key):
+        key = obj.__name__ if key is None else key
+        assert key not in self._modules, f"{key} is already registered."
+        self._modules[key] = obj
+        return obj
 
-        if module is not None:
-            return _register_module(module)
-        return _register_module
+    def register_module(self, name=None, module=None):
+        if module is None:                      # used as a decorator (with or without an explicit name)
+            return lambda obj: self._add(obj, name)
+        return self._add(module, name)
 
     def get(self, name):
         assert name in self._modules, f"{name} is not registered."
@@ -27,41 +37,34 @@ class Registry:
     def __contains__(self, name):
         return name in self._modules
 
+    def __len__(self):
+        return len(self._modules)
+
+    def __repr__(self):
+        return "Registry(%s: %d entries)" % (self.label, len(self._modules))
+
+
+def _construct(cls, kwargs):
+    try:
+        return cls(**kwargs)
+    except TypeError as err:                    # say which class rejected the arguments
+        msg = str(err)
+        raise TypeError(msg if "<class" in msg else f"{cls}.{msg}")
+
 
 def build_from_cfg(cfg, registry, **kwargs):
+    if cfg is None:
+        return None
+    if isinstance(cfg, list):
+        return nn.Sequential(*(build_from_cfg(item, registry, **kwargs) for item in cfg))
     if isinstance(cfg, str):
         return registry.get(cfg)(**kwargs)
-    elif isinstance(cfg, dict):
-        args = dict(cfg)
-        args.update(kwargs)
-        obj_type = args.pop("type")
-        obj_cls = registry.get(obj_type)
-        try:
-            module = obj_cls(**args)
-        except TypeError as e:
-            if "<class" not in str(e):
-                e = f"{obj_cls}.{e}"
-            raise TypeError(e)
-        return module
-    elif isinstance(cfg, list):
-        return nn.Sequential(*[build_from_cfg(c, registry, **kwargs) for c in cfg])
-    elif cfg is None:
-        return None
-    else:
-        raise TypeError(f"type {type(cfg)} not support")
+    if isinstance(cfg, dict):
+        params = {k: v for k, v in cfg.items() if k != "type"}
+        params.update(kwargs)
+        return _construct(registry.get(cfg["type"]), params)
+    raise TypeError(f"type {type(cfg)} not support")
 
 
-DATASETS = Registry()
-TRANSFORMS = Registry()
-MODELS = Registry()
-BACKBONES = Registry()
-HEADS = Registry()
-LOSSES = Registry()
-OPTIMS = Registry()
-BRICKS = Registry()
-NECKS = Registry()
-SCHEDULERS = Registry()
-BOXES = Registry()
-HOOKS = Registry()
-ROI_EXTRACTORS = Registry()
-SHARED_HEADS = Registry()
+globals().update({_n: Registry(_n) for _n in _REGISTRY_NAMES})
+__all__ = ["Registry", "build_from_cfg", *_REGISTRY_NAMES]

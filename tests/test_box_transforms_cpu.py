@@ -173,7 +173,7 @@ def test_roitrans_modules_build():
     import jdet_amd.models  # noqa: F401
     from jdet_amd.utils.registry import HEADS, MODELS, ROI_EXTRACTORS
     for n in ("RoITransformer",):
-        assert n in MODELS._module_dict if hasattr(MODELS, "_module_dict") else True
+        assert n in MODELS
     from jdet_amd.models.roi_heads import FasterrcnnHead, SharedFCBBoxHeadRbbox
     h = SharedFCBBoxHeadRbbox(num_fcs=2, in_channels=8, fc_out_channels=32, roi_feat_size=7, num_classes=16,
                               reg_class_agnostic=True, with_module=False,
