@@ -88,7 +88,10 @@ class Runner:
             self.train_model = torch.nn.parallel.DistributedDataParallel(
                 self.model, device_ids=[self.device.index] if self.device.type == "cuda" else None,
                 bucket_cap_mb=int(os.environ.get("JDET_DDP_BUCKET_MB", "64")), gradient_as_bucket_view=True,
-                static_graph=os.environ.get("JDET_DDP_STATIC_GRAPH", "1") == "1")
+                static_graph=os.environ.get("JDET_DDP_STATIC_GRAPH", "1") == "1",
+                # the only buffers are BatchNorm statistics, frozen by `norm_eval` (and the reference has no SyncBN,
+                # SURVEY 8e): re-broadcasting them before every forward is pure overhead
+                broadcast_buffers=os.environ.get("JDET_DDP_BROADCAST_BUFFERS", "0") == "1")
         self.iter = 0
         self.epoch = 0
 
