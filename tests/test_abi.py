@@ -80,3 +80,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libjdet_oracle" not in txt, f
+
+
+def test_bench_contract_pieces_importable_without_gpu():
+    """bench.py imports on a CPU-only host; the objects it adds to the JSON line carry the contract's keys; the
+    workload table names the four BASELINE configs"""
+    import importlib
+    bench = importlib.import_module("bench")
+    assert {"s2anet_train", "orcnn_train", "roitrans_train", "roitrans_r50_train"} <= set(bench.TRAIN_WORKLOADS)
+    r = bench.roofline_obj("roi_align_rotated", 167508864, 0.064, "k")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - 167508864 / 1e9 / 0.064e-3) < 1e-6
+    assert r["traffic"] is None or r["traffic"] > 100e6          # PMC bytes per launch, when profiles/ has them
+    for name in ("S2ANET_CFG", "RETINANET_CFG", "ORCNN_CFG"):
+        cfg = getattr(bench, name)
+        assert cfg["model"]["type"] and cfg["model"]["backbone"]["type"].startswith("Resnet")
+    assert bench.roitrans_train_cfg("Resnet101")["model"]["backbone"]["type"] == "Resnet101"
