@@ -97,3 +97,34 @@ def test_bench_contract_pieces_importable_without_gpu():
         cfg = getattr(bench, name)
         assert cfg["model"]["type"] and cfg["model"]["backbone"]["type"].startswith("Resnet")
     assert bench.roitrans_train_cfg("Resnet101")["model"]["backbone"]["type"] == "Resnet101"
+
+
+def test_argument_validation_returns_before_any_launch(built_lib):
+    """every entry point checks its arguments first and reports through the int status (no launch, so this runs
+    without a GPU): JDET_E_BADARG -1, JDET_E_UNSUPPORTED -2, JDET_E_WORKSPACE -3"""
+    lib = built_lib.lib()
+    N = None
+    assert lib.jdet_roi_align_forward(9, N, 1, 4, 8, 8, N, 1, 7, 7, 1.0, 2, 1, N, N, N) == -1       # variant
+    assert lib.jdet_roi_align_forward(0, N, 1, 4, 8, 8, N, 0, 7, 7, 1.0, 2, 1, N, N, N) == 0        # R = 0: no-op
+    assert lib.jdet_roi_align_forward(0, N, 1, 4, 8, 8, N, 3, 7, 7, 1.0, 2, 1, N, N, N) == -1       # null pointers
+    assert lib.jdet_roi_align_forward(0, N, 1, 4, 8, 8, N, 0, 17, 17, 1.0, 2, 1, N, N, N) == -2     # > 256 bins
+    assert lib.jdet_box_iou_rotated(N, 2, N, 2, 4, 0, 0, N, N) == -1                                # stride < 5
+    assert lib.jdet_box_iou_rotated(N, 0, N, 5, 5, 0, 0, N, N) == 0
+    assert lib.jdet_nms_rotated(N, 10, 7, N, 0.1, 1, 0, N, N, 0, N) == -1                           # box_len
+    assert lib.jdet_nms_rotated(N, 0, 5, N, 0.1, 1, 0, N, N, 0, N) == 0
+    assert lib.jdet_assign_max_iou(N, 0, 10, 0.5, 0.0, 0.4, 0.0, 1, 1, N, 0, N, N, N, N, 0, N) == -1  # K = 0
+    assert lib.jdet_anchor_targets_rotated(N, N, N, N, 0, 0, N, N, 1.0, N, N, N, N, N, N) == 0      # A = 0
+    assert lib.jdet_anchor_targets_rotated(N, N, N, N, 5, 1, N, N, 1.0, N, N, N, N, N, N) == -1
+    assert lib.jdet_frozen_bn_act_forward(N, N, 4, 6, N, N, N, N, 1e-5, 1, N, N) == -2              # C % 4
+    assert lib.jdet_frozen_bn_act_forward(N, N, 4, 12, N, N, N, N, 1e-5, 1, N, N) == -2             # C/4 !| 256
+    assert lib.jdet_frozen_bn_act_forward(N, N, 0, 64, N, N, N, N, 1e-5, 1, N, N) == 0
+    assert lib.jdet_frozen_bn_act_forward(N, N, 4, 64, N, N, N, N, 1e-5, 1, N, N) == -1
+    assert lib.jdet_frozen_bn_act_backward_workspace(4, 12) == 0
+    assert lib.jdet_frozen_bn_act_backward_workspace(1 << 20, 256) == 4 * 512 * 2 * 256
+    assert lib.jdet_sigmoid_focal_loss(N, N, N, -1, 15, 0.25, 2.0, N, N, N, 0, N) == -1
+    assert lib.jdet_smooth_l1_loss(N, N, N, 10, -1.0, N, N, N, 0, N) == -1
+    assert lib.jdet_align_conv_offset(N, 1, 8, 8, 8.0, 2, N, N) == -1                               # even kernel
+    assert lib.jdet_align_conv_offset(N, 0, 8, 8, 8.0, 3, N, N) == 0
+    assert lib.jdet_deform_im2col_nhwc(N, N, 1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1, N, N) == -2        # C % 4
+    assert lib.jdet_deform_col2im_nhwc_workspace(1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1) == 0
+    assert lib.jdet_set_roi_forward_mode(7) in (0, 1)                                               # ignored value
