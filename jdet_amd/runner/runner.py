@@ -224,6 +224,30 @@ class Runner:
         self.iter += 1
         return all_loss.detach(), {k: v.detach() for k, v in losses.items()}
 
+    # ------------------------------------------------------------------ training on a dataset
+    def fit(self, dataset, max_epoch=1, max_iter=None, log_interval=0):
+        """runner.py:L117-155 over a `jdet_amd.data` dataset: one process per GPU reads its own shard
+        (DistributedSampler), batches are staged to the device one step ahead on a side stream (DeviceFeeder),
+        `scheduler.step(iter, epoch, by_epoch=True)` after every iteration.  Returns the last (loss, parts)."""
+        from torch.utils.data.distributed import DistributedSampler
+        from jdet_amd.data import DeviceFeeder
+        sampler = DistributedSampler(dataset, shuffle=dataset.shuffle) if self.world_size > 1 else None
+        feeder = DeviceFeeder(dataset.loader(sampler=sampler), self.device)
+        last = None
+        for epoch in range(self.epoch, max_epoch):
+            self.epoch = epoch
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            for images, targets in feeder:
+                last = self.train_step(images, targets)
+                if log_interval and self.rank == 0 and self.iter % log_interval == 0:
+                    print("epoch %d iter %d lr %.6f loss %.4f" % (epoch, self.iter, self.optimizer.cur_lr(),
+                                                                  float(last[0])))
+                if max_iter is not None and self.iter >= max_iter:
+                    return last
+        self.epoch = max_epoch
+        return last
+
     # ------------------------------------------------------------------ checkpoints
     # runner.py:L223-262.  `jt.save` of a `.pkl` is a pickle of plain python containers with every Var turned into
     # a numpy array, so reference checkpoints load without Jittor and ours load there: {"meta", "model" (parameter

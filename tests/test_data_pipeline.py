@@ -1,0 +1,233 @@
+"""CPU: the input pipeline of the named configs -- numpy box algebra against per-box loops that
+follow the reference line by line, transforms against closed forms, datasets / collate / loader on a synthetic
+`dataset_dir` (images + labels.pkl) with the S2ANet config's transform list."""
+import math
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+
+def _rboxes(rng, n, extent=200.0):
+    return np.concatenate([rng.uniform(20, extent - 20, (n, 2)), rng.uniform(6, 60, (n, 2)),
+                           rng.uniform(-math.pi / 4, 3 * math.pi / 4, (n, 1))], 1).astype(np.float32)
+
+
+# ---- per-box restatements (python/jdet/models/boxes/box_ops.py:L436-470, L520-542, L568-590) ---------------------------
+def _best_begin_single(c):
+    x1, y1, x2, y2, x3, y3, x4, y4 = c
+    xmin, ymin, xmax, ymax = min(x1, x2, x3, x4), min(y1, y2, y3, y4), max(x1, x2, x3, x4), max(y1, y2, y3, y4)
+    comb = [[[x1, y1], [x2, y2], [x3, y3], [x4, y4]], [[x2, y2], [x3, y3], [x4, y4], [x1, y1]],
+            [[x3, y3], [x4, y4], [x1, y1], [x2, y2]], [[x4, y4], [x1, y1], [x2, y2], [x3, y3]]]
+    dst = [[xmin, ymin], [xmax, ymin], [xmax, ymax], [xmin, ymax]]
+    force, flag = 100000000.0, 0
+    for i in range(4):
+        f = sum(math.sqrt((comb[i][k][0] - dst[k][0]) ** 2 + (comb[i][k][1] - dst[k][1]) ** 2) for k in range(4))
+        if f < force:
+            force, flag = f, i
+    return np.array(comb[flag]).reshape(8)
+
+
+def _r2p_single(r):
+    x, y, w, h, a = r[:5]
+    rect = np.array([[-w / 2, w / 2, w / 2, -w / 2], [-h / 2, -h / 2, h / 2, h / 2]])
+    R = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    p = R.dot(rect)
+    return np.array([p[0, 0] + x, p[1, 0] + y, p[0, 1] + x, p[1, 1] + y, p[0, 2] + x, p[1, 2] + y, p[0, 3] + x,
+                     p[1, 3] + y], dtype=np.float32)
+
+
+def _p2r_single(poly):
+    from jdet_amd.data.np_boxes import norm_angle
+    poly = np.array(poly[:8], dtype=np.float32)
+    pt1, pt2, pt3, pt4 = (poly[0], poly[1]), (poly[2], poly[3]), (poly[4], poly[5]), (poly[6], poly[7])
+    e1 = np.sqrt((pt1[0] - pt2[0]) ** 2 + (pt1[1] - pt2[1]) ** 2)
+    e2 = np.sqrt((pt2[0] - pt3[0]) ** 2 + (pt2[1] - pt3[1]) ** 2)
+    if e1 > e2:
+        ang = np.arctan2(np.float64(pt2[1] - pt1[1]), np.float64(pt2[0] - pt1[0]))
+    else:
+        ang = np.arctan2(np.float64(pt4[1] - pt1[1]), np.float64(pt4[0] - pt1[0]))
+    return np.array([np.float64(pt1[0] + pt3[0]) / 2, np.float64(pt1[1] + pt3[1]) / 2, max(e1, e2), min(e1, e2),
+                     norm_angle(ang)], dtype=np.float32)
+
+
+def test_np_box_algebra_matches_per_box_restatement():
+    from jdet_amd.data import np_boxes as B
+    rng = np.random.default_rng(0)
+    r = _rboxes(rng, 300)
+    r[:5, 4] = [0.0, math.pi / 2, -math.pi / 4, math.pi / 4, 3 * math.pi / 4 - 1e-4]     # axis-aligned / range ends
+    r[5, 2:4] = 30.0                                                                       # square: tie of the edges
+    polys = B.rotated_box_to_poly_np(r)
+    ref = np.stack([_best_begin_single(_r2p_single(b).tolist()) for b in r]).astype(np.float32)
+    np.testing.assert_allclose(polys, ref, rtol=0, atol=3e-5)    # same vertices, same begin point (1 ulp: dot vs a*b+c*d)
+    back = B.poly_to_rotated_box_np(polys)
+    np.testing.assert_allclose(back, np.stack([_p2r_single(p) for p in polys]), rtol=0, atol=1e-6)
+    # same rectangle up to the (w,h,theta) <-> (h,w,theta +- pi/2) ambiguity: compare through the polygons' extents
+    hb, _ = B.rotated_box_to_bbox_np(r)
+    hb2, _ = B.rotated_box_to_bbox_np(back)
+    np.testing.assert_allclose(hb, hb2, atol=2e-3)
+    assert B.rotated_box_to_poly_np(np.zeros((0, 5), np.float32)).shape == (0, 8)
+    assert B.rotated_box_to_bbox_np(np.zeros((0, 5)))[0].shape == (0, 4)
+    a = np.array([-1.0, 0.0, 2.5, 4.0])
+    np.testing.assert_allclose(B.norm_angle(a), (a + math.pi / 4) % math.pi - math.pi / 4)
+
+
+def _target(r, w, h):
+    from jdet_amd.data.np_boxes import rotated_box_to_bbox_np
+    hb, polys = rotated_box_to_bbox_np(r)
+    return dict(rboxes=r.copy(), hboxes=hb.astype(np.float32), polys=polys.copy(), labels=np.ones(len(r), np.int32),
+                rboxes_ignore=np.zeros((0, 5), np.float32), hboxes_ignore=np.zeros((0, 4)),
+                polys_ignore=np.zeros((0, 8)), img_size=(w, h), ori_img_size=(w, h), scale_factor=1.0)
+
+
+def test_transforms_closed_forms():
+    from jdet_amd.data import transforms as T
+    rng = np.random.default_rng(1)
+    w, h = 200, 160
+    img = Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8))
+    r = _rboxes(rng, 20, 150.0)
+    # flip twice = identity (angles through norm_angle); image pixels mirrored
+    for direction in ("horizontal", "vertical"):
+        f = T.RotatedRandomFlip(prob=1.0, direction=direction)
+        im1, t1 = f(img, _target(r, w, h))
+        assert t1["flip"] == direction
+        a0, a1 = np.array(img), np.array(im1)
+        np.testing.assert_array_equal(a1, a0[:, ::-1] if direction == "horizontal" else a0[::-1])
+        im2, t2 = f(im1, t1)
+        np.testing.assert_array_equal(np.array(im2), a0)
+        np.testing.assert_allclose(t2["rboxes"][:, :4], r[:, :4], atol=1e-4)
+        d = (t2["rboxes"][:, 4] - r[:, 4] + math.pi / 2) % math.pi - math.pi / 2
+        np.testing.assert_allclose(d, 0, atol=1e-5)
+        np.testing.assert_allclose(t2["polys"], _target(r, w, h)["polys"], atol=1e-4)
+    t = T.RotatedRandomFlip(prob=1.0, direction="horizontal")(img, _target(r, w, h))[1]
+    np.testing.assert_allclose(t["rboxes"][:, 0], w - r[:, 0] - 1, atol=1e-5)
+    np.testing.assert_allclose(t["hboxes"][:, 0], w - _target(r, w, h)["hboxes"][:, 2], atol=1e-5)
+    assert T.RotatedRandomFlip(prob=0.0)(img, _target(r, w, h))[1].get("flip") is None
+    # resize: short side to 320 (x2), boxes scale with it
+    rs = T.RotatedResize(min_size=320, max_size=4000)
+    (oh, ow), sf = rs.get_size((w, h))
+    assert (oh, ow) == (240, 300) and sf == 1.5           # clipped to 1.5 x the short side (160 -> 240)
+    r = r.copy()
+    r[:, :2] = rng.uniform(60, 100, (len(r), 2))          # fully inside the image: no vertex gets clipped
+    im, t = rs(img, _target(r, w, h))
+    assert im.size == (300, 240) and t["img_size"] == (300, 240) and t["pad_shape"] == (300, 240)
+    assert t["scale_factor"] == 1.5 and t["keep_ratio"] is True
+    np.testing.assert_allclose(t["rboxes"][:, :2], r[:, :2] * 1.5, rtol=2e-3, atol=0.2)
+    # the refit from the polygon names the long edge w (poly_to_rotated_box): compare as (long, short)
+    np.testing.assert_allclose(t["rboxes"][:, 2:4], np.sort(r[:, 2:4], 1)[:, ::-1] * 1.5, rtol=2e-3, atol=0.2)
+    assert bool((t["rboxes"][:, 2] >= t["rboxes"][:, 3]).all())
+    assert T.Resize(1024, 1024).get_size((1024, 1024)) == ((1024, 1024), 1.)
+    assert T.Resize(800, 1333).get_size((2000, 1000))[0] == (666, 1332)     # long side capped by max_size (int(666 * 2))
+    assert T.Resize(64, 128, keep_ratio=False).get_size((50, 40)) == ((64, 128), 64 / 40)
+    # pad to a multiple of 32 with zeros, normalise with / without the BGR swap
+    im, t = T.Pad(size_divisor=32)(img, dict())
+    assert im.size == (224, 160) and t["pad_shape"] == (224, 160)
+    assert np.array(im)[:, 200:].max() == 0
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    x, t = T.Normalize(mean, std, to_bgr=False)(img, dict())
+    assert x.shape == (3, h, w) and x.dtype == np.float32 and t["to_bgr"] is False
+    np.testing.assert_allclose(x[1], (np.array(img)[:, :, 1] - mean[1]) / std[1], rtol=1e-5, atol=1e-6)
+    xb, _ = T.Normalize(mean, std, to_bgr=True)(img, dict())
+    np.testing.assert_allclose(xb[0], (np.array(img)[:, :, 2] - mean[0]) / std[0], rtol=1e-5, atol=1e-6)
+    with pytest.raises(AssertionError):
+        T.Pad(size=(10, 10), size_divisor=32)
+    with pytest.raises(TypeError):
+        T.Compose([3])
+
+
+S2ANET_TRAIN_TRANSFORMS = [   # configs/s2anet/s2anet_r50_fpn_1x_dota.py: dataset.train.transforms
+    dict(type="RotatedResize", min_size=1024, max_size=1024),
+    dict(type="RotatedRandomFlip", prob=0.5),
+    dict(type="Pad", size_divisor=32),
+    dict(type="Normalize", mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_bgr=False)]
+
+
+def _make_dataset(root, sizes, rng, empty=()):
+    os.makedirs(os.path.join(root, "images"))
+    infos = []
+    for i, (w, h) in enumerate(sizes):
+        name = "P%04d.png" % i
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "images", name))
+        n = 0 if i in empty else int(rng.integers(1, 6))
+        infos.append(dict(filename=name, width=w, height=h, ann=dict(
+            bboxes=_rboxes(rng, n, min(w, h)) if n else np.zeros((0, 5), np.float32),
+            labels=rng.integers(1, 16, n).astype(np.int64), bboxes_ignore=np.zeros((0, 5), np.float32),
+            labels_ignore=np.zeros((0,), np.int64))))
+    with open(os.path.join(root, "labels.pkl"), "wb") as f:
+        pickle.dump(infos, f)
+    return infos
+
+
+def test_dota_dataset_collate_loader_and_feeder(tmp_path):
+    from jdet_amd.data import DeviceFeeder, DOTADataset, ImageDataset, collate_batch
+    from jdet_amd.utils.registry import DATASETS, build_from_cfg
+    rng = np.random.default_rng(5)
+    root = str(tmp_path / "trainval")
+    infos = _make_dataset(root, [(96, 64), (64, 64), (80, 120), (64, 96), (50, 40)], rng, empty=(1,))
+    tfm = [dict(type="RotatedResize", min_size=64, max_size=128), dict(type="RotatedRandomFlip", prob=0.5),
+           dict(type="Pad", size_divisor=32), S2ANET_TRAIN_TRANSFORMS[3]]
+    ds = build_from_cfg(dict(type="DOTADataset", dataset_dir=root, transforms=tfm, batch_size=2, num_workers=2,
+                             shuffle=False, filter_min_size=45), DATASETS)
+    assert isinstance(ds, DOTADataset) and len(ds.CLASSES) == 15
+    assert len(ds) == 3          # the empty record and the 50x40 image (min side < 45) are filtered out
+    image, t = ds[0]
+    assert image.dtype == np.float32 and image.shape[0] == 3 and image.shape[1] % 32 == 0 and image.shape[2] % 32 == 0
+    assert set(t) >= {"rboxes", "hboxes", "polys", "labels", "rboxes_ignore", "hboxes_ignore", "polys_ignore",
+                      "classes", "ori_img_size", "img_size", "scale_factor", "filename", "img_file", "pad_shape",
+                      "mean", "std", "to_bgr", "keep_ratio"}
+    assert t["rboxes"].dtype == np.float32 and t["labels"].dtype == np.int32 and t["ori_img_size"] == (96, 64)
+    assert t["pad_shape"] == (image.shape[2], image.shape[1]) and t["rboxes"].shape[1] == 5
+    imgs, ts = collate_batch([ds[0], ds[1]])
+    assert imgs.shape[0] == 2 and imgs.shape[2] == max(ds[0][0].shape[1], ds[1][0].shape[1])
+    seen = []
+    feeder = DeviceFeeder(ds.loader(), "cpu")
+    assert len(feeder) == 2
+    for images, targets in feeder:
+        assert torch.is_tensor(images) and images.dtype == torch.float32 and images.dim() == 4
+        assert images.is_contiguous(memory_format=torch.channels_last)
+        for tg in targets:
+            assert torch.is_tensor(tg["rboxes"]) and tg["rboxes"].dtype == torch.float32
+            assert tg["labels"].dtype == torch.int32 and tg["rboxes"].shape[0] == tg["labels"].shape[0] > 0
+            seen.append(tg["filename"])
+    assert sorted(seen) == ["P0000.png", "P0002.png", "P0003.png"]
+    # category balancing repeats rare classes; DOTA submission files
+    bal = DOTADataset(dataset_dir=root, transforms=tfm, balance_category=True)
+    assert len(bal) >= len(ds)
+    res = [((np.array([[30., 30., 20., 10., 0.3, 0.9], [50., 40., 8., 8., 0.0, 0.5]]), np.array([0, 14])),
+            "P0000.png")]
+    ds.parse_result(res, str(tmp_path / "sub"))
+    rows = open(tmp_path / "sub" / "plane.txt").read().split()
+    assert rows[0] == "P0000" and rows[1] == "0.9000" and len(rows) == 10
+    assert os.path.exists(tmp_path / "sub" / "helicopter.txt")
+    with pytest.raises(NotImplementedError):
+        ds.evaluate([], None, 0)
+    # test-time dataset: images only
+    ids = ImageDataset(images_dir=os.path.join(root, "images"), transforms=[tfm[0], tfm[2], tfm[3]])
+    assert len(ids) == 5
+    im, tt = ids[2]
+    assert set(tt) >= {"ori_img_size", "img_size", "scale_factor", "img_file", "pad_shape"} and "rboxes" not in tt
+    assert tt["ori_img_size"] == (80, 120) and im.shape[0] == 3
+
+
+def test_runner_fit_over_a_dataset(tmp_path):
+    """Runner.fit: dataset -> loader -> DeviceFeeder -> train_step, with the production Runner and a tiny CPU model
+    (the detectors need a HIP device)"""
+    from tests.test_ddp_gloo import CFG, _register_tiny
+    from jdet_amd.data import DOTADataset
+    from jdet_amd.runner import Runner
+    _register_tiny()
+    rng = np.random.default_rng(9)
+    root = str(tmp_path / "train")
+    _make_dataset(root, [(64, 64)] * 6, rng)
+    tfm = [dict(type="RotatedResize", min_size=64, max_size=64), dict(type="Pad", size_divisor=32),
+           S2ANET_TRAIN_TRANSFORMS[3]]
+    ds = DOTADataset(dataset_dir=root, transforms=tfm, batch_size=2, num_workers=0, shuffle=True)
+    torch.manual_seed(0)
+    r = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    loss, parts = r.fit(ds, max_epoch=2)
+    assert r.iter == 6 and r.epoch == 2 and torch.isfinite(loss) and "loss_reg" in parts
+    loss2, _ = r.fit(ds, max_epoch=5, max_iter=8)
+    assert r.iter == 8 and torch.isfinite(loss2)
