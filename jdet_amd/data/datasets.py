@@ -11,7 +11,7 @@ The reference's datasets are Jittor `Dataset`s that batch and prefetch themselve
 `torch.utils.data.Dataset`s; `loader()` wraps them in a DataLoader (worker processes, the reference's collate rule,
 pinned host memory) and `DeviceFeeder` overlaps the host-to-device copy of batch k+1 with the step on batch k on its
 own HIP stream, delivering channels-last images and device-resident targets.  mAP evaluation (`voc_eval_dota` with
-polygon IoU) is SURVEY 8(f) item 2: not here yet.
+polygon IoU) lives in voc_eval.py: the IoU matrices come from the device kernel, the AP bookkeeping is numpy.
 """
 import os
 import pickle
@@ -174,8 +174,16 @@ class DOTADataset(CustomDataset):
             with open(os.path.join(save_path, classname + ".txt"), "w") as f:
                 f.writelines(rows)
 
-    def evaluate(self, results, work_dir, epoch, logger=None, save=True):
-        raise NotImplementedError("DOTA mAP (voc_eval_dota + polygon IoU, data/dota.py:L89-146) is SURVEY 8(f) item 2")
+    def evaluate(self, results, work_dir, epoch, logger=None, save=True, iou_matrix_fn=None):
+        """[((det_polys, det_scores, det_labels), target)] -> {"eval/<i>_<class>_AP", "eval/0_meanAP"}
+        (data/dota.py:L89-146); IoU matrices on the HIP device unless `iou_matrix_fn` is given"""
+        from .voc_eval import device_iou_matrix, evaluate_dota
+        if save and work_dir is not None:
+            path = os.path.join(work_dir, "detections/val_%s" % epoch)
+            os.makedirs(path, exist_ok=True)
+            with open(os.path.join(path, "val.pkl"), "wb") as f:
+                pickle.dump(results, f)
+        return evaluate_dota(results, self.CLASSES, iou_matrix_fn or device_iou_matrix)
 
 
 @DATASETS.register_module()

@@ -202,8 +202,6 @@ def test_dota_dataset_collate_loader_and_feeder(tmp_path):
     rows = open(tmp_path / "sub" / "plane.txt").read().split()
     assert rows[0] == "P0000" and rows[1] == "0.9000" and len(rows) == 10
     assert os.path.exists(tmp_path / "sub" / "helicopter.txt")
-    with pytest.raises(NotImplementedError):
-        ds.evaluate([], None, 0)
     # test-time dataset: images only
     ids = ImageDataset(images_dir=os.path.join(root, "images"), transforms=[tfm[0], tfm[2], tfm[3]])
     assert len(ids) == 5
@@ -231,3 +229,105 @@ def test_runner_fit_over_a_dataset(tmp_path):
     assert r.iter == 6 and r.epoch == 2 and torch.isfinite(loss) and "loss_reg" in parts
     loss2, _ = r.fit(ds, max_epoch=5, max_iter=8)
     assert r.iter == 8 and torch.isfinite(loss2)
+
+
+# ---- DOTA AP: batched-IoU implementation against the per-detection loop of devkits/voc_eval.py:L236-336 ---------------
+def _oracle_iou_matrix(det_polys, gt_polys):
+    from jdet_amd.data.np_boxes import poly_to_rotated_box_np
+    from oracle import oracle as O
+    return O.box_iou_rotated(poly_to_rotated_box_np(det_polys), poly_to_rotated_box_np(gt_polys))
+
+
+def _voc_eval_loop(dets, gts, ovthresh=0.5):
+    """restatement of the reference's loop (hbb prefilter with the +1 convention, pairwise IoU, take-once flags)"""
+    from jdet_amd.data.voc_eval import voc_ap
+    dets = np.array(dets.tolist())
+    gts = {k: dict(box=v["box"].copy(), difficult=v["difficult"].copy(), det=[False] * len(v["box"]))
+           for k, v in gts.items()}
+    npos = sum([sum(~gts[k]["difficult"]) for k in gts])
+    nd = len(dets)
+    if nd == 0 or npos == 0:
+        return 0., 0., 0.
+    confidence, dets = dets[:, -1], dets[:, :-1]
+    dets = dets[np.argsort(-confidence), :]
+    tp, fp = np.zeros(nd), np.zeros(nd)
+    for d, det in enumerate(dets):
+        bb = det[1:].astype(float)
+        ovmax, jmax = -np.inf, -1
+        R = gts[int(det[0])]
+        BBGT = R["box"].astype(float)
+        if BBGT.size > 0:
+            gx0, gy0 = BBGT[:, 0::2].min(1), BBGT[:, 1::2].min(1)
+            gx1, gy1 = BBGT[:, 0::2].max(1), BBGT[:, 1::2].max(1)
+            bx0, by0, bx1, by1 = bb[0::2].min(), bb[1::2].min(), bb[0::2].max(), bb[1::2].max()
+            iw = np.maximum(np.minimum(gx1, bx1) - np.maximum(gx0, bx0) + 1., 0.)
+            ih = np.maximum(np.minimum(gy1, by1) - np.maximum(gy0, by0) + 1., 0.)
+            inters = iw * ih
+            uni = (bx1 - bx0 + 1.) * (by1 - by0 + 1.) + (gx1 - gx0 + 1.) * (gy1 - gy0 + 1.) - inters
+            keep = np.where(inters / uni > 0)[0]
+            if len(keep) > 0:
+                ov = [float(_oracle_iou_matrix(bb[None].astype(np.float32), BBGT[j][None].astype(np.float32))[0, 0])
+                      for j in keep]
+                ovmax, jmax = np.max(ov), keep[int(np.argmax(ov))]
+        if ovmax > ovthresh:
+            if not R["difficult"][jmax]:
+                if not R["det"][jmax]:
+                    tp[d] = 1.
+                    R["det"][jmax] = 1
+                else:
+                    fp[d] = 1.
+        else:
+            fp[d] = 1.
+    fp, tp = np.cumsum(fp), np.cumsum(tp)
+    rec = tp / float(npos)
+    prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
+    return rec, prec, voc_ap(rec, prec)
+
+
+def test_voc_eval_dota_matches_the_per_detection_loop():
+    from jdet_amd.data.np_boxes import rotated_box_to_poly_np
+    from jdet_amd.data.voc_eval import evaluate_dota, voc_ap, voc_eval_dota
+    rng = np.random.default_rng(12)
+    gts, dets = {}, []
+    for img in range(6):
+        k = int(rng.integers(0, 7))
+        g = _rboxes(rng, k, 300.0)
+        gts[img] = dict(box=rotated_box_to_poly_np(g).astype(np.float64).reshape(-1, 8),
+                        difficult=rng.uniform(0, 1, k) < 0.25)
+        # detections: jittered copies of gts (some twice -> duplicates), plus random false alarms
+        cand = np.concatenate([g, g[: k // 2], _rboxes(rng, 4, 300.0)]) if k else _rboxes(rng, 3, 300.0)
+        cand = cand + rng.normal(0, 1.0, cand.shape).astype(np.float32) * np.array([1, 1, 1, 1, 0.02], np.float32)
+        p = rotated_box_to_poly_np(cand)
+        sc = rng.uniform(0.05, 1, len(p)) + np.arange(len(p)) * 1e-6 + img * 1e-4     # no ties
+        dets.append(np.concatenate([np.full((len(p), 1), img), p, sc[:, None]], 1))
+    dets = np.concatenate(dets)
+    rec, prec, ap = voc_eval_dota(dets, gts, _oracle_iou_matrix)
+    rec2, prec2, ap2 = _voc_eval_loop(dets, gts)
+    np.testing.assert_array_equal(rec, rec2)
+    np.testing.assert_array_equal(prec, prec2)
+    assert ap == ap2 and 0.2 < ap <= 1.0
+    # closed forms: perfect detections -> AP 1; nothing -> 0; 11-point metric; PR envelope
+    perfect = np.concatenate([np.concatenate([np.full((len(v["box"]), 1), k), v["box"],
+                                              np.linspace(0.9, 0.5, len(v["box"]))[:, None]], 1)
+                              for k, v in gts.items() if len(v["box"])])
+    easy = {k: dict(box=v["box"], difficult=np.zeros(len(v["box"]), bool)) for k, v in gts.items()}
+    assert abs(voc_eval_dota(perfect, easy, _oracle_iou_matrix)[2] - 1.0) < 1e-12
+    assert voc_eval_dota(np.zeros((0, 10)), easy, _oracle_iou_matrix) == (0., 0., 0.)
+    r, p = np.array([0.5, 0.5, 1.0]), np.array([1.0, 0.5, 2 / 3])
+    assert abs(voc_ap(r, p) - (0.5 * 1.0 + 0.5 * 2 / 3)) < 1e-12
+    assert abs(voc_ap(r, p, use_07_metric=True) - (6 * 1.0 + 5 * 2 / 3) / 11) < 1e-12
+    # dataset-level wrapper: classes, 0-based detection labels, scale factor, difficult (ignore) polygons
+    classes = ["a", "b", "c"]
+    results = []
+    for img in range(4):
+        g = _rboxes(rng, 5, 300.0)
+        labels = rng.integers(1, 3, 5)
+        gp = rotated_box_to_poly_np(g)
+        results.append(((gp.copy(), np.linspace(0.9, 0.6, 5), labels - 1),
+                        dict(scale_factor=2.0, polys=gp * 2.0, labels=labels,
+                             polys_ignore=rotated_box_to_poly_np(_rboxes(rng, 1, 300.0)) * 2.0)))
+    aps = evaluate_dota(results, classes, _oracle_iou_matrix)
+    assert set(aps) == {"eval/1_a_AP", "eval/2_b_AP", "eval/3_c_AP", "eval/0_meanAP"}
+    assert abs(aps["eval/1_a_AP"] - 1.0) < 1e-12 and abs(aps["eval/2_b_AP"] - 1.0) < 1e-12 and aps["eval/3_c_AP"] == 0
+    assert abs(aps["eval/0_meanAP"] - 2 / 3) < 1e-12
+    assert evaluate_dota([], classes, _oracle_iou_matrix)["eval/0_meanAP"] == 0

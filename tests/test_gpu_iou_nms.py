@@ -167,3 +167,25 @@ def test_multiclass_nms_rotated(dev):
     assert total == det.shape[0]
     e_det, e_lab = multiclass_nms_rotated(boxes, sc * 0, 0.05, dict(iou_thr=0.1), 100)
     assert e_det.shape == (0, 6) and e_lab.shape == (0,)
+
+
+def test_dota_evaluation_iou_runs_on_the_device(dev):
+    """DOTADataset.evaluate's IoU matrices (polygons of rotated boxes -> box_iou_rotated on the device) equal the
+    oracle's, and the AP of perfect detections is 1"""
+    from jdet_amd.data.np_boxes import poly_to_rotated_box_np, rotated_box_to_poly_np
+    from jdet_amd.data.voc_eval import device_iou_matrix, evaluate_dota
+    rng = np.random.default_rng(21)
+    a = rotated_box_to_poly_np(I.random_obbs(rng, 40))
+    b = rotated_box_to_poly_np(I.clustered_obbs(rng, 30, 6, 1024.0))
+    got = device_iou_matrix(a, b, dev)
+    ref = O.box_iou_rotated(poly_to_rotated_box_np(a), poly_to_rotated_box_np(b))
+    np.testing.assert_array_equal(got, ref)
+    results = []
+    for _ in range(3):
+        g = I.random_obbs(rng, 6)
+        gp = rotated_box_to_poly_np(g)
+        labels = rng.integers(1, 4, 6)
+        results.append(((gp.copy(), np.linspace(0.9, 0.5, 6), labels - 1),
+                        dict(scale_factor=1.0, polys=gp, labels=labels, polys_ignore=np.zeros((0, 8)))))
+    aps = evaluate_dota(results, ["a", "b", "c"], lambda x, y: device_iou_matrix(x, y, dev))
+    assert abs(aps["eval/0_meanAP"] - 1.0) < 1e-12
