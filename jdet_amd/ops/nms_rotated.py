@@ -16,9 +16,10 @@ __all__ = ["nms_rotated", "ml_nms_rotated", "multiclass_nms_rotated", "nms_rotat
 REFERENCE_RULE = "cpu"
 
 
-def nms_rotated_keep_mask(dets, order, iou_threshold):
+def nms_rotated_keep_mask(dets, order, iou_threshold, rule=None):
     """dets (n,5|6) fp32, order (n,) visiting order (descending score; for 6-column dets any order that is
-    descending in score inside each label) -> bool keep mask over original indices.  Device-only, fixed shapes."""
+    descending in score inside each label) -> bool keep mask over original indices.  Device-only, fixed shapes.
+    `rule`: "cpu" (suppress at iou >= thr) | "cuda" (iou > thr); None = the module-level REFERENCE_RULE."""
     L.need_device(dets, order)
     d = L.f32c(dets)
     n, bl = d.shape
@@ -27,7 +28,7 @@ def nms_rotated_keep_mask(dets, order, iou_threshold):
     ws_bytes = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=d.device)
     L.check(L.lib().jdet_nms_rotated(L.ptr(d), n, bl, L.ptr(o), float(iou_threshold),
-                                     1 if REFERENCE_RULE == "cpu" else 0, L.REFERENCE_SORT,
+                                     1 if (rule or REFERENCE_RULE) == "cpu" else 0, L.REFERENCE_SORT,
                                      L.ptr(keep), L.ptr(ws), ws_bytes, L.stream_ptr(d)), "jdet_nms_rotated")
     return keep.bool()
 

@@ -331,3 +331,87 @@ def test_voc_eval_dota_matches_the_per_detection_loop():
     assert abs(aps["eval/1_a_AP"] - 1.0) < 1e-12 and abs(aps["eval/2_b_AP"] - 1.0) < 1e-12 and aps["eval/3_c_AP"] == 0
     assert abs(aps["eval/0_meanAP"] - 2 / 3) < 1e-12
     assert evaluate_dota([], classes, _oracle_iou_matrix)["eval/0_meanAP"] == 0
+
+
+# ---- merging tile detections (devkits/result_merge.py) ----------------------------------------------------------------
+def _oracle_group_nms(polys, scores, groups, thresh):
+    """per-group greedy NMS with the C++ oracle (cmp_ge=0: iou > thresh suppresses)"""
+    from jdet_amd.data.np_boxes import poly_to_rotated_box_np
+    from oracle import oracle as O
+    keep = np.zeros(len(polys), bool)
+    for g in np.unique(groups):
+        idx = np.nonzero(groups == g)[0]
+        boxes = poly_to_rotated_box_np(polys[idx])
+        order = np.argsort(-np.asarray(scores)[idx], kind="stable").astype(np.int32)
+        keep[idx] = O.nms_rotated_keep(boxes, order, thresh, cmp_ge=0).astype(bool)
+    return keep
+
+
+def _greedy_poly_nms(dets, thresh):
+    """restatement of py_cpu_nms_poly_fast (L69-129) with the oracle as the polygon IoU"""
+    x1, y1 = dets[:, 0:8:2].min(1), dets[:, 1:8:2].min(1)
+    x2, y2 = dets[:, 0:8:2].max(1), dets[:, 1:8:2].max(1)
+    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
+    order = dets[:, 8].argsort()[::-1]
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(i)
+        w = np.maximum(0.0, np.minimum(x2[i], x2[order[1:]]) - np.maximum(x1[i], x1[order[1:]]))
+        h = np.maximum(0.0, np.minimum(y2[i], y2[order[1:]]) - np.maximum(y1[i], y1[order[1:]]))
+        ovr = w * h / (areas[i] + areas[order[1:]] - w * h)
+        for j in np.where(ovr > 0)[0]:
+            ovr[j] = _oracle_iou_matrix(dets[i:i + 1, :8].astype(np.float32),
+                                        dets[order[j + 1]:order[j + 1] + 1, :8].astype(np.float32))[0, 0]
+        order = order[np.where(ovr <= thresh)[0] + 1]
+    return keep
+
+
+def test_merge_tile_results(tmp_path):
+    from jdet_amd.data.np_boxes import rotated_box_to_poly_np
+    from jdet_amd.data.result_merge import mergebypoly, parse_tile_name
+    assert parse_tile_name("P0001__1__824___0") == ("P0001", 824, 0, 1.0)
+    assert parse_tile_name("P0706__0.5__1648___2472") == ("P0706", 1648, 2472, 0.5)
+    rng = np.random.default_rng(3)
+    src, dst = tmp_path / "raw", tmp_path / "merged"
+    os.makedirs(src)
+    expected = {}
+    for cls in ("plane", "harbor"):
+        rows, full = [], {}
+        for img in ("P0001", "P0002"):
+            objs = I_clustered(rng, 40)
+            for (tx, ty) in ((0, 0), (824, 0), (0, 824)):
+                for rate in (1.0, 0.5):
+                    # every object is reported by every tile that "sees" it, with a little jitter
+                    b = objs + rng.normal(0, 0.5, objs.shape).astype(np.float32) * np.array([1, 1, 1, 1, 0.01], np.float32)
+                    polys = rotated_box_to_poly_np(b).astype(np.float64)
+                    tile = polys * rate
+                    tile[:, 0::2] -= tx
+                    tile[:, 1::2] -= ty
+                    sc = rng.uniform(0.1, 1.0, len(b))
+                    name = "%s__%g__%d___%d" % (img, rate, tx, ty)
+                    for p, s_ in zip(tile, sc):
+                        rows.append(name + " " + "%.6f" % s_ + " " + " ".join("%.4f" % v for v in p))
+                        back = p.copy()
+                        back[0::2] = (np.array([float("%.4f" % v) for v in p[0::2]]) + tx) / rate
+                        back[1::2] = (np.array([float("%.4f" % v) for v in p[1::2]]) + ty) / rate
+                        full.setdefault(img, []).append(np.concatenate([back, [float("%.6f" % s_)]]))
+        with open(src / (cls + ".txt"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        expected[cls] = full
+    kept = mergebypoly(str(src), str(dst), threshold_type=1, group_nms=_oracle_group_nms)
+    from jdet_amd.data.result_merge import NMS_THRESHOLD_BY_CLASS
+    for cls, full in expected.items():
+        out = [l.split() for l in open(dst / (cls + ".txt")).read().strip().split("\n")]
+        assert len(out) == kept[cls] < sum(len(v) for v in full.values())
+        for img, dets in full.items():
+            dets = np.stack(dets)
+            ref_keep = _greedy_poly_nms(dets, NMS_THRESHOLD_BY_CLASS[cls])
+            got = np.array([[float(v) for v in r[1:]] for r in out if r[0] == img])
+            np.testing.assert_allclose(got[:, 0], dets[ref_keep, 8], rtol=0, atol=1e-12)    # same boxes, same order
+            np.testing.assert_allclose(got[:, 1:], dets[ref_keep, :8], rtol=0, atol=1e-9)
+
+
+def I_clustered(rng, n):
+    from tests import inputs as I
+    return I.clustered_obbs(rng, n, 8, 1600.0)

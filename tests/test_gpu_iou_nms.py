@@ -189,3 +189,24 @@ def test_dota_evaluation_iou_runs_on_the_device(dev):
                         dict(scale_factor=1.0, polys=gp, labels=labels, polys_ignore=np.zeros((0, 8)))))
     aps = evaluate_dota(results, ["a", "b", "c"], lambda x, y: device_iou_matrix(x, y, dev))
     assert abs(aps["eval/0_meanAP"] - 1.0) < 1e-12
+
+
+def test_merge_nms_groups_on_the_device(dev):
+    """result merging: all images of a class in ONE launch (image index as label, iou > thr suppresses) == greedy NMS
+    image by image with the oracle"""
+    from jdet_amd.data.np_boxes import poly_to_rotated_box_np, rotated_box_to_poly_np
+    from jdet_amd.data.result_merge import device_group_nms
+    rng = np.random.default_rng(31)
+    n = 1500
+    polys = rotated_box_to_poly_np(I.clustered_obbs(rng, n, 40, 2048.0))
+    scores = (rng.uniform(0, 1, n) + np.arange(n) * 1e-7).astype(np.float32)
+    groups = rng.integers(0, 7, n)
+    for thr in (0.1, 0.3):
+        got = device_group_nms(polys, scores, groups, thr, dev)
+        ref = np.zeros(n, bool)
+        for g in np.unique(groups):
+            idx = np.nonzero(groups == g)[0]
+            order = np.argsort(-scores[idx], kind="stable").astype(np.int32)
+            ref[idx] = O.nms_rotated_keep(poly_to_rotated_box_np(polys[idx]), order, thr, cmp_ge=0).astype(bool)
+        np.testing.assert_array_equal(got, ref)
+        assert 0 < got.sum() < n
