@@ -87,9 +87,25 @@ def make_step(workload, d):
     if workload == "roi_align_rotated":
         feat, rois = d["feat"], d["rois"]
         R = rois.shape[0]
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        fp, rp = feat.data_ptr(), rois.data_ptr()
+        path = os.environ.get("JDET_ROI_FWD_PATH", "tile")
+        if path in ("tile", "tile_exact"):
+            # default product path: tile-stationary kernel, channels-last result (logical shape (R,256,7,7))
+            out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
+            op = out.data_ptr()
+            exact = 1 if path == "tile_exact" else 0
+
+            def step():
+                L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, exact, op,
+                                                      L.stream_ptr(feat)), "fwd_cl")
+            d["out"] = out
+            return (step, nbytes / 1e9, "GB", nbytes,
+                    "roi_align_tile_fwd_kernel<ROTATED,%s> (one launch, channels-last output)"
+                    % ("reference order" if exact else "fma"), "f32")
         out = torch.empty((R, 256, 7, 7), device=feat.device)
         obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)
-        fp, rp, op = feat.data_ptr(), rois.data_ptr(), out.data_ptr()
+        op = out.data_ptr()
         o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
         use_order = os.environ.get("JDET_BENCH_NO_ORDER", "0") != "1"
         lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
@@ -102,12 +118,14 @@ def make_step(workload, d):
             L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
                                                o0 if use_order else None, op, st), "fwd")
         d["out"] = out
-        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         return step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves>", "f32"
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]
         gin = torch.empty_like(feat)
+        cl = os.environ.get("JDET_BENCH_BWD_LAYOUT", "cl") == "cl"   # grad_out channels-last (what the tile forward pairs with)
+        if cl:
+            grad = grad.contiguous(memory_format=torch.channels_last)
         gp, rp, ip = grad.data_ptr(), rois.data_ptr(), gin.data_ptr()
         use_ws = os.environ.get("JDET_BENCH_BWD_ATOMIC", "0") != "1"
         wsb = lib.jdet_roi_align_backward_workspace(0, R, 1, 256, 256, 256, 7, 7, 2) if use_ws else 0
@@ -115,10 +133,14 @@ def make_step(workload, d):
         wp = ws.data_ptr() if wsb else None
 
         def step():
-            L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, None, ip,
-                                                wp, wsb, L.stream_ptr(feat)), "bwd")
+            if cl and wsb:
+                L.check(lib.jdet_roi_align_backward_cl(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, ip, wp, wsb,
+                                                       L.stream_ptr(feat)), "bwd_cl")
+            else:
+                L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, None, ip,
+                                                    wp, wsb, L.stream_ptr(feat)), "bwd")
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
-        return step, nbytes / 1e9, "GB", nbytes, "roi_align backward (taps+scan+fill+transpose+gather | atomic)", "f32"
+        return step, nbytes / 1e9, "GB", nbytes, "roi_align backward (geom+taps+scan+fill%s+gather | atomic)" % ("" if cl else "+transpose"), "f32"
     if workload == "box_iou_rotated":
         from jdet_amd.ops import box_iou_rotated
         b1, b2 = d["b1"], d["b2"]

@@ -73,6 +73,22 @@ int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, in
                            int sample_num, int n_orient, const int32_t* order, float* out,
                            jdet_stream_t stream);
 
+/* Tile-stationary RoIAlign forward, channels-last in and out (csrc/roi_align_tile.hip).  Same jt.code sites
+ * as jdet_roi_align_forward (roi_align_rotated.py:L265-283, roi_align_rotated_v1.py:L308-326,
+ * roi_align.py:L217-237); same values.
+ *   out_cl : (R, PH, PW, C) -- the reference's (R, C, PH, PW) tensor stored channels-last: the 32-channel
+ *            chunk of a bin is one 128-byte store and a consumer reads it through channels-last strides.
+ *   exact_order 1: the reference's operation order (bit-identical to the CPU oracle); 0: same weights, fma.
+ * The map tile (+ halo) is staged in LDS once per workgroup and every tap of every bin whose centre lies in
+ * the tile is served from LDS; each map byte leaves HBM once and no scheduling pre-pass is needed.
+ * Supported (jdet_roi_align_forward_cl_supported() == 1): rotated v0 / v1 and horizontal v0 / v1, C % 4 == 0,
+ * sample_num 1 or 2, PH*PW <= 64, H*W*C*4 < 2 GiB per image; otherwise JDET_E_UNSUPPORTED (use
+ * jdet_roi_align_forward).  RoIs with a negative batch index are skipped (their rows stay untouched). */
+int jdet_roi_align_forward_cl_supported(int variant, int C, int H, int W, int PH, int PW, int sample_num);
+int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                              const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                              int exact_order, float* out_cl, jdet_stream_t stream);
+
 /* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
  *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);
  *                equals the reference up to fp32 re-association of the bilinear weights.
@@ -102,6 +118,13 @@ int jdet_roi_align_backward(int variant, const float* grad_out, const float* roi
                             int C, int H, int W, int PH, int PW, float spatial_scale,
                             int sample_num, int n_orient, const int32_t* order, float* grad_in_nhwc,
                             void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
+/* Same as jdet_roi_align_backward for a channels-last gradient grad_out_cl (R, PH, PW, C): the sorted gather
+ * reads it directly (no (R,C,bin) -> (R,bin,C) transpose pass).  Needs the workspace of
+ * jdet_roi_align_backward_workspace(); returns JDET_E_UNSUPPORTED where that query returns 0. */
+int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N, int C,
+                               int H, int W, int PH, int PW, float spatial_scale, int sample_num,
+                               float* grad_in_nhwc, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
 /* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and
  * box_iou_rotated_v1.py:L512 (the python-side "too small" zeroing L515-523 stays in the

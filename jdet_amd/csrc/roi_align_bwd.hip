@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void bwd_transpose_kernel(const float* __restr
 
 template <int VARIANT>
 int run_gather(const float* grad_out, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,
-               float scale, int sample_num, float* grad_in, void* ws, hipStream_t st) {
+               float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, hipStream_t st) {
   const int nbins = PH * PW, spb = sample_num * sample_num;
   const long npix = (long)N * H * W, ntaps = (long)R * nbins * spb * 4;
   CsrWs w = csr_carve(ws, npix, ntaps);
@@ -134,6 +134,8 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
   const long nsamp = (long)R * nbins * spb;
   hipLaunchKernelGGL((bwd_taps_kernel<VARIANT>), dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, geoms, R,
                      H, W, PH, PW, sample_num, w.tap_key, w.tap_pos, w.tap_w, w.counts);
+  if (grad_out_cl)   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
+    return csr_finish_and_gather(w, npix, ntaps, spb * 4, grad_out, C, grad_in, st);
   dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
   hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
   return csr_finish_and_gather(w, npix, ntaps, spb * 4, gT, C, grad_in, st);
@@ -161,6 +163,21 @@ JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int
          align256(sizeof(RoiGeom) * (size_t)R);
 }
 
+static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,
+                           int PH, int PW, float spatial_scale, int sample_num, float* grad_in, void* workspace,
+                           bool grad_out_cl, hipStream_t st) {
+  switch (variant) {
+    case JDET_ROI_ROTATED:
+      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+    case JDET_ROI_ROTATED_V1:
+      return run_gather<JDET_ROI_ROTATED_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+    case JDET_ROI_HBB_V0:
+      return run_gather<JDET_ROI_HBB_V0>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+    default:
+      return run_gather<JDET_ROI_HBB_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+  }
+}
+
 JDET_API int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,
                                      int C, int H, int W, int PH, int PW, float spatial_scale,
                                      int sample_num, int n_orient, const int32_t* order, float* grad_in,
@@ -174,14 +191,20 @@ JDET_API int jdet_roi_align_backward(int variant, const float* grad_out, const f
   if (variant < 0 || variant > 4 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || !grad_out ||
       !rois || !grad_in)
     return JDET_E_BADARG;
-  switch (variant) {
-    case JDET_ROI_ROTATED:
-      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, st);
-    case JDET_ROI_ROTATED_V1:
-      return run_gather<JDET_ROI_ROTATED_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, st);
-    case JDET_ROI_HBB_V0:
-      return run_gather<JDET_ROI_HBB_V0>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, st);
-    default:
-      return run_gather<JDET_ROI_HBB_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, st);
-  }
+  return backward_gather(variant, grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
+                         workspace, false, st);
+}
+
+JDET_API int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N,
+                                        int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
+                                        float* grad_in, void* workspace, size_t workspace_bytes,
+                                        jdet_stream_t stream) {
+  if (variant < 0 || variant > 4 || N < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || R < 0)
+    return JDET_E_BADARG;
+  const size_t need = jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num);
+  if (need == 0) return JDET_E_UNSUPPORTED;   // RiRoIAlign, adaptive sampling, C % 4, R == 0: use the (R,C,PH,PW) entry
+  if (!workspace || workspace_bytes < need) return JDET_E_WORKSPACE;
+  if (!grad_out_cl || !rois || !grad_in) return JDET_E_BADARG;
+  return backward_gather(variant, grad_out_cl, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
+                         workspace, true, (hipStream_t)stream);
 }

@@ -91,19 +91,9 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float
   return g;
 }
 
-// One bilinear sample: 4 weights + 4 pixel offsets (y*W+x), valid flag.
-struct Sample {
-  float w1, w2, w3, w4;
-  int o1, o2, o3, o4;
-  int valid;
-};
-
+// RoI frame -> map coordinates (the three rotation / translation conventions of the dialects).
 template <int VARIANT>
-__device__ __forceinline__ Sample make_sample(const RoiGeom& g, int ph, int pw, int iy, int ix,
-                                              int H, int W) {
-  const float yy = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
-  const float xx = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
-  float x, y;
+__device__ __forceinline__ void roi_xform(const RoiGeom& g, float xx, float yy, float& x, float& y) {
   if (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) {
     x = xx;
     y = yy;
@@ -114,12 +104,28 @@ __device__ __forceinline__ Sample make_sample(const RoiGeom& g, int ph, int pw, 
     x = xx * g.cosT - yy * g.sinT + g.center_w;
     y = xx * g.sinT + yy * g.cosT + g.center_h;
   }
-  Sample s;
+}
+
+// Position part of one bilinear sample: the four corner coordinates and the lerp fractions.
+struct SamplePos {
+  int y_low, x_low, y_high, x_high;
+  float ly, lx;
+  int valid;
+};
+
+template <int VARIANT>
+__device__ __forceinline__ SamplePos sample_pos(const RoiGeom& g, int ph, int pw, int iy, int ix,
+                                                int H, int W) {
+  const float yy = g.start_h + ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+  const float xx = g.start_w + pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+  float x, y;
+  roi_xform<VARIANT>(g, xx, yy, x, y);
+  SamplePos p;
   if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
-    s.w1 = s.w2 = s.w3 = s.w4 = 0.f;
-    s.o1 = s.o2 = s.o3 = s.o4 = 0;
-    s.valid = 0;
-    return s;
+    p.y_low = p.x_low = p.y_high = p.x_high = 0;
+    p.ly = p.lx = 0.f;
+    p.valid = 0;
+    return p;
   }
   if (VARIANT == JDET_ROI_ROTATED_V1) {
     if (y < 0) y = 0;
@@ -141,18 +147,44 @@ __device__ __forceinline__ Sample make_sample(const RoiGeom& g, int ph, int pw, 
   } else {
     x_high = x_low + 1;
   }
-  const float ly = y - y_low;
-  const float lx = x - x_low;
-  const float hy = (float)(1. - (double)ly);  // reference: `1. - ly` in double
-  const float hx = (float)(1. - (double)lx);
+  p.y_low = y_low;
+  p.x_low = x_low;
+  p.y_high = y_high;
+  p.x_high = x_high;
+  p.ly = y - y_low;
+  p.lx = x - x_low;
+  p.valid = 1;
+  return p;
+}
+
+// One bilinear sample: 4 weights + 4 pixel offsets (y*W+x), valid flag.
+struct Sample {
+  float w1, w2, w3, w4;
+  int o1, o2, o3, o4;
+  int valid;
+};
+
+template <int VARIANT>
+__device__ __forceinline__ Sample make_sample(const RoiGeom& g, int ph, int pw, int iy, int ix,
+                                              int H, int W) {
+  const SamplePos p = sample_pos<VARIANT>(g, ph, pw, iy, ix, H, W);
+  Sample s;
+  if (!p.valid) {
+    s.w1 = s.w2 = s.w3 = s.w4 = 0.f;
+    s.o1 = s.o2 = s.o3 = s.o4 = 0;
+    s.valid = 0;
+    return s;
+  }
+  const float hy = (float)(1. - (double)p.ly);  // reference: `1. - ly` in double
+  const float hx = (float)(1. - (double)p.lx);
   s.w1 = hy * hx;
-  s.w2 = hy * lx;
-  s.w3 = ly * hx;
-  s.w4 = ly * lx;
-  s.o1 = y_low * W + x_low;
-  s.o2 = y_low * W + x_high;
-  s.o3 = y_high * W + x_low;
-  s.o4 = y_high * W + x_high;
+  s.w2 = hy * p.lx;
+  s.w3 = p.ly * hx;
+  s.w4 = p.ly * p.lx;
+  s.o1 = p.y_low * W + p.x_low;
+  s.o2 = p.y_low * W + p.x_high;
+  s.o3 = p.y_high * W + p.x_low;
+  s.o4 = p.y_high * W + p.x_high;
   s.valid = 1;
   return s;
 }

@@ -32,6 +32,50 @@ def to_nhwc(x):
 # below this many RoIs the map traffic is too small for the XCD schedule to matter
 SPATIAL_ORDER_MIN_ROIS = 64
 
+# Forward path (process-wide; tests and bench switch it):
+#   "tile"       tile-stationary kernel (csrc/roi_align_tile.hip), fma arithmetic, channels-last output  [default]
+#   "tile_exact" the same kernel in the reference's operation order (bit-identical to the CPU oracle)
+#   "roi"        RoI-stationary kernels (csrc/roi_align.hip), (R,C,PH,PW)-contiguous output; their arithmetic
+#                mode is jdet_set_roi_forward_mode (0 merged taps, 1 reference order)
+# Dialects / shapes the tile kernel does not take (RiRoIAlign, adaptive sampling, C % 4 != 0, > 64 bins) always use
+# "roi".  Either way the result is the same logical (R, C, PH, PW) tensor; only its strides differ.
+_FORWARD_PATH = ["tile"]
+
+
+def set_forward_path(name):
+    assert name in ("tile", "tile_exact", "roi")
+    prev = _FORWARD_PATH[0]
+    _FORWARD_PATH[0] = name
+    return prev
+
+
+def _tile_ok(variant, C, H, W, PH, PW, sample_num):
+    return _FORWARD_PATH[0] != "roi" and bool(
+        L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
+
+
+def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order):
+    """grad w.r.t. one feature map (NHWC memory).  A channels-last grad_out (what a channels-last forward result
+    gets back from a layout-preserving consumer) feeds the sorted gather directly: no transpose pass."""
+    N, C, H, W = shape
+    R = rois_c.shape[0]
+    grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g_out.device,
+                          memory_format=torch.channels_last)
+    if g_out.dtype != torch.float32:
+        g_out = g_out.float()
+    wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=g_out.device) if wsb else None
+    if wsb and R and g_out.is_contiguous(memory_format=torch.channels_last) and not g_out.is_contiguous():
+        L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
+                                                   scale, sample_num, L.ptr(grad_in), L.ptr(ws), wsb,
+                                                   L.stream_ptr(g_out)), "jdet_roi_align_backward_cl")
+        return grad_in
+    g = g_out.contiguous()
+    L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
+                                            scale, sample_num, n_orient, L.ptr(order), L.ptr(grad_in),
+                                            L.ptr(ws), wsb, L.stream_ptr(g)), "jdet_roi_align_backward")
+    return grad_in
+
 
 def spatial_order(rois_c, spatial_scale, N, H, W):
     """XCD-aware processing order (jdet_roi_spatial_order); a pure performance hint."""
@@ -57,12 +101,21 @@ class RoIAlignFunction(torch.autograd.Function):
         rois_c = L.f32c(rois)
         N, C, H, W = feat.shape
         R = rois_c.shape[0]
-        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
-        order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
-        L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                               float(spatial_scale), int(sample_num), int(n_orient),
-                                               L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
-                "jdet_roi_align_forward")
+        if _tile_ok(variant, C, H, W, PH, PW, sample_num):
+            out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
+                              memory_format=torch.channels_last)
+            order = None
+            L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                                      float(spatial_scale), int(sample_num),
+                                                      1 if _FORWARD_PATH[0] == "tile_exact" else 0, L.ptr(out),
+                                                      L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+        else:
+            out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
+            order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
+            L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                                   float(spatial_scale), int(sample_num), int(n_orient),
+                                                   L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
+                    "jdet_roi_align_forward")
         ctx.save_for_backward(rois_c, order)
         ctx.cfg = (variant, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
         return out
@@ -70,17 +123,8 @@ class RoIAlignFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         rois_c, order = ctx.saved_tensors
-        variant, (N, C, H, W), PH, PW, scale, sample_num, n_orient = ctx.cfg
-        g = L.f32c(grad_output)
-        R = rois_c.shape[0]
-        grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
-                              memory_format=torch.channels_last)
-        wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device) if wsb else None
-        L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
-                                                scale, sample_num, n_orient, L.ptr(order), L.ptr(grad_in),
-                                                L.ptr(ws), wsb, L.stream_ptr(g)),
-                "jdet_roi_align_backward")
+        variant, shape, PH, PW, scale, sample_num, n_orient = ctx.cfg
+        grad_in = _backward_into(variant, grad_output, rois_c, shape, PH, PW, scale, sample_num, n_orient, order)
         return grad_in, None, None, None, None, None, None
 
 
@@ -102,7 +146,10 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
         rois_c = L.f32c(rois)
         R = rois_c.shape[0]
         C = feats[0].shape[1]
-        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device)
+        tile = all(_tile_ok(variant, C, f.shape[2], f.shape[3], PH, PW, sample_num) for f in feats)
+        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device,
+                          memory_format=torch.channels_last if tile else torch.contiguous_format)
+        exact = 1 if _FORWARD_PATH[0] == "tile_exact" else 0
         lvl = target_lvls.to(rois_c.device)
         masked, shapes = [], []
         for i, f in enumerate(feats):
@@ -111,7 +158,11 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             assert Ci == C
             r_i = rois_c.clone()
             r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
-            if R:
+            if R and tile:
+                L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
+                                                          float(scales[i]), int(sample_num), exact, L.ptr(out),
+                                                          L.stream_ptr(fm)), "jdet_roi_align_forward_cl")
+            elif R:
                 L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                        float(scales[i]), int(sample_num), int(n_orient), None,
                                                        L.ptr(out), L.stream_ptr(fm)), "jdet_roi_align_forward")
@@ -125,21 +176,13 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         masked = ctx.saved_tensors
         variant, PH, PW, scales, sample_num, n_orient, shapes = ctx.cfg
-        g = L.f32c(grad_output)
         grads = []
-        for i, (r_i, (N, C, H, W)) in enumerate(zip(masked, shapes)):
+        for i, (r_i, shape) in enumerate(zip(masked, shapes)):
             if not ctx.needs_input_grad[3 + i]:
                 grads.append(None)
                 continue
-            R = r_i.shape[0]
-            grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device,
-                                  memory_format=torch.channels_last)
-            wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device) if wsb else None
-            L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(r_i), R, N, C, H, W, PH, PW,
-                                                    float(scales[i]), sample_num, n_orient, None, L.ptr(grad_in),
-                                                    L.ptr(ws), wsb, L.stream_ptr(g)), "jdet_roi_align_backward")
-            grads.append(grad_in)
+            grads.append(_backward_into(variant, grad_output, r_i, shape, PH, PW, float(scales[i]), sample_num,
+                                        n_orient, None))
         return (None, None, None, *grads)
 
 
