@@ -95,13 +95,16 @@ def make_step(workload, d):
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
             exact = 1 if path == "tile_exact" else 0
+            wsb = lib.jdet_roi_align_forward_cl_workspace(1, 256, 256, R, 7, 7)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+            wp = ws.data_ptr()
 
             def step():
-                L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, exact, op,
+                L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, exact, op, wp, wsb,
                                                       L.stream_ptr(feat)), "fwd_cl")
             d["out"] = out
             return (step, nbytes / 1e9, "GB", nbytes,
-                    "roi_align_tile_fwd_kernel<ROTATED,%s> (one launch, channels-last output)"
+                    "roi_tile_plan_kernel + roi_align_tile_pool_kernel<ROTATED,%s> (channels-last output)"
                     % ("reference order" if exact else "fma"), "f32")
         out = torch.empty((R, 256, 7, 7), device=feat.device)
         obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)

@@ -79,15 +79,24 @@ int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, in
  *   out_cl : (R, PH, PW, C) -- the reference's (R, C, PH, PW) tensor stored channels-last: the 32-channel
  *            chunk of a bin is one 128-byte store and a consumer reads it through channels-last strides.
  *   exact_order 1: the reference's operation order (bit-identical to the CPU oracle); 0: same weights, fma.
- * The map tile (+ halo) is staged in LDS once per workgroup and every tap of every bin whose centre lies in
- * the tile is served from LDS; each map byte leaves HBM once and no scheduling pre-pass is needed.
+ *   workspace : jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW) bytes of scratch (the plan: per map
+ *            tile the list of bins whose centre lies in it, with their sample tables).
+ * Two launches (+ an 8-byte zero fill): a plan kernel (no map traffic) and a pool kernel that stages a map tile
+ * (+ halo) of one 32-channel chunk in LDS and serves every tap of the tile's bins from LDS; each map byte leaves
+ * HBM once and no RoI ordering pass is needed.
  * Supported (jdet_roi_align_forward_cl_supported() == 1): rotated v0 / v1 and horizontal v0 / v1, C % 4 == 0,
  * sample_num 1 or 2, PH*PW <= 64, H*W*C*4 < 2 GiB per image; otherwise JDET_E_UNSUPPORTED (use
  * jdet_roi_align_forward).  RoIs with a negative batch index are skipped (their rows stay untouched). */
 int jdet_roi_align_forward_cl_supported(int variant, int C, int H, int W, int PH, int PW, int sample_num);
+size_t jdet_roi_align_forward_cl_workspace(int N, int H, int W, int R, int PH, int PW);
 int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W,
                               const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
-                              int exact_order, float* out_cl, jdet_stream_t stream);
+                              int exact_order, float* out_cl, void* workspace, size_t workspace_bytes,
+                              jdet_stream_t stream);
+
+/* Profiling hook of the tile kernel (scripts/tile_timeline.py): buf = device array of 32 uint64 per workgroup
+ * (s_memtime stamps at the phase boundaries, hardware id in slot 31), or NULL to switch it off. */
+int jdet_debug_roi_tile_timeline(void* buf);
 
 /* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
  *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);

@@ -54,6 +54,19 @@ def _tile_ok(variant, C, H, W, PH, PW, sample_num):
         L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
 
 
+def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
+    """tile-stationary forward into the channels-last `out` (plan + pool launches, csrc/roi_align_tile.hip)"""
+    N, C, H, W = feat.shape
+    R = rois_c.shape[0]
+    if R == 0 or N == 0:
+        return
+    wsb = L.lib().jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+    L.check(L.lib().jdet_roi_align_forward_cl(int(variant), L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                              float(scale), int(sample_num), int(exact), L.ptr(out), L.ptr(ws), wsb,
+                                              L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+
+
 def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order):
     """grad w.r.t. one feature map (NHWC memory).  A channels-last grad_out (what a channels-last forward result
     gets back from a layout-preserving consumer) feeds the sorted gather directly: no transpose pass."""
@@ -105,10 +118,8 @@ class RoIAlignFunction(torch.autograd.Function):
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
                               memory_format=torch.channels_last)
             order = None
-            L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                                      float(spatial_scale), int(sample_num),
-                                                      1 if _FORWARD_PATH[0] == "tile_exact" else 0, L.ptr(out),
-                                                      L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+            _forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num,
+                        1 if _FORWARD_PATH[0] == "tile_exact" else 0)
         else:
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
@@ -159,9 +170,7 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             r_i = rois_c.clone()
             r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
             if R and tile:
-                L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
-                                                          float(scales[i]), int(sample_num), exact, L.ptr(out),
-                                                          L.stream_ptr(fm)), "jdet_roi_align_forward_cl")
+                _forward_cl(variant, fm, r_i, out, PH, PW, scales[i], sample_num, exact)
             elif R:
                 L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                        float(scales[i]), int(sample_num), int(n_orient), None,
