@@ -96,7 +96,7 @@ def make_step(workload, d):
             op = out.data_ptr()
             exact = 1 if path == "tile_exact" else 0
             wsb = lib.jdet_roi_align_forward_cl_workspace(1, 256, 256, R, 7, 7)
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+            ws = torch.zeros((wsb,), dtype=torch.uint8, device=feat.device)   # cursor (first 256 B) zero on entry
             wp = ws.data_ptr()
 
             def step():

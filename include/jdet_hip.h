@@ -80,8 +80,10 @@ int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, in
  *            chunk of a bin is one 128-byte store and a consumer reads it through channels-last strides.
  *   exact_order 1: the reference's operation order (bit-identical to the CPU oracle); 0: same weights, fma.
  *   workspace : jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW) bytes of scratch (the plan: per map
- *            tile the list of bins whose centre lies in it, with their sample tables).
- * Two launches (+ an 8-byte zero fill): a plan kernel (no map traffic) and a pool kernel that stages a map tile
+ *            tile the list of bins whose centre lies in it, with their sample tables).  Its FIRST 256 BYTES
+ *            MUST BE ZERO ON ENTRY (the plan's allocation cursor) and are zero again when the call's work has
+ *            run: zero-fill a buffer once, then keep re-using it on one stream.
+ * Two launches: a plan kernel (no map traffic) and a pool kernel that stages a map tile
  * (+ halo) of one 32-channel chunk in LDS and serves every tap of the tile's bins from LDS; each map byte leaves
  * HBM once and no RoI ordering pass is needed.
  * Supported (jdet_roi_align_forward_cl_supported() == 1): rotated v0 / v1 and horizontal v0 / v1, C % 4 == 0,

@@ -54,6 +54,21 @@ def _tile_ok(variant, C, H, W, PH, PW, sample_num):
         L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
 
 
+_PLAN_WS = {}
+
+
+def _plan_workspace(dev, nbytes):
+    """Scratch of the tile path.  Contract of jdet_roi_align_forward_cl: the first 256 bytes (the plan's cursor) are
+    zero on entry and are handed back zeroed, so the buffer is zero-filled once and then re-used -- one buffer per
+    (device, stream): launches on one stream are ordered, two streams must not share a plan."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _PLAN_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros((max(nbytes, 1 << 20),), dtype=torch.uint8, device=dev)
+        _PLAN_WS[key] = ws
+    return ws
+
+
 def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
     """tile-stationary forward into the channels-last `out` (plan + pool launches, csrc/roi_align_tile.hip)"""
     N, C, H, W = feat.shape
@@ -61,10 +76,10 @@ def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
     if R == 0 or N == 0:
         return
     wsb = L.lib().jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+    ws = _plan_workspace(feat.device, wsb)
     L.check(L.lib().jdet_roi_align_forward_cl(int(variant), L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                              float(scale), int(sample_num), int(exact), L.ptr(out), L.ptr(ws), wsb,
-                                              L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+                                              float(scale), int(sample_num), int(exact), L.ptr(out), L.ptr(ws),
+                                              ws.numel(), L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
 
 
 def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order):

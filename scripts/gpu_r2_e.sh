@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out/r2_e
+OUT=gpurun_out/r2_f
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_closed_form.py -x -q -m gpu > $OUT/pytest_roi.log 2>&1

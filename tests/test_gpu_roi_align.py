@@ -160,10 +160,11 @@ def test_tile_path_many_rois_and_big_rois(dev):
         r2 = r.clone()
         r2[5, 0] = -1.0
         wsb = L.lib().jdet_roi_align_forward_cl_workspace(N, H, W, 730, 7, 7)
-        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        ws = torch.zeros((wsb,), dtype=torch.uint8, device=dev)   # plan cursor: zero on entry, zero on return
         L.check(L.lib().jdet_roi_align_forward_cl(0, x.data_ptr(), N, C, H, W, r2.data_ptr(), 730, 7, 7, scale, 2, 1,
                                                   out.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(x)), "fwd_cl")
         o = out.cpu().numpy()
+        assert int(ws[:256].to(torch.int32).abs().sum().item()) == 0    # the cursor came back zeroed
         assert (o[5] == 7.0).all()
         np.testing.assert_array_equal(np.delete(o, 5, 0), np.delete(y, 5, 0))
     finally:
