@@ -89,7 +89,7 @@ def make_step(workload, d):
         R = rois.shape[0]
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         fp, rp = feat.data_ptr(), rois.data_ptr()
-        path = os.environ.get("JDET_ROI_FWD_PATH", "tile")
+        path = os.environ.get("JDET_ROI_FWD_PATH", "roi_cl")
         if path in ("tile", "tile_exact"):
             # default product path: tile-stationary kernel, channels-last result (logical shape (R,256,7,7))
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
@@ -106,7 +106,9 @@ def make_step(workload, d):
             return (step, nbytes / 1e9, "GB", nbytes,
                     "roi_tile_plan_kernel + roi_align_tile_pool_kernel<ROTATED,%s> (channels-last output)"
                     % ("reference order" if exact else "fma"), "f32")
-        out = torch.empty((R, 256, 7, 7), device=feat.device)
+        cl = path == "roi_cl"   # default product path: RoI-stationary kernels, channels-last result
+        out = torch.empty((R, 256, 7, 7), device=feat.device,
+                          memory_format=torch.channels_last if cl else torch.contiguous_format)
         obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)
         op = out.data_ptr()
         o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
@@ -118,10 +120,15 @@ def make_step(workload, d):
             st = L.stream_ptr(feat)
             if use_order:
                 L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
-            L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
-                                               o0 if use_order else None, op, st), "fwd")
+            if cl:
+                L.check(lib.jdet_roi_align_forward_cl_roi(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2,
+                                                          o0 if use_order else None, op, st), "fwd_cl_roi")
+            else:
+                L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
+                                                   o0 if use_order else None, op, st), "fwd")
         d["out"] = out
-        return step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves>", "f32"
+        return (step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,%s>"
+                % ("channels-last out" if cl else "(R,C,7,7) out"), "f32")
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]
@@ -344,11 +351,61 @@ def roofline_obj(workload, nbytes, dev_ms, kname):
             "traffic": traffic, "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
 
 
+def launch_command(argv, gpus, port=None):
+    """`python bench.py --gpus N ...` started by hand (no WORLD_SIZE in the environment): the command that runs the
+    same arguments as N ranks of one node, one rank per GPU, rendezvous on 127.0.0.1."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def selftest_cpu(a, world, rank):
+    """launcher / timing plumbing on CPU ranks (gloo): NOT a benchmark; used by tests/test_abi.py to drive
+    `bench.py --gpus 2` end to end without a GPU"""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+    x = torch.randn(64, 64)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        x = torch.tanh(x @ x.t() / 64)
+    t = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+        n = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        n = 1
+    if rank == 0:
+        print(json.dumps({"metric": "selftest steps/s (CPU, launcher plumbing only)", "value": a.steps * n / t,
+                          "unit": "step/s", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": 1e3 * t / a.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "selftest_cpu", "parallelism": "replicas x%d" % n}}))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become N ranks (one per GPU) of one node
+        import subprocess
+        raise SystemExit(subprocess.call(launch_command(sys.argv[1:], a.gpus)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: reporting the launched world size" % (a.gpus, world),
+              file=sys.stderr)
+    if a.workload == "selftest_cpu":
+        return selftest_cpu(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback in the product path)")
     torch.cuda.set_device(local)

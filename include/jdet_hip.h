@@ -96,6 +96,15 @@ int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C,
                               int exact_order, float* out_cl, void* workspace, size_t workspace_bytes,
                               jdet_stream_t stream);
 
+/* RoI-stationary forward (the kernels of jdet_roi_align_forward) with the channels-last result layout
+ * out_cl (R, PH, PW, C): each wave stores a bin's channel chunk straight from registers (1 KiB contiguous,
+ * non-temporal) instead of transposing the RoI's block through LDS.  Rotated v0 / v1 and horizontal v0 / v1,
+ * C % 4 == 0, any sample_num (<= 0 adaptive); otherwise JDET_E_UNSUPPORTED.  `order` as in
+ * jdet_roi_align_forward. */
+int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                                  const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                                  const int32_t* order, float* out_cl, jdet_stream_t stream);
+
 /* Profiling hook of the tile kernel (scripts/tile_timeline.py): buf = device array of 32 uint64 per workgroup
  * (s_memtime stamps at the phase boundaries, hardware id in slot 31), or NULL to switch it off. */
 int jdet_debug_roi_tile_timeline(void* buf);

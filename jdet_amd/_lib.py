@@ -23,6 +23,7 @@ SIGNATURES = {
     "jdet_nhwc_to_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
     "jdet_roi_align_forward_cl_supported": (_i, [_i] * 7),
+    "jdet_roi_align_forward_cl_roi": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _p, _p]),
     "jdet_roi_align_forward_cl_workspace": (_sz, [_i] * 6),
     "jdet_roi_align_forward_cl": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_cl": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p, _p, _sz, _p]),
@@ -108,6 +109,10 @@ def check(status, what):
 
 
 def stream_ptr(t=None):
+    """launch stream of the op whose tensor is `t`.  The C entry points launch on the CURRENT HIP device, so the
+    tensor's device is made current here (every launch site fetches its stream through this function)."""
+    if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+        torch.cuda.set_device(t.device)
     return torch.cuda.current_stream(t.device if t is not None else None).cuda_stream
 
 

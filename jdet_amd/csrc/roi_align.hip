@@ -77,10 +77,12 @@ __device__ __forceinline__ RoiGeom vec_prologue(const float* feat, const float* 
 
 // Direct path for one (RoI, <=256-channel chunk): every tap is a buffer_load_dwordx4 whose pixel
 // byte offset is an SGPR; results go to s_out[channel][bin].  NW waves split the bins.
-template <int VARIANT, int NW, int SG, int ABL>
+// OUT_CL: results go straight from registers to the channels-last output row (r, bin, c0 + 4*lane .. +3) -- one
+// contiguous 1 KiB non-temporal store per (wave, bin), no LDS staging; otherwise to s_out[channel][bin].
+template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false>
 __device__ __forceinline__ void direct_chunk(const RoiGeom& g, const __amdgpu_buffer_rsrc_t rsrc, int c0,
                                              int cc, int C, int H, int W, int PW, int nbins, int wave,
-                                             int lane, float* __restrict__ s_out) {
+                                             int lane, float* __restrict__ s_out, float* __restrict__ out_row = nullptr) {
   const bool lane_ok = lane * 4 < cc;
   const int voff = (c0 + (lane_ok ? lane * 4 : 0)) * 4;  // byte offset of this lane's channels
   const int pix_bytes = C * 4;
@@ -162,14 +164,19 @@ __device__ __forceinline__ void direct_chunk(const RoiGeom& g, const __amdgpu_bu
         }
       }
       if (lane_ok) {
+        if (OUT_CL) {
+          const v4f o = {acc[0] / g.count, acc[1] / g.count, acc[2] / g.count, acc[3] / g.count};
+          __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(out_row + (size_t)bin * C + c0 + lane * 4));
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) s_out[(lane * 4 + k) * nbins + bin] = acc[k] / g.count;
+          for (int k = 0; k < 4; k++) s_out[(lane * 4 + k) * nbins + bin] = acc[k] / g.count;
+        }
       }
     }
   }
 }
 
-template <int VARIANT, int NW, int SG, int ABL>
+template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false>
 __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
@@ -185,6 +192,11 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
   __amdgpu_buffer_rsrc_t rsrc;
   const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc);
   if (g.batch < 0) return;  // masked RoI (belongs to another pyramid level): its output rows are not ours
+  if (OUT_CL) {
+    direct_chunk<VARIANT, NW, SG, ABL, true>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out,
+                                             out + (size_t)r * nbins * C);
+    return;
+  }
   direct_chunk<VARIANT, NW, SG, ABL>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out);
   __syncthreads();
   float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
 //   * sin/cos in double once per workgroup (wave 0) instead of once per wave.
 // Result = reference value up to fp32 re-association of the weights (<= a few ulp of sum|w.v|);
 // jdet_set_roi_forward_mode(1) selects the reference-order kernel above (bit-identical to the oracle).
-template <int VARIANT, int NW, int ABL = 0>
+template <int VARIANT, int NW, int ABL = 0, bool OUT_CL = false>
 __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     int C, int H, int W, int PH, int PW, float spatial_scale, const int32_t* __restrict__ order, int abl_mask) {
@@ -353,12 +365,17 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
         }
       }
     if (lane_ok) {
-      s_out[(lane * 4 + 0) * nbins + bin] = acc.x;
-      s_out[(lane * 4 + 1) * nbins + bin] = acc.y;
-      s_out[(lane * 4 + 2) * nbins + bin] = acc.z;
-      s_out[(lane * 4 + 3) * nbins + bin] = acc.w;
+      if (OUT_CL) {   // channels-last row (r, bin, :): one contiguous 1 KiB store per wave, no LDS staging
+        __builtin_nontemporal_store(acc, reinterpret_cast<v4f*>(out + ((size_t)r * nbins + bin) * C + c0 + lane * 4));
+      } else {
+        s_out[(lane * 4 + 0) * nbins + bin] = acc.x;
+        s_out[(lane * 4 + 1) * nbins + bin] = acc.y;
+        s_out[(lane * 4 + 2) * nbins + bin] = acc.z;
+        s_out[(lane * 4 + 3) * nbins + bin] = acc.w;
+      }
     }
   }
+  if (OUT_CL) return;
   __syncthreads();
   float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
   if (ABL & 4) {
@@ -777,12 +794,25 @@ int g_fwd_reference_order = 0;
 
 template <int VARIANT>
 int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, int H, int W, int PH,
-               int PW, float scale, int sample_num, int nO, const int32_t* order, hipStream_t st) {
+               int PW, float scale, int sample_num, int nO, const int32_t* order, hipStream_t st,
+               bool out_cl = false) {
   const int chunks = jdet_cdiv(C, kChunkC);
   const size_t lds = (size_t)min(C, kChunkC) * PH * PW * sizeof(float);
   dim3 grid(R, chunks);
   const bool vec = (C % 4 == 0) && VARIANT != JDET_ROI_RIROI && (size_t)H * W * C * 4 < (1ull << 31);
   const int nbins = PH * PW;
+  if (out_cl) {   // channels-last output: vector kernels only (the callers check jdet_roi_align_forward_cl_supported)
+    if (!vec) return JDET_E_UNSUPPORTED;
+    constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
+    // (the merged kernel keeps its per-wave tap lists in the first 2 KiB / wave of the dynamic LDS block)
+    if (sample_num == 2 && !g_fwd_reference_order && nbins <= 64)
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 0, true>), grid, dim3(256), 8 * 2048, st, feat, rois, out,
+                         C, H, W, PH, PW, scale, order, 0);
+    else
+      hipLaunchKernelGGL((roi_align_fwd_vec_kernel<V, 4, 4, 0, true>), grid, dim3(256), 16, st, feat, rois, out, C, H,
+                         W, PH, PW, scale, sample_num, order);
+    return jdet_launch_status();
+  }
   if (vec && sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && lds >= 8 * 2048) {
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     static const int nw = env_int("JDET_ROI_FWD_WAVES", 4);
@@ -917,6 +947,28 @@ JDET_API int jdet_roi_align_forward(int variant, const float* feat, int N, int C
       return launch_fwd<JDET_ROI_HBB_V0>(feat, rois, out, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st);
     default:
       return launch_fwd<JDET_ROI_HBB_V1>(feat, rois, out, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st);
+  }
+}
+
+// RoI-stationary forward with a channels-last result (R, PH, PW, C): same kernels, results stored straight from
+// registers (one contiguous 1 KiB row chunk per wave and bin) instead of being transposed through LDS.
+JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N, int C, int H, int W,
+                                           const float* rois, int R, int PH, int PW, float spatial_scale,
+                                           int sample_num, const int32_t* order, float* out_cl, jdet_stream_t stream) {
+  int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, 1);
+  if (e) return e;
+  if (variant == JDET_ROI_RIROI || C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
+  if (R == 0) return JDET_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case JDET_ROI_ROTATED:
+      return launch_fwd<JDET_ROI_ROTATED>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
+    case JDET_ROI_ROTATED_V1:
+      return launch_fwd<JDET_ROI_ROTATED_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
+    case JDET_ROI_HBB_V0:
+      return launch_fwd<JDET_ROI_HBB_V0>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
+    default:
+      return launch_fwd<JDET_ROI_HBB_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
   }
 }
 

@@ -35,17 +35,49 @@ def parse_tile_name(subname):
     return subname.split("__")[0], int(x), int(y), float(_RATE.findall(subname)[0])
 
 
-def device_group_nms(polys, scores, groups, thresh, device=None):
-    """greedy NMS inside every group at once (IoU > thresh suppresses) -> bool keep mask"""
+MAX_BOXES_PER_LAUNCH = 32768   # the suppression matrix is n x ceil(n / 64) words: 128 MiB at this size
+
+
+def group_chunks(groups, max_boxes=MAX_BOXES_PER_LAUNCH):
+    """Split the detections into runs of WHOLE groups with at most `max_boxes` boxes each (groups never interact, so
+    every run is an independent NMS problem; the workspace of one launch is quadratic in its size).  A single group
+    larger than `max_boxes` becomes a run of its own.  Returns index arrays."""
+    groups = np.asarray(groups)
+    order = np.argsort(groups, kind="stable")
+    g_sorted = groups[order]
+    starts = np.flatnonzero(np.r_[True, g_sorted[1:] != g_sorted[:-1]])
+    ends = np.r_[starts[1:], len(groups)]
+    runs, cur, cur_n = [], [], 0
+    for a, b in zip(starts, ends):
+        if cur and cur_n + (b - a) > max_boxes:
+            runs.append(np.concatenate(cur))
+            cur, cur_n = [], 0
+        cur.append(order[a:b])
+        cur_n += b - a
+    if cur:
+        runs.append(np.concatenate(cur))
+    return runs
+
+
+def device_group_nms(polys, scores, groups, thresh, device=None, max_boxes=MAX_BOXES_PER_LAUNCH):
+    """greedy NMS inside every group (IoU > thresh suppresses) -> bool keep mask.  One launch per run of whole groups
+    (all groups at once when they fit `max_boxes`)."""
     import torch
     from jdet_amd.ops.nms_rotated import nms_rotated_keep_mask
     dev = torch.device("cuda") if device is None else torch.device(device)
-    boxes = torch.from_numpy(np.concatenate([poly_to_rotated_box_np(polys),
-                                             np.asarray(groups, np.float32)[:, None]], 1)).to(dev)
-    s = torch.from_numpy(np.asarray(scores, np.float32)).to(dev)
-    order = torch.argsort(s, descending=True, stable=True)
-    order = order[torch.argsort(boxes[order, 5], stable=True)]
-    return nms_rotated_keep_mask(boxes, order, thresh, rule="cuda").cpu().numpy()
+    rb = np.concatenate([poly_to_rotated_box_np(polys), np.asarray(groups, np.float32)[:, None]], 1)
+    sc = np.asarray(scores, np.float32)
+    keep = np.zeros(len(sc), bool)
+    for idx in group_chunks(groups, max_boxes):
+        if len(idx) > 524288:
+            raise ValueError("%d detections of one original image in one class: beyond what one rotated-NMS launch "
+                             "handles (524288); filter by score first" % len(idx))
+        boxes = torch.from_numpy(rb[idx]).to(dev)
+        s = torch.from_numpy(sc[idx]).to(dev)
+        order = torch.argsort(s, descending=True, stable=True)
+        order = order[torch.argsort(boxes[order, 5], stable=True)]
+        keep[idx] = nms_rotated_keep_mask(boxes, order, thresh, rule="cuda").cpu().numpy().astype(bool)
+    return keep
 
 
 def merge_class_file(src, dst, thresh, group_nms=device_group_nms):

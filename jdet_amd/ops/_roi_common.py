@@ -33,25 +33,32 @@ def to_nhwc(x):
 SPATIAL_ORDER_MIN_ROIS = 64
 
 # Forward path (process-wide; tests and bench switch it):
-#   "tile"       tile-stationary kernel (csrc/roi_align_tile.hip), fma arithmetic, channels-last output  [default]
-#   "tile_exact" the same kernel in the reference's operation order (bit-identical to the CPU oracle)
-#   "roi"        RoI-stationary kernels (csrc/roi_align.hip), (R,C,PH,PW)-contiguous output; their arithmetic
-#                mode is jdet_set_roi_forward_mode (0 merged taps, 1 reference order)
-# Dialects / shapes the tile kernel does not take (RiRoIAlign, adaptive sampling, C % 4 != 0, > 64 bins) always use
-# "roi".  Either way the result is the same logical (R, C, PH, PW) tensor; only its strides differ.
-_FORWARD_PATH = ["tile"]
+#   "roi_cl"     RoI-stationary kernels (csrc/roi_align.hip), channels-last result stored straight from registers
+#                [default: 65 us at the north-star point vs 78 us for the tile path, see DESIGN.md 3.1]
+#   "roi"        the same kernels with the reference's (R,C,PH,PW)-contiguous result (transposed through LDS)
+#   "tile"       tile-stationary plan + pool kernels (csrc/roi_align_tile.hip), fma arithmetic, channels-last result
+#   "tile_exact" the tile kernels in the reference's operation order (bit-identical to the CPU oracle)
+# The arithmetic of the RoI-stationary kernels is jdet_set_roi_forward_mode (0 merged taps, 1 reference order).
+# Dialects / shapes a path does not take (RiRoIAlign, C % 4 != 0; for the tile path also adaptive sampling and
+# > 64 bins) fall back to "roi".  Either way the result is the same logical (R, C, PH, PW) tensor; only its strides
+# differ.
+_FORWARD_PATH = ["roi_cl"]
 
 
 def set_forward_path(name):
-    assert name in ("tile", "tile_exact", "roi")
+    assert name in ("tile", "tile_exact", "roi", "roi_cl")
     prev = _FORWARD_PATH[0]
     _FORWARD_PATH[0] = name
     return prev
 
 
 def _tile_ok(variant, C, H, W, PH, PW, sample_num):
-    return _FORWARD_PATH[0] != "roi" and bool(
+    return _FORWARD_PATH[0] in ("tile", "tile_exact") and bool(
         L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
+
+
+def _roi_cl_ok(variant, C, H, W):
+    return _FORWARD_PATH[0] == "roi_cl" and variant != V_RI and C % 4 == 0 and H * W * C * 4 < (1 << 31)
 
 
 _PLAN_WS = {}
@@ -135,6 +142,14 @@ class RoIAlignFunction(torch.autograd.Function):
             order = None
             _forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num,
                         1 if _FORWARD_PATH[0] == "tile_exact" else 0)
+        elif _roi_cl_ok(variant, C, H, W):
+            out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
+                              memory_format=torch.channels_last)
+            order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
+            L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                                          float(spatial_scale), int(sample_num), L.ptr(order),
+                                                          L.ptr(out), L.stream_ptr(feat)),
+                    "jdet_roi_align_forward_cl_roi")
         else:
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
@@ -173,8 +188,9 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
         R = rois_c.shape[0]
         C = feats[0].shape[1]
         tile = all(_tile_ok(variant, C, f.shape[2], f.shape[3], PH, PW, sample_num) for f in feats)
+        roi_cl = (not tile) and all(_roi_cl_ok(variant, C, f.shape[2], f.shape[3]) for f in feats)
         out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device,
-                          memory_format=torch.channels_last if tile else torch.contiguous_format)
+                          memory_format=torch.channels_last if (tile or roi_cl) else torch.contiguous_format)
         exact = 1 if _FORWARD_PATH[0] == "tile_exact" else 0
         lvl = target_lvls.to(rois_c.device)
         masked, shapes = [], []
@@ -186,6 +202,10 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
             if R and tile:
                 _forward_cl(variant, fm, r_i, out, PH, PW, scales[i], sample_num, exact)
+            elif R and roi_cl:
+                L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
+                                                              float(scales[i]), int(sample_num), None, L.ptr(out),
+                                                              L.stream_ptr(fm)), "jdet_roi_align_forward_cl_roi")
             elif R:
                 L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                        float(scales[i]), int(sample_num), int(n_orient), None,

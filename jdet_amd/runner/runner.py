@@ -52,12 +52,14 @@ class Runner:
         # graph=True: the whole step (forward, losses, backward | one flat all-reduce | clip + SGD) replays as
         # HIP graphs; needs a model whose step is fixed-shape and sync-free (the single-stage heads)
         self.use_graph = (os.environ.get("JDET_TRAIN_GRAPH", "0") == "1") if graph is None else bool(graph)
-        self._graphs = {}
         if conv_autotune:
             # DOTA tiles have one fixed shape: let MIOpen time its solvers once per conv geometry instead of
             # taking the heuristic pick (measured 63.6 -> 58.0 ms per S2ANet step, profiles/r01_miopen_find.txt)
             torch.backends.cudnn.benchmark = True
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type == "cuda":
+            # the C-ABI kernels launch on the CURRENT HIP device: make the runner's device current (one process per GPU)
+            torch.cuda.set_device(self.device)
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world_size > 1 else 0
         self.model = build_from_cfg(cfg["model"], MODELS).to(self.device)
@@ -94,6 +96,10 @@ class Runner:
                 broadcast_buffers=os.environ.get("JDET_DDP_BROADCAST_BUFFERS", "0") == "1")
         self.iter = 0
         self.epoch = 0
+        from collections import OrderedDict
+        self._graphs = OrderedDict()
+        self._graph_cap = int(os.environ.get("JDET_GRAPH_CACHE", "4"))   # captured steps kept (LRU)
+        self._graph_misses = 0                                           # consecutive steps that had to capture
 
     # ------------------------------------------------------------------ HIP-graph step
     def _graph_key(self, images, targets):
@@ -182,9 +188,24 @@ class Runner:
         key = self._graph_key(images, targets)
         st = self._graphs.get(key)
         if st is None:
+            # The key holds every target shape (the per-image gt counts): a real dataset gives a new key almost every
+            # step, and each capture costs two warm-up passes, a private memory pool and a flat gradient buffer.
+            # Graph mode is for fixed-shape batches: after a few consecutive misses it is switched off; the cache is
+            # bounded (least recently used capture dropped).
+            self._graph_misses += 1
+            if self._graph_misses > max(2, self._graph_cap):
+                if self.rank == 0:
+                    print("jdet_amd.Runner: %d consecutive steps with a new batch signature -- HIP-graph mode is for "
+                          "fixed-shape batches; continuing with eager steps" % self._graph_misses)
+                self._leave_graph_mode()
+                return self._eager_step(images, targets)
             self.model.train()
+            while len(self._graphs) >= self._graph_cap:
+                self._graphs.popitem(last=False)
             st = self._graphs[key] = self._capture(images, targets)
         else:
+            self._graph_misses = 0
+            self._graphs.move_to_end(key)
             st["images"].copy_(images, non_blocking=True)
             for dst, src in zip(st["targets"], targets):
                 for k, v in src.items():
@@ -218,11 +239,39 @@ class Runner:
         else:
             losses = self.train_model(images, targets)
         all_loss, losses = parse_losses(losses)
-        self.optimizer.step(all_loss)
+        if self.world_size > 1 and self.train_model is self.model:
+            # no DDP wrapper (graph mode warms up / falls back through here): the replicas stay identical only if the
+            # gradients are averaged before the update, exactly as the graph step does with its flat buffer
+            self.optimizer.zero_grad(set_to_none=True)
+            all_loss.backward()
+            self._allreduce_grads()
+            self.optimizer.step(None)
+        else:
+            self.optimizer.step(all_loss)
         if self.scheduler is not None:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
         self.iter += 1
         return all_loss.detach(), {k: v.detach() for k, v in losses.items()}
+
+    def _allreduce_grads(self):
+        grads = [p.grad for p in self.model.parameters() if p.requires_grad and p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat.div_(self.world_size)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view(g.shape))   # reshape(-1) flattened in logical order, whatever g's strides
+            off += n
+
+    def _leave_graph_mode(self):
+        """drop the captures and continue eagerly (p.grad no longer aliases a flat capture buffer)"""
+        self.use_graph = False
+        self._graphs.clear()
+        for p in self.model.parameters():
+            p.grad = None
 
     # ------------------------------------------------------------------ training on a dataset
     def fit(self, dataset, max_epoch=1, max_iter=None, log_interval=0):
@@ -231,6 +280,11 @@ class Runner:
         `scheduler.step(iter, epoch, by_epoch=True)` after every iteration.  Returns the last (loss, parts)."""
         from torch.utils.data.distributed import DistributedSampler
         from jdet_amd.data import DeviceFeeder
+        if self.use_graph:
+            # batches of a dataset differ in their gt counts: every step would re-capture (see _graph_step)
+            if self.rank == 0:
+                print("jdet_amd.Runner.fit: HIP-graph mode needs fixed-shape batches; using eager steps")
+            self._leave_graph_mode()
         sampler = DistributedSampler(dataset, shuffle=dataset.shuffle) if self.world_size > 1 else None
         feeder = DeviceFeeder(dataset.loader(sampler=sampler), self.device)
         last = None
@@ -259,11 +313,15 @@ class Runner:
         data = {
             "meta": {"jdet_version": "jdet_amd", "epoch": self.epoch, "iter": self.iter,
                      "save_time": time.strftime("%Y-%m-%d %H:%M:%S")},
-            "model": {k: v.detach().cpu().numpy() for k, v in self.model.state_dict().items()},
+            # torch-only bookkeeping buffers are not parameters of the reference's modules
+            "model": {k: v.detach().cpu().numpy() for k, v in self.model.state_dict().items()
+                      if not k.endswith("num_batches_tracked")},
             "scheduler": self.scheduler.parameters() if self.scheduler is not None and
             hasattr(self.scheduler, "parameters") else {},
-            "optimizer": {"lr": self.optimizer.cur_lr()},
+            "optimizer": self._optimizer_state(),
         }
+        data["meta"].update({"max_iter": self.cfg.get("max_iter"), "max_epoch": self.cfg.get("max_epoch")}
+                            if hasattr(self.cfg, "get") else {})
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, "wb") as f:
             pickle.dump(data, f)
@@ -276,9 +334,14 @@ class Runner:
         with open(path, "rb") as f:
             data = pickle.load(f)
         if not model_only and isinstance(data, dict):
+            # runner.py:L243-247: resume = meta counters + scheduler + optimizer state
             meta = data.get("meta", {})
             self.epoch = meta.get("epoch", self.epoch)
             self.iter = meta.get("iter", self.iter)
+            if self.scheduler is not None and data.get("scheduler") and hasattr(self.scheduler, "load_parameters"):
+                self.scheduler.load_parameters(data["scheduler"])
+            if data.get("optimizer"):
+                self._load_optimizer_state(data["optimizer"])
         if isinstance(data, dict) and "model" in data:
             params = data["model"]
         elif isinstance(data, dict) and "state_dict" in data:
@@ -299,6 +362,34 @@ class Runner:
                     continue
                 own[k].copy_(t.to(own[k].dtype))      # keeps the parameter's own memory format
         return missing, unexpected, mismatched
+
+    def _optimizer_state(self):
+        """lr + one momentum buffer per trainable parameter NAME (numpy), so that a resumed run continues the
+        same trajectory (optimizer.py:L8-36 keeps the same state in Jittor's optimizer)"""
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        mom = {}
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                buf = self.optimizer.state.get(p, {}).get("momentum_buffer")
+                if buf is not None and id(p) in names:
+                    mom[names[id(p)]] = buf.detach().cpu().numpy()
+        return {"lr": self.optimizer.cur_lr(), "momentum_buffer": mom}
+
+    def _load_optimizer_state(self, st):
+        if not isinstance(st, dict):
+            return
+        if "lr" in st:
+            for g in self.optimizer.param_groups:
+                g["lr"] = float(st["lr"])
+        params = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for n, arr in (st.get("momentum_buffer") or {}).items():
+                p = params.get(n)
+                if p is None or tuple(np.shape(arr)) != tuple(p.shape):
+                    continue
+                buf = torch.zeros_like(p)
+                buf.copy_(torch.as_tensor(np.asarray(arr)).to(p.dtype))
+                self.optimizer.state[p]["momentum_buffer"] = buf
 
     def test_time(self, images, targets, warmup=10, iters=100):
         """the reference's own throughput definition (runner.py:L91-115): FPS = batch*world*iters/wall"""

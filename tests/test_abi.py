@@ -99,6 +99,28 @@ def test_bench_contract_pieces_importable_without_gpu():
     assert bench.roitrans_train_cfg("Resnet101")["model"]["backbone"]["type"] == "Resnet101"
 
 
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` started by hand (no WORLD_SIZE) re-launches itself as 2 ranks of one node and the
+    JSON line reports the size of the initialised group (the flag used to be parsed and ignored).
+    Driven on CPU ranks through the plumbing-only `selftest_cpu` workload."""
+    import json
+    import subprocess
+    import sys
+    import importlib
+    bench = importlib.import_module("bench")
+    cmd = bench.launch_command(["--gpus", "2", "--workload", "s2anet_train"], 2, port=12345)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--workload", "s2anet_train"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "selftest_cpu",
+                        "--steps", "5", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["config"]["parallelism"] == "replicas x2"
+
+
 def test_argument_validation_returns_before_any_launch(built_lib):
     """every entry point checks its arguments first and reports through the int status (no launch, so this runs
     without a GPU): JDET_E_BADARG -1, JDET_E_UNSUPPORTED -2, JDET_E_WORKSPACE -3"""

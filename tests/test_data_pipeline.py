@@ -415,3 +415,24 @@ def test_merge_tile_results(tmp_path):
 def I_clustered(rng, n):
     from tests import inputs as I
     return I.clustered_obbs(rng, n, 8, 1600.0)
+
+
+def test_group_chunks_split_on_group_boundaries():
+    """tile merging: the detections of a class are de-duplicated in runs of WHOLE images with a bounded number of boxes
+    (the NMS workspace is quadratic); a run never cuts an image, every detection is in exactly one run"""
+    from jdet_amd.data.result_merge import group_chunks
+    rng = np.random.default_rng(0)
+    groups = rng.integers(0, 40, 5000)
+    runs = group_chunks(groups, max_boxes=600)
+    allidx = np.concatenate(runs)
+    assert sorted(allidx.tolist()) == list(range(5000))
+    seen = set()
+    for r in runs:
+        gs = set(groups[r].tolist())
+        assert not gs & seen            # an image lives in one run only
+        seen |= gs
+        sizes = [int((groups == g).sum()) for g in gs]
+        assert len(r) <= 600 or len(gs) == 1, (len(r), sizes)
+    assert len(runs) > 1
+    one = group_chunks(np.zeros(1000, int), max_boxes=100)     # a single oversized image stays whole
+    assert len(one) == 1 and len(one[0]) == 1000

@@ -191,3 +191,76 @@ def test_fit_shards_the_dataset_across_ranks(tmp_path):
     mp.spawn(_fit_worker, args=(2, port, root, out), nprocs=2, join=True)
     a, b = torch.load(out + ".0"), torch.load(out + ".1")
     assert len(a) == len(b) == 4 and not set(a) & set(b) and len(set(a) | set(b)) == 8
+
+
+def _manual_avg_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from jdet_amd.runner import Runner
+        _register_tiny()
+        torch.manual_seed(7)
+        # no DDP wrapper under world_size 2: the path the HIP-graph mode warms up (and falls back) through
+        r = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+        assert r.world_size == world and r.train_model is r.model
+        for it in range(4):
+            images, targets = _batch(100 + 10 * it + rank)
+            r.train_step(images, targets)
+        for k, v in r.model.state_dict().items():     # gradients were averaged by hand: replicas identical
+            ref = v.clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(ref, v), k
+        for p in r.model.parameters():                 # ... and so are the momentum buffers
+            ref = r.optimizer.state[p]["momentum_buffer"].clone()
+            dist.broadcast(ref, 0)
+            assert torch.equal(ref, r.optimizer.state[p]["momentum_buffer"])
+        if rank == 0:
+            torch.save({k: v.clone() for k, v in r.model.state_dict().items()}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicas_without_ddp_wrapper_average_their_gradients(tmp_path):
+    """graph mode runs its first iterations (and its fallback) through the eager step WITHOUT a DDP wrapper: the
+    gradients must be all-reduced by hand there, or the replicas drift apart for good."""
+    port = 33500 + os.getpid() % 2000
+    out = str(tmp_path / "m.pt")
+    mp.spawn(_manual_avg_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    from jdet_amd.runner import Runner
+    _register_tiny()
+    torch.manual_seed(7)
+    r = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    for it in range(4):
+        i0, t0 = _batch(100 + 10 * it + 0)
+        i1, t1 = _batch(100 + 10 * it + 1)
+        r.train_step(torch.cat([i0, i1]), t0 + t1)
+    for k, v in r.model.state_dict().items():
+        assert torch.allclose(got[k], v, atol=1e-6), k
+
+
+def test_resume_continues_the_same_trajectory(tmp_path):
+    """save -> load restores counters, scheduler and optimizer state INCLUDING the momentum buffers
+    (runner.py:L243-247): three more steps after a resume equal three more steps of the original run"""
+    import pickle
+    from jdet_amd.runner import Runner
+    _register_tiny()
+    torch.manual_seed(3)
+    a = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    for it in range(3):
+        a.train_step(*_batch(it))
+    path = a.save(str(tmp_path / "ckpt.pkl"))
+    raw = pickle.load(open(path, "rb"))
+    assert set(raw["optimizer"]) >= {"lr", "momentum_buffer"} and len(raw["optimizer"]["momentum_buffer"]) == 4
+    assert not any(k.endswith("num_batches_tracked") for k in raw["model"])
+    torch.manual_seed(99)
+    b = Runner(CFG, device="cpu", channels_last=False, ddp=False, conv_autotune=False)
+    b.load(path)
+    assert b.iter == 3 and abs(b.optimizer.cur_lr() - a.optimizer.cur_lr()) < 1e-12
+    for it in range(3, 6):
+        la, _ = a.train_step(*_batch(it))
+        lb, _ = b.train_step(*_batch(it))
+        assert abs(float(la) - float(lb)) < 1e-7
+    for (k, v), (_, w) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.allclose(v, w, atol=1e-7), k

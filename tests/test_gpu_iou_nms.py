@@ -155,16 +155,24 @@ def test_multiclass_nms_rotated(dev):
     det, lab = multiclass_nms_rotated(boxes, sc, 0.05, dict(type="nms_rotated", iou_thr=0.1), 2000)
     assert det.shape[1] == 6 and det.shape[0] == lab.shape[0] > 0
     assert torch.all(det[1:, 5] <= det[:-1, 5]) and lab.min() >= 0 and lab.max() < ncls
-    # per-class check against the oracle
+    # per-class check against the oracle: the kept IDENTITIES (box, score, class), not just how many
     scn, bn = sc.cpu().numpy()[:, 1:], boxes.cpu().numpy()
-    total = 0
+    expect = []
     for c in range(ncls):
-        m = scn[:, c] > 0.05
-        if not m.any():
+        m = np.nonzero(scn[:, c] > 0.05)[0]
+        if m.size == 0:
             continue
         order = np.argsort(-scn[m, c], kind="stable").astype(np.int32)
-        total += int(O.nms_rotated_keep(bn[m], order, 0.1).sum())
-    assert total == det.shape[0]
+        keep = O.nms_rotated_keep(bn[m], order, 0.1)
+        for i in m[keep]:
+            expect.append((float(scn[i, c]), c, int(i)))
+    assert len(expect) == det.shape[0]
+    # the op returns the survivors of all classes sorted by score (no ties in this input)
+    expect.sort(key=lambda t: -t[0])
+    dn, ln = det.cpu().numpy(), lab.cpu().numpy()
+    np.testing.assert_array_equal(ln, np.array([c for _, c, _ in expect]))
+    np.testing.assert_array_equal(dn[:, 5], np.array([s for s, _, _ in expect], np.float32))
+    np.testing.assert_array_equal(dn[:, :5], bn[[i for _, _, i in expect]])
     e_det, e_lab = multiclass_nms_rotated(boxes, sc * 0, 0.05, dict(iou_thr=0.1), 100)
     assert e_det.shape == (0, 6) and e_lab.shape == (0,)
 

@@ -10,7 +10,16 @@ from tests import inputs as I
 pytestmark = pytest.mark.gpu
 
 
-def test_oriented_extractor_vs_per_level_oracle(dev):
+@pytest.fixture
+def reference_order():
+    """bit-exact comparisons run the RoIAlign kernels in the reference's operation order"""
+    from jdet_amd import _lib as L
+    prev = L.lib().jdet_set_roi_forward_mode(1)
+    yield
+    L.lib().jdet_set_roi_forward_mode(prev)
+
+
+def test_oriented_extractor_vs_per_level_oracle(dev, reference_order):
     from jdet_amd.models.roi_extractors import OrientedSingleRoIExtractor, RboxSingleRoIExtractor, SingleRoIExtractor
     rng = np.random.default_rng(0)
     strides = [4, 8, 16, 32]

@@ -16,10 +16,12 @@ FWD_MERGED_ATOL = 2e-6   # default mode
 BWD_ATOL = 2e-5
 
 
-PATHS = [("roi", 1, FWD_ATOL), ("roi", 0, FWD_MERGED_ATOL), ("tile_exact", 0, FWD_ATOL), ("tile", 0, FWD_MERGED_ATOL)]
+PATHS = [("roi", 1, FWD_ATOL), ("roi", 0, FWD_MERGED_ATOL), ("roi_cl", 1, FWD_ATOL), ("roi_cl", 0, FWD_MERGED_ATOL),
+         ("tile_exact", 0, FWD_ATOL), ("tile", 0, FWD_MERGED_ATOL)]
 
 
-@pytest.fixture(params=PATHS, ids=["roi-reforder", "roi-merged", "tile-exact", "tile"], autouse=True)
+@pytest.fixture(params=PATHS, ids=["roi-reforder", "roi-merged", "roicl-reforder", "roicl-merged", "tile-exact", "tile"],
+                autouse=True)
 def fwd_mode(request):
     """every forward path: RoI-stationary kernels (reference-order / merged-tap arithmetic) and the tile-stationary
     kernel (reference-order / fma arithmetic).  Yields the forward tolerance of the path."""
