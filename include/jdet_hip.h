@@ -254,6 +254,24 @@ int jdet_delta2bbox_rotated(const float* rois, const float* deltas, int n, int n
 int jdet_bbox2delta_rotated(const float* proposals, const float* gt, int n, const float* means5,
                             const float* stds5, float* out, jdet_stream_t stream);
 
+/* Box codecs of the Oriented R-CNN path, one fused launch each.  Replace the Jittor tensor programs
+ * models/boxes/coder.py:L332-437 (MidpointOffsetCoder: horizontal anchor (n,4) <-> 6 deltas (dx, dy, dw, dh, da,
+ * db) of a rotated box given by its enclosing box and the offsets of its top-most / right-most vertex; decode
+ * rebuilds the parallelogram, stretches it to a rectangle and returns the regularised obb (n,5)) and L449-518
+ * (OrientedDeltaXYWHTCoder: rotated RoI (n,5) <-> 5 deltas in the RoI's frame, the angle delta taken as the
+ * smaller of dtheta / dtheta + pi/2 with a w <-> h swap; decode is class-wise: deltas (n, ncls*5) -> (n, ncls*5)),
+ * with obb2hbb / obb2poly / rectpoly2obb / regular_theta / regular_obb of ops/bbox_transforms.py:L499-517,L575-646
+ * inlined.  `max_shape` is accepted and ignored by the reference's decoders, so it is not a parameter here.
+ * means / stds are HOST pointers (6 resp. 5 floats). */
+int jdet_midpoint_offset_decode(const float* anchors_hbb, const float* deltas, long n, const float* means6,
+                                const float* stds6, float wh_ratio_clip, float* out_obb, jdet_stream_t stream);
+int jdet_midpoint_offset_encode(const float* anchors_hbb, const float* gt_obb, long n, const float* means6,
+                                const float* stds6, float* out6, jdet_stream_t stream);
+int jdet_oriented_delta_decode(const float* rois, const float* deltas, long n, int ncls, const float* means5,
+                               const float* stds5, float wh_ratio_clip, float* out, jdet_stream_t stream);
+int jdet_oriented_delta_encode(const float* rois, const float* gt, long n, const float* means5, const float* stds5,
+                               float* out, jdet_stream_t stream);
+
 /* Dense anchor targets: replaces the index-list scatter of anchor_target_single
  * (models/boxes/anchor_target.py:L137-168) for the PseudoSampler case.  gt_inds (A) is the assigner's
  * output (0 negative, -1 ignored, i+1 = gt i); every anchor gets label (gt_labels[i] or 1 when gt_labels is

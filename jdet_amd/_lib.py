@@ -52,6 +52,10 @@ SIGNATURES = {
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),
     "jdet_bbox2delta_rotated": (_i, [_p, _p, _i, _p, _p, _p, _p]),
+    "jdet_midpoint_offset_decode": (_i, [_p, _p, _l, _p, _p, _f, _p, _p]),
+    "jdet_midpoint_offset_encode": (_i, [_p, _p, _l, _p, _p, _p, _p]),
+    "jdet_oriented_delta_decode": (_i, [_p, _p, _l, _i, _p, _p, _f, _p, _p]),
+    "jdet_oriented_delta_encode": (_i, [_p, _p, _l, _p, _p, _p, _p]),
     "jdet_anchor_targets_rotated": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p, _p]),
     "jdet_assign_max_iou_workspace": (_sz, [_i]),
     "jdet_assign_max_iou": (_i, [_p, _i, _i, _f, _f, _f, _f, _i, _i, _p, _i, _p, _p, _p, _p, _sz, _p]),
@@ -136,6 +140,13 @@ def f32c(t):
 def vec5(v):
     """host float[5] argument (codec means / stds)"""
     return (ctypes.c_float * 5)(*[float(x) for x in v])
+
+
+def vecn(v, n):
+    """host float[n] argument"""
+    v = [float(x) for x in v]
+    assert len(v) == n
+    return (ctypes.c_float * n)(*v)
 
 
 def ptr(t):

@@ -1,0 +1,68 @@
+// Active rotating filters (ORConv2d) for gfx950: a weight (nOut, nIn, nOri, kH, kW) is expanded to the nRot
+// rotated copies (nOut * nRot, nIn * nOri, kH, kW) by a byte index table (ops/orn.py:L17-72: `indices[l][k]` = 1-based
+// destination entry of source entry l under rotation k); the backward sums the gradient of the copies back.
+// 73 728 weights at S2ANet's or_conv: a launch-latency-sized gather.  One thread per SOURCE entry, the nRot
+// destinations of a thread form a permutation orbit, so neither direction needs atomics.
+#include "common.h"
+
+namespace {
+
+struct ArfShape {
+  int nIn, nEntry, nRot;   // nEntry = nOri * kH * kW
+};
+
+// destination element of source element (i, j, l) under rotation k
+__device__ __forceinline__ size_t arf_dst(const ArfShape& s, const uint8_t* __restrict__ indices, int i, int j, int l,
+                                          int k) {
+  const int m = (int)indices[l * s.nRot + k] - 1;
+  return ((size_t)(i * s.nRot + k) * s.nIn + j) * s.nEntry + m;
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void arf_kernel(long n, const float* __restrict__ src,
+                                                  const uint8_t* __restrict__ indices, ArfShape s,
+                                                  float* __restrict__ dst) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int l = (int)(idx % s.nEntry);
+    const int j = (int)((idx / s.nEntry) % s.nIn);
+    const int i = (int)(idx / s.nEntry / s.nIn);
+    if (BACKWARD) {
+      float acc = 0;
+      for (int k = 0; k < s.nRot; k++) acc = acc + src[arf_dst(s, indices, i, j, l, k)];
+      dst[idx] = acc;
+    } else {
+      const float v = src[idx];
+      for (int k = 0; k < s.nRot; k++) dst[arf_dst(s, indices, i, j, l, k)] = v;
+    }
+  }
+}
+
+int arf_launch(bool backward, const float* src, const uint8_t* indices, int nOut, int nIn, int nOri, int kH, int kW,
+               int nRot, float* dst, hipStream_t st) {
+  if (nOut < 0 || nIn < 0 || nOri <= 0 || kH <= 0 || kW <= 0 || nRot <= 0) return JDET_E_BADARG;
+  const long n = (long)nOut * nIn * nOri * kH * kW;
+  if (n == 0) return JDET_OK;
+  if (!src || !indices || !dst) return JDET_E_BADARG;
+  ArfShape s{nIn, nOri * kH * kW, nRot};
+  long g = (n + 255) / 256;
+  if (g > 262144) g = 262144;
+  if (backward)
+    hipLaunchKernelGGL((arf_kernel<true>), dim3((unsigned)g), dim3(256), 0, st, n, src, indices, s, dst);
+  else
+    hipLaunchKernelGGL((arf_kernel<false>), dim3((unsigned)g), dim3(256), 0, st, n, src, indices, s, dst);
+  return jdet_launch_status();
+}
+
+}  // namespace
+
+JDET_API int jdet_arf_forward(const float* weight, const uint8_t* indices, int nOut, int nIn, int nOri,
+                              int kH, int kW, int nRot, float* out, jdet_stream_t stream) {
+  return arf_launch(false, weight, indices, nOut, nIn, nOri, kH, kW, nRot, out, (hipStream_t)stream);
+}
+
+JDET_API int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
+                               int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream) {
+  return arf_launch(true, grad_out, indices, nOut, nIn, nOri, kH, kW, nRot, grad_weight, (hipStream_t)stream);
+}
+
+JDET_API int jdet_version(void) { return 2; }

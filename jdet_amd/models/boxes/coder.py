@@ -1,8 +1,17 @@
 """BBox coders of the named configs.  Mirrors python/jdet/models/boxes/coder.py:
 `DeltaXYWHABBoxCoder` L76-141."""
+import torch
+
+from jdet_amd import _lib as L
 from jdet_amd.utils.registry import BOXES
 
 from .box_ops import bbox2delta_rotated, delta2bbox_rotated
+
+
+def _fused_ok(*ts):
+    """the fused HIP codecs produce values, not graphs: used whenever no gradient is asked for"""
+    return all(t.is_cuda and t.dim() == 2 for t in ts) and not (torch.is_grad_enabled() and
+                                                                  any(t.requires_grad for t in ts))
 
 
 @BOXES.register_module()
@@ -35,9 +44,15 @@ class MidpointOffsetCoder:
         self.stds = target_stds
 
     def encode(self, bboxes, gt_bboxes):
-        import torch
         from jdet_amd.ops.bbox_transforms import obb2hbb, obb2poly
         assert bboxes.size(0) == gt_bboxes.size(0)
+        if _fused_ok(bboxes, gt_bboxes) and bboxes.shape[1] == 4 and gt_bboxes.shape[1] == 5:
+            a, g = L.f32c(bboxes), L.f32c(gt_bboxes)
+            out = torch.empty((a.shape[0], 6), dtype=torch.float32, device=a.device)
+            L.check(L.lib().jdet_midpoint_offset_encode(L.ptr(a), L.ptr(g), a.shape[0], L.vecn(self.means, 6),
+                                                        L.vecn(self.stds, 6), L.ptr(out), L.stream_ptr(a)),
+                    "jdet_midpoint_offset_encode")
+            return out
         pred_bboxes, gt = bboxes.float(), gt_bboxes.float()
         px = (pred_bboxes[..., 0] + pred_bboxes[..., 2]) * 0.5
         py = (pred_bboxes[..., 1] + pred_bboxes[..., 3]) * 0.5
@@ -70,9 +85,15 @@ class MidpointOffsetCoder:
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         import math
-        import torch
         from jdet_amd.ops.bbox_transforms import rectpoly2obb
         assert pred_bboxes.size(0) == bboxes.size(0)
+        if _fused_ok(bboxes, pred_bboxes) and bboxes.shape[1] == 4 and pred_bboxes.shape[1] == 6:
+            a, d = L.f32c(bboxes), L.f32c(pred_bboxes)
+            out = torch.empty((a.shape[0], 5), dtype=torch.float32, device=a.device)
+            L.check(L.lib().jdet_midpoint_offset_decode(L.ptr(a), L.ptr(d), a.shape[0], L.vecn(self.means, 6),
+                                                        L.vecn(self.stds, 6), float(wh_ratio_clip), L.ptr(out),
+                                                        L.stream_ptr(a)), "jdet_midpoint_offset_decode")
+            return out
         means = pred_bboxes.new_tensor(self.means).repeat(1, pred_bboxes.size(1) // 6)
         stds = pred_bboxes.new_tensor(self.stds).repeat(1, pred_bboxes.size(1) // 6)
         d = pred_bboxes * stds + means
@@ -113,10 +134,16 @@ class OrientedDeltaXYWHTCoder:
 
     def encode(self, bboxes, gt_bboxes):
         import math
-        import torch
         from jdet_amd.ops.bbox_transforms import regular_theta
         assert bboxes.size(0) == gt_bboxes.size(0)
         assert bboxes.size(-1) == gt_bboxes.size(-1) == 5
+        if _fused_ok(bboxes, gt_bboxes):
+            p, g = L.f32c(bboxes), L.f32c(gt_bboxes)
+            out = torch.empty_like(p)
+            L.check(L.lib().jdet_oriented_delta_encode(L.ptr(p), L.ptr(g), p.shape[0], L.vecn(self.means, 5),
+                                                       L.vecn(self.stds, 5), L.ptr(out), L.stream_ptr(p)),
+                    "jdet_oriented_delta_encode")
+            return out
         px, py, pw, ph, ptheta = bboxes.float().unbind(dim=-1)
         gx, gy, gw, gh, gtheta = gt_bboxes.float().unbind(dim=-1)
         dtheta1 = regular_theta(gtheta - ptheta)
@@ -136,9 +163,16 @@ class OrientedDeltaXYWHTCoder:
 
     def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
         import math
-        import torch
         from jdet_amd.ops.bbox_transforms import regular_obb, regular_theta
         assert pred_bboxes.size(0) == bboxes.size(0)
+        if _fused_ok(bboxes, pred_bboxes) and bboxes.shape[1] == 5 and pred_bboxes.shape[1] % 5 == 0:
+            r, d = L.f32c(bboxes), L.f32c(pred_bboxes)
+            out = torch.empty_like(d)
+            L.check(L.lib().jdet_oriented_delta_decode(L.ptr(r), L.ptr(d), d.shape[0], d.shape[1] // 5,
+                                                       L.vecn(self.means, 5), L.vecn(self.stds, 5),
+                                                       float(wh_ratio_clip), L.ptr(out), L.stream_ptr(d)),
+                    "jdet_oriented_delta_decode")
+            return out
         means = pred_bboxes.new_tensor(self.means).repeat(1, pred_bboxes.size(1) // 5)
         stds = pred_bboxes.new_tensor(self.stds).repeat(1, pred_bboxes.size(1) // 5)
         d = pred_bboxes * stds + means

@@ -1,20 +1,73 @@
-"""Oriented R-CNN RoI head.  Mirrors python/jdet/models/roi_heads/oriented_head.py:L13-530: assign
-(rotated IoU v1) + RandomSamplerRotated per image -> arb2roi -> OrientedSingleRoIExtractor
-(ROIAlignRotated_v1 on 4 FPN levels) -> 2 shared FCs -> fc_cls (C+1, background = last) / fc_reg (5,
-class agnostic) -> CE + SmoothL1 on OrientedDeltaXYWHTCoder targets.  Labels are 0-based with
-background = num_classes (`target["labels"] - 1`, L472)."""
+"""Oriented R-CNN RoI head.
+
+Contract of python/jdet/models/roi_heads/oriented_head.py:L13-530 (constructor arguments and defaults, parameter
+names `shared_fcs.N / cls_fcs / reg_fcs / fc_cls / fc_reg`, loss keys `loss_cls` / `orcnn_bbox_loss`, inference
+output `(polys (k,8), scores (k,), labels (k,))` per image): assign proposals (+ the gts themselves) to gts by
+rotated IoU (v1 convention), sample 512 RoIs per image (25 % positives), pool them with ROIAlignRotated_v1 on four
+FPN levels, two shared FC layers, a (C+1)-way classifier (background = last class) and a class-agnostic 5-parameter
+regressor on OrientedDeltaXYWHTCoder targets.
+
+Execution (this file's own; the reference builds per-image SamplingResult index lists, L466-501):
+  * the RPN hands over a proposal TABLE per image -- always `nms_post` rows [box5, score], padding rows with score
+    < 0 -- and everything downstream keeps fixed shapes: padding rows get overlap -1 (ignored by the assigner), the
+    sample is `num` rows per image drawn by random keys + top-k with a validity mask (models/boxes/fixed_shape.py),
+    unused rows point at a small dummy box and carry weight 0.  No nonzero / boolean indexing / `.any()` in the
+    train step, so no device -> host round trip and the step can be captured in a HIP graph.
+  * RoI features arrive channels-last from the RoIAlign kernels; the first FC layer consumes them in that order
+    (its weight columns are permuted once at load / save time, `RoIFeatureLinear`), so the 51 MB per step transposes
+    in both directions of the reference layout disappear while checkpoints keep the reference's weight order.
+"""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from jdet_amd.models.boxes.fixed_shape import sample_rows
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.ops.bbox_transforms import get_bbox_dim, obb2poly
-from jdet_amd.utils.general import multi_apply
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, ROI_EXTRACTORS, build_from_cfg
 
 
 def _pair(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class RoIFeatureLinear(nn.Linear):
+    """First FC layer on pooled RoI features (R, C, PH, PW).
+
+    The parameter is stored with its input columns in (ph, pw, c) order -- the memory order of a channels-last
+    feature tensor, which is then consumed as a plain (R, PH*PW*C) matrix without a copy.  State dicts hold the
+    reference's (c, ph, pw) column order (`x.flatten(1)` of an NCHW tensor, oriented_head.py:L267): the hooks below
+    permute on save and load, so reference checkpoints load unchanged."""
+
+    def __init__(self, channels, area, out_features):
+        super().__init__(channels * area, out_features)
+        self.channels, self.area = channels, area
+        self._register_state_dict_hook(RoIFeatureLinear._to_reference_order)
+        self._register_load_state_dict_pre_hook(self._from_reference_order)
+
+    def _permute(self, w, to_reference):
+        o = w.shape[0]
+        if to_reference:
+            return w.reshape(o, self.area, self.channels).permute(0, 2, 1).reshape(o, -1)
+        return w.reshape(o, self.channels, self.area).permute(0, 2, 1).reshape(o, -1)
+
+    @staticmethod
+    def _to_reference_order(module, state_dict, prefix, local_metadata):
+        key = prefix + "weight"
+        if key in state_dict:
+            state_dict[key] = module._permute(state_dict[key], True).contiguous()
+
+    def _from_reference_order(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        key = prefix + "weight"
+        if key in state_dict and tuple(state_dict[key].shape) == tuple(self.weight.shape):
+            state_dict[key] = self._permute(state_dict[key], False).contiguous()
+
+    def forward(self, x):
+        if x.dim() == 4:
+            # (R, C, PH, PW) -> rows in (ph, pw, c) order: a view for channels-last memory, one copy otherwise
+            x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
+        return F.linear(x, self.weight, self.bias)
 
 
 @HEADS.register_module()
@@ -37,295 +90,167 @@ class OrientedHead(nn.Module):
                  start_bbox_type="obb", end_bbox_type="obb", reg_dim=None, reg_class_agnostic=True,
                  reg_decoded_bbox=False, pos_weight=-1):
         super().__init__()
-        assert with_cls or with_reg
-        self.with_avg_pool = with_avg_pool
-        self.with_cls = with_cls
-        self.with_reg = with_reg
-        self.with_bbox = with_bbox
-        self.with_shared_head = with_shared_head
-        self.in_channels = in_channels
-        self.num_classes = num_classes
-        self.reg_class_agnostic = reg_class_agnostic
-        self.reg_decoded_bbox = reg_decoded_bbox
-        self.pos_weight = pos_weight
-        self.score_thresh = score_thresh
+        assert with_bbox and with_cls and with_reg and not with_shared_head and not with_avg_pool
+        assert start_bbox_type == "obb" and end_bbox_type == "obb" and not reg_decoded_bbox, \
+            "the Oriented R-CNN configuration (obb proposals -> obb detections, encoded regression targets)"
+        assert num_shared_convs + num_shared_fcs + num_cls_convs + num_cls_fcs + num_reg_convs + num_reg_fcs > 0
+        self.num_classes, self.in_channels = num_classes, in_channels
+        self.reg_class_agnostic, self.pos_weight, self.score_thresh = reg_class_agnostic, pos_weight, score_thresh
+        self.start_bbox_type, self.end_bbox_type = start_bbox_type, end_bbox_type
+        self.reg_dim = get_bbox_dim(end_bbox_type) if reg_dim is None else reg_dim
         self.roi_feat_size = _pair(7)
         self.roi_feat_area = self.roi_feat_size[0] * self.roi_feat_size[1]
-        self.start_bbox_type = start_bbox_type
-        self.end_bbox_type = end_bbox_type
-        assert self.start_bbox_type in ["hbb", "obb", "poly"]
-        assert self.end_bbox_type in ["hbb", "obb", "poly"]
-        self.reg_dim = get_bbox_dim(self.end_bbox_type) if reg_dim is None else reg_dim
-        assert (num_shared_convs + num_shared_fcs + num_cls_convs + num_cls_fcs + num_reg_convs + num_reg_fcs > 0)
-        if num_cls_convs > 0 or num_reg_convs > 0:
-            assert num_shared_fcs == 0
-        if not self.with_cls:
-            assert num_cls_convs == 0 and num_cls_fcs == 0
-        if not self.with_reg:
-            assert num_reg_convs == 0 and num_reg_fcs == 0
-        self.num_shared_convs = num_shared_convs
-        self.num_shared_fcs = num_shared_fcs
-        self.num_cls_convs = num_cls_convs
-        self.num_cls_fcs = num_cls_fcs
-        self.num_reg_convs = num_reg_convs
-        self.num_reg_fcs = num_reg_fcs
-        self.conv_out_channels = conv_out_channels
-        self.fc_out_channels = fc_out_channels
+        self.fc_out_channels, self.conv_out_channels = fc_out_channels, conv_out_channels
         self.bbox_coder = build_from_cfg(bbox_coder, BOXES)
         self.loss_cls = build_from_cfg(loss_cls, LOSSES)
         self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
         self.assigner = build_from_cfg(assigner, BOXES)
-        self.sampler = build_from_cfg(sampler, BOXES)
+        self.sampler = build_from_cfg(sampler, BOXES)          # carries num / pos_fraction / neg_pos_ub / add_gt
         self.bbox_roi_extractor = build_from_cfg(bbox_roi_extractor, ROI_EXTRACTORS)
-        self._init_layers()
+        # trunk: [shared convs] -> flatten -> [shared fcs]; then per branch [convs] -> [fcs] -> output layer
+        self.shared_convs, self.shared_fcs, width, flat = self._branch(num_shared_convs, num_shared_fcs, in_channels,
+                                                                       False)
+        self.cls_convs, self.cls_fcs, cls_width, cls_flat = self._branch(num_cls_convs, num_cls_fcs, width, flat)
+        self.reg_convs, self.reg_fcs, reg_width, reg_flat = self._branch(num_reg_convs, num_reg_fcs, width, flat)
+        self.fc_cls = self._output_layer(cls_width, cls_flat, num_classes + 1)
+        self.fc_reg = self._output_layer(reg_width, reg_flat,
+                                         self.reg_dim if reg_class_agnostic else self.reg_dim * num_classes)
         self.init_weights()
 
-    def _add_conv_fc_branch(self, num_branch_convs, num_branch_fcs, in_channels, is_shared=False):
-        last_layer_dim = in_channels
-        branch_convs = nn.ModuleList()
-        if num_branch_convs > 0:
-            for i in range(num_branch_convs):
-                conv_in_channels = last_layer_dim if i == 0 else self.conv_out_channels
-                branch_convs.append(ConvModule(conv_in_channels, self.conv_out_channels, 3, padding=1, conv_cfg=None,
-                                               norm_cfg=None))
-            last_layer_dim = self.conv_out_channels
-        branch_fcs = nn.ModuleList()
-        if num_branch_fcs > 0:
-            if (is_shared or self.num_shared_fcs == 0) and not self.with_avg_pool:
-                last_layer_dim *= self.roi_feat_area
-            for i in range(num_branch_fcs):
-                fc_in_channels = last_layer_dim if i == 0 else self.fc_out_channels
-                branch_fcs.append(nn.Linear(fc_in_channels, self.fc_out_channels))
-            last_layer_dim = self.fc_out_channels
-        return branch_convs, branch_fcs, last_layer_dim
+    # ------------------------------------------------------------------ layers
+    def _branch(self, n_convs, n_fcs, width, flat):
+        """`flat`: the input is already a (R, width) matrix.  Returns (convs, fcs, output width, output is flat)."""
+        convs, fcs = nn.ModuleList(), nn.ModuleList()
+        for i in range(n_convs):
+            assert not flat, "convolutions cannot follow a fully connected layer"
+            convs.append(ConvModule(width, self.conv_out_channels, 3, padding=1, conv_cfg=None, norm_cfg=None))
+            width = self.conv_out_channels
+        for i in range(n_fcs):
+            fcs.append(nn.Linear(width, self.fc_out_channels) if flat else
+                       RoIFeatureLinear(width, self.roi_feat_area, self.fc_out_channels))
+            width, flat = self.fc_out_channels, True
+        return convs, fcs, width, flat
 
-    def _init_layers(self):
-        if self.with_avg_pool:
-            self.avg_pool = nn.AvgPool2d(self.roi_feat_size)
-        self.shared_convs, self.shared_fcs, last_layer_dim = self._add_conv_fc_branch(
-            self.num_shared_convs, self.num_shared_fcs, self.in_channels, True)
-        self.shared_out_channels = last_layer_dim
-        self.cls_convs, self.cls_fcs, self.cls_last_dim = self._add_conv_fc_branch(
-            self.num_cls_convs, self.num_cls_fcs, self.shared_out_channels)
-        self.reg_convs, self.reg_fcs, self.reg_last_dim = self._add_conv_fc_branch(
-            self.num_reg_convs, self.num_reg_fcs, self.shared_out_channels)
-        if self.num_shared_fcs == 0 and not self.with_avg_pool:
-            if self.num_cls_fcs == 0:
-                self.cls_last_dim *= self.roi_feat_area
-            if self.num_reg_fcs == 0:
-                self.reg_last_dim *= self.roi_feat_area
-        self.relu = nn.ReLU(inplace=True)
-        if self.with_cls:
-            self.fc_cls = nn.Linear(self.cls_last_dim, self.num_classes + 1)
-        if self.with_reg:
-            out_dim_reg = self.reg_dim if self.reg_class_agnostic else self.reg_dim * self.num_classes
-            self.fc_reg = nn.Linear(self.reg_last_dim, out_dim_reg)
+    def _output_layer(self, width, flat, out):
+        return nn.Linear(width, out) if flat else RoIFeatureLinear(width, self.roi_feat_area, out)
 
     def init_weights(self):
-        if self.with_cls:
-            nn.init.normal_(self.fc_cls.weight, 0, 0.01)
-            nn.init.constant_(self.fc_cls.bias, 0)
-        if self.with_reg:
-            nn.init.normal_(self.fc_reg.weight, 0, 0.001)
-            nn.init.constant_(self.fc_reg.bias, 0)
-        for module_list in [self.shared_fcs, self.cls_fcs, self.reg_fcs]:
-            for m in module_list.modules():
-                if isinstance(m, nn.Linear):
-                    nn.init.xavier_uniform_(m.weight)
-                    nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01)
+        nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001)
+        nn.init.constant_(self.fc_reg.bias, 0)
+        for fcs in (self.shared_fcs, self.cls_fcs, self.reg_fcs):
+            for m in fcs:
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
 
-    def arb2roi(self, bbox_list, bbox_type="hbb"):
-        assert bbox_type in ["hbb", "obb", "poly"]
-        bbox_dim = get_bbox_dim(bbox_type)
-        rois_list = []
-        for img_id, bboxes in enumerate(bbox_list):
-            if bboxes.size(0) > 0:
-                img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
-                rois = torch.cat([img_inds, bboxes[:, :bbox_dim]], dim=-1)
-            else:
-                rois = bboxes.new_zeros((0, bbox_dim + 1))
-            rois_list.append(rois)
-        return torch.cat(rois_list, 0)
+    def _trunk(self, feats, rois):
+        x = self.bbox_roi_extractor(feats[:self.bbox_roi_extractor.num_inputs], rois)
+        for conv in self.shared_convs:
+            x = conv(x)
+        for fc in self.shared_fcs:
+            x = F.relu(fc(x))
+        outs = []
+        for convs, fcs, last in ((self.cls_convs, self.cls_fcs, self.fc_cls), (self.reg_convs, self.reg_fcs, self.fc_reg)):
+            y = x
+            for conv in convs:
+                y = conv(y)
+            for fc in fcs:
+                y = F.relu(fc(y))
+            outs.append(last(y))
+        return outs
 
-    def get_results(self, multi_bboxes, multi_scores, score_factors=None, bbox_type="hbb"):
-        bbox_dim = get_bbox_dim(bbox_type)
-        num_classes = multi_scores.size(1) - 1
-        if multi_bboxes.shape[1] > bbox_dim:
-            bboxes = multi_bboxes.view(multi_scores.size(0), -1, bbox_dim)
-        else:
-            bboxes = multi_bboxes[:, None].expand(-1, num_classes, bbox_dim)
-        scores = multi_scores[:, :-1]
-        valid_mask = scores > self.score_thresh
-        bboxes = bboxes[valid_mask]
-        if score_factors is not None:
-            scores = scores * score_factors[:, None]
-        scores = scores[valid_mask]
-        labels = valid_mask.nonzero()[:, 1]
-        if bboxes.numel() == 0:
-            return multi_bboxes.new_zeros((0, 9)), multi_bboxes.new_zeros((0,), dtype=torch.long)
-        dets = torch.cat([obb2poly(bboxes), scores.unsqueeze(1)], dim=1)
-        return dets, labels
+    # ------------------------------------------------------------------ training
+    @staticmethod
+    def _dummy_box(like):
+        return like.new_tensor([8.0, 8.0, 4.0, 4.0, 0.0])
 
-    def forward_single(self, x, sampling_results, test=False):
-        if test:
-            rois = self.arb2roi(sampling_results, bbox_type=self.start_bbox_type)
-        else:
-            rois = self.arb2roi([res.bboxes for res in sampling_results], bbox_type=self.start_bbox_type)
-        x = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
-        if self.num_shared_convs > 0:
-            for conv in self.shared_convs:
-                x = conv(x)
-        if self.num_shared_fcs > 0:
-            if self.with_avg_pool:
-                x = self.avg_pool(x)
-            x = x.flatten(1)
-            for fc in self.shared_fcs:
-                x = F.relu(fc(x))
-        x_cls = x_reg = x
-        for conv in self.cls_convs:
-            x_cls = conv(x_cls)
-        if x_cls.dim() > 2:
-            if self.with_avg_pool:
-                x_cls = self.avg_pool(x_cls)
-            x_cls = x_cls.flatten(1)
-        for fc in self.cls_fcs:
-            x_cls = F.relu(fc(x_cls))
-        for conv in self.reg_convs:
-            x_reg = conv(x_reg)
-        if x_reg.dim() > 2:
-            if self.with_avg_pool:
-                x_reg = self.avg_pool(x_reg)
-            x_reg = x_reg.flatten(1)
-        for fc in self.reg_fcs:
-            x_reg = F.relu(fc(x_reg))
-        cls_score = self.fc_cls(x_cls) if self.with_cls else None
-        bbox_pred = self.fc_reg(x_reg) if self.with_reg else None
-        return cls_score, bbox_pred, rois
+    def _image_samples(self, table, target):
+        """proposal table (P, 6) of one image -> the image's `num` sampled rows:
+        boxes (num,5), labels (num,) long, label_weights (num,), bbox_targets (num,5), bbox_weights (num,5)"""
+        gt = target["rboxes"].clone()
+        gt[:, -1] *= -1                                   # Oriented R-CNN angle convention (L459-466)
+        gt_labels = (target["labels"] - 1).long()         # 0-based, background = num_classes (L472)
+        boxes, alive = table[:, :5], table[:, 5] >= 0
+        overlaps = self.assigner.iou_calculator(gt, boxes)
+        overlaps = torch.where(alive[None, :], overlaps, torch.full_like(overlaps, -1.0))   # padding rows: ignored
+        assign = self.assigner.assign_wrt_overlaps(overlaps, gt_labels)
+        gt_inds, labels = assign.gt_inds.long(), assign.labels.long()
+        s = self.sampler
+        if s.add_gt_as_proposals:                          # the gts join the candidates, matched to themselves (L92-99)
+            k = gt.shape[0]
+            boxes = torch.cat([gt, boxes])
+            gt_inds = torch.cat([torch.arange(1, k + 1, device=gt.device), gt_inds])
+            labels = torch.cat([gt_labels, labels])
+        rows, valid, is_pos = sample_rows(gt_inds, s.num, s.pos_fraction, s.neg_pos_ub)
+        sel = torch.where(valid[:, None], boxes[rows], self._dummy_box(boxes)[None, :])
+        matched = gt[(gt_inds[rows] - 1).clamp(min=0)]
+        bg = torch.full_like(rows, self.num_classes)
+        out_labels = torch.where(is_pos, labels[rows], bg)
+        pw = 1.0 if self.pos_weight <= 0 else self.pos_weight
+        label_weights = valid.float() * torch.where(is_pos, torch.full_like(valid, pw, dtype=torch.float32),
+                                                    torch.ones_like(valid, dtype=torch.float32))
+        bbox_targets = self.bbox_coder.encode(sel, matched)
+        bbox_weights = is_pos.float()[:, None].expand(-1, self.reg_dim)
+        bbox_targets = torch.where(is_pos[:, None], bbox_targets, torch.zeros_like(bbox_targets))
+        return sel, out_labels, label_weights, bbox_targets, bbox_weights, valid
 
-    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
-             reduction_override=None):
+    def forward_train(self, feats, proposal_tables, targets):
+        per_image = [self._image_samples(t, tg) for t, tg in zip(proposal_tables, targets)]
+        rois = torch.cat([torch.cat([b.new_full((b.shape[0], 1), float(i)), b], dim=1)
+                          for i, (b, *_rest) in enumerate(per_image)])
+        labels, label_w, box_t, box_w, valid = (torch.cat([p[k] for p in per_image]) for k in range(1, 6))
+        cls_score, bbox_pred = self._trunk(feats, rois)
+        n_rows = valid.sum().float()
         losses = dict()
-        if cls_score is not None:
-            # device-side count: no host `.item()` sync (reference: oriented_head.py:L321)
-            avg_factor = torch.clamp((label_weights > 0).sum().float(), min=1.0)
-            if cls_score.numel() > 0:
-                losses["loss_cls"] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
-                                                   reduction_override=reduction_override)
-        if bbox_pred is not None:
-            bg_class_ind = self.num_classes
-            pos_inds = (labels >= 0) & (labels < bg_class_ind)
-            if bool(pos_inds.any()):
-                if self.reg_decoded_bbox:
-                    bbox_pred = self.bbox_coder.decode(rois[:, 1:], bbox_pred)
-                if self.reg_class_agnostic:
-                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), self.reg_dim)[pos_inds]
-                else:
-                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), -1, self.reg_dim)[pos_inds, labels[pos_inds]]
-                losses["orcnn_bbox_loss"] = self.loss_bbox(pos_bbox_pred, bbox_targets[pos_inds], bbox_weights[pos_inds],
-                                                           avg_factor=bbox_targets.size(0),
-                                                           reduction_override=reduction_override)
-            else:
-                losses["orcnn_bbox_loss"] = bbox_pred.sum() * 0
+        # classification: mean over the sampled rows (L318-325); regression: positives only, normalised by the
+        # number of sampled rows (L326-343) -- both as weighted sums over the fixed-size row set
+        losses["loss_cls"] = self.loss_cls(cls_score, labels, label_w,
+                                           avg_factor=torch.clamp((label_w > 0).sum().float(), min=1.0))
+        if self.reg_class_agnostic:
+            pred = bbox_pred.view(bbox_pred.size(0), self.reg_dim)
+        else:
+            cls_of_row = labels.clamp(max=self.num_classes - 1)
+            pred = bbox_pred.view(bbox_pred.size(0), -1, self.reg_dim)
+            pred = pred.gather(1, cls_of_row[:, None, None].expand(-1, 1, self.reg_dim))[:, 0]
+        losses["orcnn_bbox_loss"] = self.loss_bbox(pred, box_t, box_w, avg_factor=torch.clamp(n_rows, min=1.0))
         return losses
 
-    def get_bboxes_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels):
-        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
-        num_samples = num_pos + num_neg
-        labels = torch.full((num_samples,), self.num_classes, dtype=torch.long, device=pos_bboxes.device)
-        label_weights = pos_bboxes.new_zeros((num_samples,))
-        bbox_targets = pos_bboxes.new_zeros((num_samples, self.reg_dim))
-        bbox_weights = pos_bboxes.new_zeros((num_samples, self.reg_dim))
-        if num_pos > 0:
-            labels[:num_pos] = pos_gt_labels.long()
-            label_weights[:num_pos] = 1.0 if self.pos_weight <= 0 else self.pos_weight
-            if not self.reg_decoded_bbox:
-                pos_bbox_targets = self.bbox_coder.encode(pos_bboxes, pos_gt_bboxes)
-            else:
-                pos_bbox_targets = pos_gt_bboxes
-            bbox_targets[:num_pos, :] = pos_bbox_targets
-            bbox_weights[:num_pos, :] = 1
-        if num_neg > 0:
-            label_weights[-num_neg:] = 1.0
-        return labels, label_weights, bbox_targets, bbox_weights
-
-    def get_bboxes_targets(self, sampling_results, concat=True):
-        outputs = multi_apply(self.get_bboxes_target_single, [res.pos_bboxes for res in sampling_results],
-                              [res.neg_bboxes for res in sampling_results],
-                              [res.pos_gt_bboxes for res in sampling_results],
-                              [res.pos_gt_labels for res in sampling_results])
-        labels, label_weights, bbox_targets, bbox_weights = outputs
-        if concat:
-            labels, label_weights = torch.cat(labels, 0), torch.cat(label_weights, 0)
-            bbox_targets, bbox_weights = torch.cat(bbox_targets, 0), torch.cat(bbox_weights, 0)
-        return labels, label_weights, bbox_targets, bbox_weights
-
-    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False):
-        if isinstance(cls_score, list):
-            cls_score = sum(cls_score) / float(len(cls_score))
-        scores = F.softmax(cls_score, dim=1) if cls_score is not None else None
-        if bbox_pred is not None:
-            bboxes = self.bbox_coder.decode(rois[:, 1:], bbox_pred, max_shape=img_shape)
+    # ------------------------------------------------------------------ inference
+    def get_results(self, boxes, scores):
+        """boxes (R, 5 | 5*C) decoded, scores (R, C+1) -> (dets (k,9) [poly8, score], labels (k,))"""
+        num_classes = scores.size(1) - 1
+        if boxes.shape[1] > 5:
+            boxes = boxes.view(scores.size(0), -1, 5)
         else:
-            assert self.start_bbox_type == self.end_bbox_type
-            bboxes = rois[:, 1:].clone()
-        if rescale:
-            if isinstance(scale_factor, float):
-                scale_factor = [scale_factor for _ in range(4)]
-            scale_factor = bboxes.new_tensor(scale_factor)
-            bboxes = bboxes.view(bboxes.size(0), -1, get_bbox_dim(self.end_bbox_type))
-            if self.end_bbox_type == "hbb":
-                bboxes = bboxes / scale_factor
-            elif self.end_bbox_type == "obb":
-                bboxes = torch.cat([bboxes[..., :4] / scale_factor, bboxes[..., 4:]], dim=-1)
-            elif self.end_bbox_type == "poly":
-                bboxes = bboxes / scale_factor.repeat(2)
-            bboxes = bboxes.view(bboxes.size(0), -1)
-        return self.get_results(bboxes, scores, bbox_type=self.end_bbox_type)
+            boxes = boxes[:, None].expand(-1, num_classes, 5)
+        fg = scores[:, :-1]
+        hit = fg > self.score_thresh
+        labels = hit.nonzero()[:, 1]                  # inference output has a data-dependent length
+        if labels.numel() == 0:
+            return boxes.new_zeros((0, 9)), boxes.new_zeros((0,), dtype=torch.long)
+        return torch.cat([obb2poly(boxes[hit]), fg[hit].unsqueeze(1)], dim=1), labels
+
+    def forward_test(self, feats, proposal_tables, targets):
+        results = []
+        for i, (table, target) in enumerate(zip(proposal_tables, targets)):
+            alive = table[:, 5] >= 0
+            boxes = torch.where(alive[:, None], table[:, :5], self._dummy_box(table)[None, :])
+            rois = torch.cat([boxes.new_full((boxes.shape[0], 1), float(i)), boxes], dim=1)
+            cls_score, bbox_pred = self._trunk(feats, rois)
+            scores = F.softmax(cls_score, dim=1) * alive[:, None].float()       # padding rows score 0 everywhere
+            decoded = self.bbox_coder.decode(boxes, bbox_pred, max_shape=target["img_size"])
+            sf = target["scale_factor"]
+            sf = decoded.new_tensor([sf] * 4 if isinstance(sf, float) else sf)
+            decoded = decoded.view(decoded.size(0), -1, 5)
+            decoded = torch.cat([decoded[..., :4] / sf, decoded[..., 4:]], dim=-1).view(decoded.size(0), -1)
+            dets, labels = self.get_results(decoded, scores)
+            results.append((dets[:, :8], dets[:, 8], labels))
+        return results
 
     def forward(self, x, proposal_list, targets):
         if self.training:
-            gt_obboxes, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_obboxes_ignore = [], [], [], [], []
-            for target in targets:
-                if target["rboxes"] is None:
-                    obb = None
-                else:
-                    obb = target["rboxes"].clone()
-                    obb[:, -1] *= -1
-                if target.get("rboxes_ignore") is None or target["rboxes_ignore"].numel() == 0:
-                    obb_ignore = None
-                else:
-                    obb_ignore = target["rboxes_ignore"].clone()
-                    obb_ignore[:, -1] *= -1
-                gt_obboxes.append(obb)
-                gt_obboxes_ignore.append(obb_ignore)
-                gt_bboxes.append(target.get("hboxes"))
-                gt_bboxes_ignore.append(target.get("hboxes_ignore"))
-                gt_labels.append(target["labels"] - 1)
-            if self.with_bbox:
-                start_bbox_type, end_bbox_type = self.start_bbox_type, self.end_bbox_type
-                target_bboxes = gt_bboxes if start_bbox_type == "hbb" else gt_obboxes
-                target_bboxes_ignore = gt_bboxes_ignore if start_bbox_type == "hbb" else gt_obboxes_ignore
-                sampling_results = []
-                for i in range(len(targets)):
-                    assign_result = self.assigner.assign(proposal_list[i], target_bboxes[i], target_bboxes_ignore[i],
-                                                         gt_labels[i])
-                    sampling_result = self.sampler.sample(assign_result, proposal_list[i], target_bboxes[i],
-                                                          gt_labels[i])
-                    if start_bbox_type != end_bbox_type:
-                        if gt_obboxes[i].numel() == 0:
-                            sampling_result.pos_gt_bboxes = gt_obboxes[i].new_zeros((0, gt_obboxes[0].size(-1)))
-                        else:
-                            sampling_result.pos_gt_bboxes = gt_obboxes[i][sampling_result.pos_assigned_gt_inds, :]
-                    sampling_results.append(sampling_result)
-            scores, bbox_deltas, rois = self.forward_single(x, sampling_results, test=False)
-            bbox_targets = self.get_bboxes_targets(sampling_results)
-            return self.loss(scores, bbox_deltas, rois, *bbox_targets)
-        result = []
-        for i in range(len(targets)):
-            scores, bbox_deltas, rois = self.forward_single(x, [proposal_list[i]], test=True)
-            det_bboxes, det_labels = self.get_bboxes(rois, scores, bbox_deltas, targets[i]["img_size"],
-                                                     targets[i]["scale_factor"], rescale=True)
-            result.append((det_bboxes[:, :8], det_bboxes[:, 8], det_labels))
-        return result
+            return self.forward_train(x, proposal_list, targets)
+        return self.forward_test(x, proposal_list, targets)
 
     execute = forward

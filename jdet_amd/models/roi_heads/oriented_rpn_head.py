@@ -1,16 +1,33 @@
-"""Oriented R-CNN RPN head.  Mirrors python/jdet/models/roi_heads/oriented_rpn_head.py:L9-492: 3x3 conv +
-1x1 cls (A*num_classes) + 1x1 reg (A*6); targets by MaxIoUAssigner on horizontal anchors vs the gts'
-enclosing boxes, RandomSampler(256), MidpointOffsetCoder; proposals by per-level top-k, midpoint-offset
-decode, horizontal NMS on the enclosing boxes with the per-level coordinate offset trick."""
+"""Oriented R-CNN RPN head.
+
+Contract of python/jdet/models/roi_heads/oriented_rpn_head.py:L9-492 (constructor arguments, parameter names
+`rpn_conv / rpn_cls / rpn_reg`, loss keys, `forward(features, targets) -> (proposals per image, losses)`):
+3x3 conv + 1x1 objectness (A per location) + 1x1 regression (A*6); targets = MaxIoUAssigner on the horizontal
+anchors inside the image vs the gts' enclosing boxes, RandomSampler(256), MidpointOffsetCoder; proposals = per-level
+top-k by score, midpoint-offset decode, per-level horizontal NMS on the enclosing boxes, best `nms_post` overall.
+
+The execution is NOT the reference's (per-image index lists built with nonzero / boolean masks / randperm, each a
+device -> host round trip, L281-366, L120-226).  Every tensor here has a shape fixed by the image size and the
+number of gts:
+  * targets are dense over ALL anchors of an image: anchors outside the image get overlap -1 (so the assigner
+    ignores them and they can neither be sampled nor decide a low-quality match -- the same set the reference
+    reaches by filtering first, L300-305); the sampled subset is drawn with random keys + top-k
+    (models/boxes/fixed_shape.py) and written with a masked scatter; the sample counts that normalise the losses
+    stay on the device.
+  * proposals are always `nms_post` rows per image: [xc, yc, w, h, theta, score] sorted by score, rows beyond the
+    survivors of NMS carry score -1 (consumers ignore them).  No boolean indexing, no `.all()` / `.any()`.
+"""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from jdet_amd.models.boxes.anchor_target import anchor_inside_flags, images_to_levels
-from jdet_amd.ops.bbox_transforms import bbox2type, get_bbox_dim, get_bbox_type, obb2hbb
-from jdet_amd.ops.nms import nms_dets
-from jdet_amd.utils.general import multi_apply
+from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
+from jdet_amd.models.boxes.fixed_shape import sample_fixed, scatter_rows
+from jdet_amd.ops.bbox_transforms import obb2hbb
+from jdet_amd.ops.nms import nms_keep_mask
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
+
+INVALID_SCORE = -1.0   # score of a padding row in a proposal table
 
 
 @HEADS.register_module()
@@ -29,209 +46,130 @@ class OrientedRPNHead(nn.Module):
                  sampler=dict(type="RandomSampler", num=256, pos_fraction=0.5, neg_pos_ub=-1,
                               add_gt_as_proposals=False)):
         super().__init__()
-        self.min_bbox_size = min_bbox_size
-        self.nms_thresh = nms_thresh
-        self.nms_pre = nms_pre
-        self.nms_post = nms_post
-        self.in_channels = in_channels
-        self.feat_channels = feat_channels
-        self.num_classes = num_classes
-        self.unmap_outputs = True
-        self.bbox_type = bbox_type
-        self.reg_dim = reg_dim
-        self.pos_weight = pos_weight
-        self.use_sigmoid_cls = loss_cls.get("use_sigmoid", False)
-        self.sampling = loss_cls["type"] not in ["FocalLoss", "GHMC", "QualityFocalLoss"]
-        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
-        self.reg_decoded_bbox = reg_decoded_bbox
+        assert bbox_type == "obb" and reg_dim == 6 and not reg_decoded_bbox, "the Oriented R-CNN configuration"
+        assert loss_cls.get("use_sigmoid", False) and num_classes == 1, "objectness = one sigmoid per anchor"
+        self.in_channels, self.feat_channels, self.num_classes = in_channels, feat_channels, num_classes
+        self.min_bbox_size, self.nms_thresh, self.nms_pre, self.nms_post = min_bbox_size, nms_thresh, nms_pre, nms_post
+        self.reg_dim, self.pos_weight = reg_dim, pos_weight
         self.background_label = num_classes if background_label is None else background_label
-        assert self.background_label == 0 or self.background_label == num_classes
+        self.cls_out_channels = num_classes
         self.bbox_coder = build_from_cfg(bbox_coder, BOXES)
         self.loss_cls = build_from_cfg(loss_cls, LOSSES)
         self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
         self.assigner = build_from_cfg(assigner, BOXES)
-        self.sampler = build_from_cfg(sampler, BOXES)
+        self.sampler = build_from_cfg(sampler, BOXES)     # carries num / pos_fraction / neg_pos_ub
         self.anchor_generator = build_from_cfg(anchor_generator, BOXES)
         self.num_anchors = self.anchor_generator.num_base_anchors[0]
-        self._init_layers()
+        self.rpn_conv = nn.Conv2d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv2d(feat_channels, self.num_anchors * num_classes, 1)
+        self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 6, 1)
 
-    def _init_layers(self):
-        self.rpn_conv = nn.Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
-        self.rpn_cls = nn.Conv2d(self.feat_channels, self.num_anchors * self.num_classes, 1)
-        self.rpn_reg = nn.Conv2d(self.feat_channels, self.num_anchors * 6, 1)
-
-    @staticmethod
-    def unmap(data, count, inds, fill=0):
-        if data.dim() == 1:
-            ret = torch.full((count,), fill, dtype=data.dtype, device=data.device)
-            ret[inds.bool()] = data
-        else:
-            ret = torch.full((count,) + tuple(data.shape[1:]), fill, dtype=data.dtype, device=data.device)
-            ret[inds.bool(), :] = data
-        return ret
-
+    # ------------------------------------------------------------------ network
     def forward_single(self, x):
         x = F.relu(self.rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)
 
-    def _get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape):
-        level_ids, mlvl_scores, mlvl_valid_anchors, mlvl_bbox_pred = [], [], [], []
-        for idx in range(len(cls_scores)):
-            rpn_cls_score, rpn_bbox_pred = cls_scores[idx], bbox_preds[idx]
-            assert rpn_cls_score.shape[-2:] == rpn_bbox_pred.shape[-2:]
-            rpn_cls_score = rpn_cls_score.permute(1, 2, 0)
-            if self.use_sigmoid_cls:
-                scores = rpn_cls_score.reshape(-1).sigmoid()
-            else:
-                scores = rpn_cls_score.reshape(-1, 2).softmax(dim=1)[:, 1]
-            rpn_bbox_pred = rpn_bbox_pred.permute(1, 2, 0).reshape(-1, self.reg_dim)
-            anchors = mlvl_anchors[idx]
-            if self.nms_pre > 0 and scores.shape[0] > self.nms_pre:
-                ranked_scores, rank_inds = scores.sort(descending=True, stable=True)
-                topk_inds = rank_inds[:self.nms_pre]
-                scores = ranked_scores[:self.nms_pre]
-                rpn_bbox_pred = rpn_bbox_pred[topk_inds, :]
-                anchors = anchors[topk_inds, :]
-            mlvl_scores.append(scores)
-            mlvl_bbox_pred.append(rpn_bbox_pred)
-            mlvl_valid_anchors.append(anchors)
-            level_ids.append(torch.full((scores.size(0),), idx, dtype=torch.long, device=scores.device))
-        anchors = torch.cat(mlvl_valid_anchors)
-        rpn_bbox_pred = torch.cat(mlvl_bbox_pred)
-        scores = torch.cat(mlvl_scores)
-        proposals = self.bbox_coder.decode(anchors, rpn_bbox_pred, max_shape=img_shape)
-        ids = torch.cat(level_ids)
-        if self.min_bbox_size >= 0:
-            w, h = proposals[:, 2], proposals[:, 3]
-            valid_mask = (w > self.min_bbox_size) & (h > self.min_bbox_size)
-            if not bool(valid_mask.all()):
-                proposals, scores, ids = proposals[valid_mask], scores[valid_mask], ids[valid_mask]
-        # per-level NMS: the reference shifts each level by level_id * (max_coordinate + 1) and runs one plain NMS
-        # (L214-219); the level id goes in as a label here -- same keep set, cross-level tiles skipped
-        hproposals = obb2hbb(proposals)
-        keep = nms_dets(torch.cat([hproposals, scores.unsqueeze(1)], dim=1), self.nms_thresh, labels=ids)
-        dets = torch.cat([proposals, scores.unsqueeze(1)], dim=1)[keep, :]
-        return dets[:self.nms_post]
+    @staticmethod
+    def _per_anchor(t, width):
+        """(N, A*width, H, W) -> (N, H*W*A, width): the anchor order of grid_anchors (location-major, A fastest)"""
+        n = t.shape[0]
+        return t.permute(0, 2, 3, 1).reshape(n, -1, width)
 
-    def get_bboxes(self, cls_scores, bbox_preds, targets):
-        assert len(cls_scores) == len(bbox_preds)
-        num_levels = len(cls_scores)
-        featmap_sizes = [tuple(cls_scores[i].shape[-2:]) for i in range(num_levels)]
-        mlvl_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=cls_scores[0].device)
-        result_list = []
-        for img_id, target in enumerate(targets):
-            cls_score_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
-            bbox_pred_list = [bbox_preds[i][img_id].detach() for i in range(num_levels)]
-            result_list.append(self._get_bboxes_single(cls_score_list, bbox_pred_list, mlvl_anchors,
-                                                       target["img_size"]))
-        return result_list
-
-    def _get_targets_single(self, anchors_list, valid_flag_list, target):
-        if target["rboxes"] is None:
-            gt_bboxes = None
-        else:
-            gt_bboxes = target["rboxes"].clone()
-            gt_bboxes[:, -1] *= -1     # Oriented R-CNN angle convention
-        if target.get("rboxes_ignore") is None or target["rboxes_ignore"].numel() == 0:
-            gt_bboxes_ignore = None
-        else:
-            gt_bboxes_ignore = target["rboxes_ignore"].clone()
-            gt_bboxes_ignore[:, -1] *= -1
-        gt_labels = None
-        flat_anchors = torch.cat(anchors_list)
-        valid_flags = torch.cat(valid_flag_list)
-        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, target["img_size"][:2], allowed_border=0)
-        if not bool(inside_flags.any()):
-            return (None,) * 7
-        anchors = flat_anchors[inside_flags, :]
-        anchor_bbox_type = get_bbox_type(anchors)
-        gt_bbox_type = get_bbox_type(gt_bboxes)
-        target_bboxes = bbox2type(gt_bboxes, anchor_bbox_type)
-        target_bboxes_ignore = None if gt_bboxes_ignore is None or gt_bboxes_ignore.numel() == 0 else \
-            bbox2type(gt_bboxes_ignore, anchor_bbox_type)
-        assign_result = self.assigner.assign(anchors, target_bboxes, target_bboxes_ignore,
-                                             None if self.sampling else gt_labels)
-        sampling_result = self.sampler.sample(assign_result, anchors, target_bboxes)
-        if anchor_bbox_type != gt_bbox_type:
-            if gt_bboxes.numel() == 0:
-                sampling_result.pos_gt_bboxes = gt_bboxes.new_empty((0, get_bbox_dim(gt_bbox_type)))
-            else:
-                sampling_result.pos_gt_bboxes = gt_bboxes[sampling_result.pos_assigned_gt_inds, :]
-        num_valid_anchors = anchors.shape[0]
-        bbox_targets = anchors.new_zeros((anchors.size(0), self.reg_dim))
-        bbox_weights = anchors.new_zeros((anchors.size(0), self.reg_dim))
-        labels = torch.full((num_valid_anchors,), self.background_label, dtype=torch.long, device=anchors.device)
-        label_weights = anchors.new_zeros((num_valid_anchors,))
-        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
-        if len(pos_inds) > 0:
-            if not self.reg_decoded_bbox:
-                pos_bbox_targets = self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
-            else:
-                pos_bbox_targets = sampling_result.pos_gt_bboxes
-            bbox_targets[pos_inds, :] = pos_bbox_targets
-            bbox_weights[pos_inds, :] = 1.0
-            if gt_labels is None:
-                labels[pos_inds] = 1
-            else:
-                labels[pos_inds] = gt_labels[sampling_result.pos_assigned_gt_inds]
-            label_weights[pos_inds] = 1.0 if self.pos_weight <= 0 else self.pos_weight
-        if len(neg_inds) > 0:
-            label_weights[neg_inds] = 1.0
-        if self.unmap_outputs:
-            num_total_anchors = flat_anchors.size(0)
-            labels = self.unmap(labels, num_total_anchors, inside_flags, fill=self.background_label)
-            label_weights = self.unmap(label_weights, num_total_anchors, inside_flags)
-            bbox_targets = self.unmap(bbox_targets, num_total_anchors, inside_flags)
-            bbox_weights = self.unmap(bbox_weights, num_total_anchors, inside_flags)
-        return (labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, sampling_result)
-
-    def get_targets(self, anchor_list, valid_flag_list, targets):
-        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
-        (all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_inds_list, neg_inds_list,
-         sampling_results_list) = multi_apply(self._get_targets_single, anchor_list, valid_flag_list, targets)
-        num_total_pos = sum([max(inds.numel(), 1) for inds in pos_inds_list])
-        num_total_neg = sum([max(inds.numel(), 1) for inds in neg_inds_list])
-        return (images_to_levels(all_labels, num_level_anchors), images_to_levels(all_label_weights, num_level_anchors),
-                images_to_levels(all_bbox_targets, num_level_anchors),
-                images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
-
-    def loss_single(self, cls_score, bbox_pred, anchors, labels, label_weights, bbox_targets, bbox_weights,
-                    num_total_samples):
-        labels = labels.reshape(-1)
-        label_weights = label_weights.reshape(-1)
-        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
-        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
-        bbox_targets = bbox_targets.reshape(-1, self.reg_dim)
-        bbox_weights = bbox_weights.reshape(-1, self.reg_dim)
-        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, self.reg_dim)
-        if self.reg_decoded_bbox:
-            bbox_pred = self.bbox_coder.decode(anchors.reshape(-1, anchors.size(-1)), bbox_pred)
-        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
-        return loss_cls, loss_bbox
+    # ------------------------------------------------------------------ targets (dense over all anchors)
+    def _image_targets(self, anchors, inside, target):
+        """anchors (A,4) of all levels, inside (A,) bool -> labels (A,) long, label_weights (A,), bbox_targets (A,6),
+        bbox_weights (A,6), n_pos, n_neg (0-d device tensors)"""
+        gt_obb = target["rboxes"].clone()
+        gt_obb[:, -1] *= -1                      # Oriented R-CNN angle convention (SURVEY 9.1, L283-288)
+        gt_hbb = obb2hbb(gt_obb)                 # the assigner sees the anchors' box type (L308-312)
+        overlaps = self.assigner.iou_calculator(gt_hbb, anchors)
+        overlaps = torch.where(inside[None, :], overlaps, torch.full_like(overlaps, -1.0))
+        assign = self.assigner.assign_wrt_overlaps(overlaps, None)
+        s = self.sampler
+        pos_idx, pos_valid, neg_idx, neg_valid = sample_fixed(assign.gt_inds, s.num, s.pos_fraction, s.neg_pos_ub)
+        matched = (assign.gt_inds[pos_idx].long() - 1).clamp(min=0)
+        pos_targets = self.bbox_coder.encode(anchors[pos_idx], gt_obb[matched])
+        A = anchors.shape[0]
+        dev = anchors.device
+        labels = scatter_rows(torch.full((A,), self.background_label, dtype=torch.long, device=dev), pos_idx,
+                              pos_valid, 1)
+        pw = 1.0 if self.pos_weight <= 0 else self.pos_weight
+        label_weights = scatter_rows(torch.zeros((A,), device=dev), pos_idx, pos_valid, pw)
+        label_weights = scatter_rows(label_weights, neg_idx, neg_valid, 1.0)
+        bbox_targets = scatter_rows(torch.zeros((A, self.reg_dim), device=dev), pos_idx, pos_valid, pos_targets)
+        bbox_weights = scatter_rows(torch.zeros((A, self.reg_dim), device=dev), pos_idx, pos_valid, 1.0)
+        return labels, label_weights, bbox_targets, bbox_weights, pos_valid.sum(), neg_valid.sum()
 
     def loss(self, cls_scores, bbox_preds, targets):
-        featmap_sizes = [tuple(featmap.shape[-2:]) for featmap in cls_scores]
-        assert len(featmap_sizes) == self.anchor_generator.num_levels
-        device = cls_scores[0].device
-        multi_level_anchors = self.anchor_generator.grid_anchors(featmap_sizes, device=device)
-        anchor_list = [multi_level_anchors for _ in range(len(targets))]
-        valid_flag_list = [self.anchor_generator.valid_flags(featmap_sizes, target["pad_shape"], device=device)
-                           for target in targets]
-        labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg = \
-            self.get_targets(anchor_list, valid_flag_list, targets)
-        num_level_anchors = [anchors.size(0) for anchors in anchor_list[0]]
-        concat_anchor_list = [torch.cat(anchor_list[i]) for i in range(len(anchor_list))]
-        all_anchor_list = images_to_levels(concat_anchor_list, num_level_anchors)
-        num_total_samples = num_total_pos + num_total_neg
-        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, all_anchor_list, labels_list,
-                                              label_weights_list, bbox_targets_list, bbox_weights_list,
-                                              num_total_samples=num_total_samples)
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        dev = cls_scores[0].device
+        level_anchors = self.anchor_generator.grid_anchors(sizes, device=dev)
+        anchors = torch.cat(level_anchors)
+        per_image = []
+        for target in targets:
+            valid = torch.cat(self.anchor_generator.valid_flags(sizes, target["pad_shape"], device=dev))
+            inside = anchor_inside_flags(anchors, valid, target["img_size"][:2], allowed_border=0)
+            per_image.append(self._image_targets(anchors, inside, target))
+        labels, label_w, box_t, box_w = (torch.stack([p[k] for p in per_image]) for k in range(4))
+        # sum over images of max(#pos, 1) + max(#neg, 1)  (L376-378), kept on the device
+        n_samples = sum(torch.clamp(p[4], min=1) + torch.clamp(p[5], min=1) for p in per_image).float()
+        losses_cls, losses_bbox = [], []
+        start = 0
+        for cls, reg, lvl in zip(cls_scores, bbox_preds, level_anchors):
+            n = lvl.shape[0]
+            sl = slice(start, start + n)
+            start += n
+            score = self._per_anchor(cls, self.cls_out_channels).reshape(-1, self.cls_out_channels)
+            losses_cls.append(self.loss_cls(score, labels[:, sl].reshape(-1), label_w[:, sl].reshape(-1),
+                                            avg_factor=n_samples))
+            pred = self._per_anchor(reg, self.reg_dim).reshape(-1, self.reg_dim)
+            losses_bbox.append(self.loss_bbox(pred, box_t[:, sl].reshape(-1, self.reg_dim),
+                                              box_w[:, sl].reshape(-1, self.reg_dim), avg_factor=n_samples))
         return dict(loss_rpn_cls=losses_cls, loss_rpn_bbox=losses_bbox)
 
+    # ------------------------------------------------------------------ proposals (always nms_post rows)
+    def _image_proposals(self, level_scores, level_deltas, level_anchors, img_shape):
+        scores, deltas, anchors, ids = [], [], [], []
+        for lvl, (s, d, a) in enumerate(zip(level_scores, level_deltas, level_anchors)):
+            s = s.sigmoid()
+            if 0 < self.nms_pre < s.shape[0]:
+                s, top = torch.topk(s, self.nms_pre)          # descending; equal scores: lowest index first
+                d, a = d[top], a[top]
+            scores.append(s)
+            deltas.append(d)
+            anchors.append(a)
+            ids.append(torch.full((s.shape[0],), lvl, dtype=torch.long, device=s.device))
+        scores, ids = torch.cat(scores), torch.cat(ids)
+        boxes = self.bbox_coder.decode(torch.cat(anchors), torch.cat(deltas), max_shape=img_shape)
+        alive = torch.ones_like(scores, dtype=torch.bool)
+        if self.min_bbox_size >= 0:
+            alive = (boxes[:, 2] > self.min_bbox_size) & (boxes[:, 3] > self.min_bbox_size)
+        # dropped boxes get the lowest scores: they are visited last, suppress nothing that is kept, and are
+        # removed again below (the reference filters them out before the NMS, L207-212)
+        keep, _ = nms_keep_mask(obb2hbb(boxes), torch.where(alive, scores, torch.full_like(scores, -2.0)),
+                                self.nms_thresh, labels=ids)
+        ranked = torch.where(keep & alive, scores, torch.full_like(scores, INVALID_SCORE))
+        k = min(self.nms_post, ranked.shape[0])
+        top_scores, top = torch.topk(ranked, k)
+        table = torch.cat([boxes[top], top_scores[:, None]], dim=1)
+        if k < self.nms_post:
+            pad = table.new_zeros((self.nms_post - k, 6))
+            pad[:, 5] = INVALID_SCORE
+            table = torch.cat([table, pad])
+        return table
+
+    def get_bboxes(self, cls_scores, bbox_preds, targets):
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        level_anchors = self.anchor_generator.grid_anchors(sizes, device=cls_scores[0].device)
+        scores = [self._per_anchor(c.detach(), 1)[..., 0] for c in cls_scores]          # (N, H*W*A) per level
+        deltas = [self._per_anchor(r.detach(), self.reg_dim) for r in bbox_preds]
+        return [self._image_proposals([s[i] for s in scores], [d[i] for d in deltas], level_anchors,
+                                      target["img_size"]) for i, target in enumerate(targets)]
+
     def forward(self, features, targets):
-        outs = multi_apply(self.forward_single, features)
-        losses = self.loss(*outs, targets) if self.training else dict()
-        proposals = self.get_bboxes(*outs, targets)
-        return proposals, losses
+        outs = [self.forward_single(f) for f in features]
+        cls_scores, bbox_preds = [o[0] for o in outs], [o[1] for o in outs]
+        losses = self.loss(cls_scores, bbox_preds, targets) if self.training else dict()
+        return self.get_bboxes(cls_scores, bbox_preds, targets), losses
 
     execute = forward

@@ -9,7 +9,7 @@ L490,L547); the bilinear gather / scatter around it is hand-written:
   deform_nhwc.hip.  x NHWC, columns (B*Ho*Wo, kh*kw, Cin), so out_nhwc = cols @ Wt^T, grad_cols =
   grad_out_nhwc @ Wt and grad_Wt = grad_out_nhwc^T @ cols are plain row-major GEMMs with no layout
   copies, and the input gradient is a sorted gather (no fp atomics).
-* general path (groups / deformable groups / offset gradient): csrc/deform_arf.hip, the reference's
+* general path (groups / deformable groups / offset gradient): csrc/deform_nchw.hip, the reference's
   NCHW column layout.
 Both compute the same per-element arithmetic.
 """

@@ -10,17 +10,16 @@ import torch
 from .. import _lib as L
 
 
-def nms(boxes, scores, thresh, labels=None):
-    """`labels` (optional, e.g. FPN level ids): boxes with different labels never suppress each other -- the
-    effect of the reference's "add level_id * (max_coordinate + 1) to the boxes" trick
-    (oriented_rpn_head.py:L214-219), obtained by skipping the cross-label 64x64 tiles instead of computing their
-    zero IoUs."""
+def nms_keep_mask(boxes, scores, thresh, labels=None):
+    """greedy horizontal NMS -> bool keep mask over the input order; device-only, fixed shapes (no host sync).
+    `labels` (optional, e.g. FPN level ids): boxes with different labels never suppress each other -- the effect of
+    the reference's "add level_id * (max_coordinate + 1) to the boxes" trick (oriented_rpn_head.py:L214-219), obtained
+    by skipping the cross-label 64x64 tiles instead of computing their zero IoUs.  Returns (keep, order) with
+    `order` = indices by descending score (stable)."""
     assert boxes.shape[-1] == 4 and len(scores) == len(boxes)
     if scores.dim() == 2:
         scores = scores[:, 0]
     n = boxes.shape[0]
-    if n == 0:
-        return torch.zeros((0,), dtype=torch.long, device=boxes.device)
     L.need_device(boxes, scores)
     b = boxes.float()
     cols = [(b[:, 0] + b[:, 2]) * 0.5, (b[:, 1] + b[:, 3]) * 0.5, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
@@ -37,7 +36,15 @@ def nms(boxes, scores, thresh, labels=None):
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=b.device)
     L.check(L.lib().jdet_nms_rotated(L.ptr(obb), n, obb.shape[1], L.ptr(o32), float(thresh), 0, 0, L.ptr(keep), L.ptr(ws), wsb,
                                      L.stream_ptr(b)), "jdet_nms_rotated (horizontal)")
-    return order[keep[order].bool()]
+    return keep.bool(), order
+
+
+def nms(boxes, scores, thresh, labels=None):
+    """kept indices in descending-score order (data-dependent length: one host sync, as `jt.nms`)"""
+    if boxes.shape[0] == 0:
+        return torch.zeros((0,), dtype=torch.long, device=boxes.device)
+    keep, order = nms_keep_mask(boxes, scores, thresh, labels)
+    return order[keep[order]]
 
 
 def nms_dets(dets, thresh, labels=None):

@@ -351,16 +351,18 @@ class Runner:
         own = self.model.state_dict()
         missing = [k for k in own if k not in params and not k.endswith("num_batches_tracked")]
         unexpected = [k for k in params if k not in own]
-        mismatched = []
-        with torch.no_grad():
-            for k, v in params.items():
-                if k not in own:
-                    continue
-                t = torch.as_tensor(np.asarray(v))
-                if tuple(t.shape) != tuple(own[k].shape):
-                    mismatched.append(k)
-                    continue
-                own[k].copy_(t.to(own[k].dtype))      # keeps the parameter's own memory format
+        mismatched, good = [], {}
+        for k, v in params.items():
+            if k not in own:
+                continue
+            t = torch.as_tensor(np.asarray(v))
+            if tuple(t.shape) != tuple(own[k].shape):
+                mismatched.append(k)
+                continue
+            good[k] = t.to(own[k].dtype)
+        # through load_state_dict: modules that keep a parameter in another element order than the reference
+        # (RoIFeatureLinear) convert in their load hooks; copies keep each parameter's own memory format
+        self.model.load_state_dict(good, strict=False)
         return missing, unexpected, mismatched
 
     def _optimizer_state(self):

@@ -243,3 +243,127 @@ def delta2bbox(rois, deltas, means, stds, max_shape=None, wh_ratio_clip=16 / 100
         x1, x2 = np.clip(x1, 0, max_shape[1] - 1), np.clip(x2, 0, max_shape[1] - 1)
         y1, y2 = np.clip(y1, 0, max_shape[0] - 1), np.clip(y2, 0, max_shape[0] - 1)
     return np.stack([x1, y1, x2, y2], -1).astype(np.float32)
+
+
+# ---- Oriented R-CNN box algebra and codecs ---------------------------------------------------------------------
+def regular_theta(theta, start=-math.pi / 2, cycle=math.pi):
+    """ops/bbox_transforms.py:L499-505 (mode '180'); `%` = floor-mod"""
+    theta = np.asarray(theta, np.float32)
+    return ((theta - np.float32(start)) % np.float32(cycle) + np.float32(start)).astype(np.float32)
+
+
+def regular_obb(b):
+    """ops/bbox_transforms.py:L507-517: w >= h (else swap and add pi/2), theta wrapped into [-pi/2, pi/2)"""
+    b = np.asarray(b, np.float32)
+    x, y, w, h, t = [b[..., i] for i in range(5)]
+    m = (w > h).astype(np.float32)
+    wr = w * m + h * (1 - m)
+    hr = h * m + w * (1 - m)
+    tr = regular_theta(t * m + (t + np.float32(math.pi / 2)) * (1 - m))
+    return np.stack([x, y, wr, hr, tr], -1).astype(np.float32)
+
+
+def obb2poly(b):
+    """ops/bbox_transforms.py:L626-637: v1 = (w/2 cos, -w/2 sin), v2 = (-h/2 sin, -h/2 cos); c+v1+v2, c+v1-v2, c-v1-v2, c-v1+v2"""
+    b = np.asarray(b, np.float32)
+    c, w, h, t = b[..., :2], b[..., 2:3], b[..., 3:4], b[..., 4:5]
+    Cos, Sin = np.cos(t), np.sin(t)
+    v1 = np.concatenate([w / 2 * Cos, -w / 2 * Sin], -1)
+    v2 = np.concatenate([-h / 2 * Sin, -h / 2 * Cos], -1)
+    return np.concatenate([c + v1 + v2, c + v1 - v2, c - v1 - v2, c - v1 + v2], -1).astype(np.float32)
+
+
+def obb2hbb(b):
+    """ops/bbox_transforms.py:L640-646"""
+    b = np.asarray(b, np.float32)
+    c, w, h, t = b[..., :2], b[..., 2:3], b[..., 3:4], b[..., 4:5]
+    Cos, Sin = np.cos(t), np.sin(t)
+    bias = np.concatenate([np.abs(w / 2 * Cos) + np.abs(h / 2 * Sin), np.abs(w / 2 * Sin) + np.abs(h / 2 * Cos)], -1)
+    return np.concatenate([c - bias, c + bias], -1).astype(np.float32)
+
+
+def rectpoly2obb(p):
+    """ops/bbox_transforms.py:L575-597"""
+    p = np.asarray(p, np.float32)
+    theta = np.arctan2(-(p[..., 3] - p[..., 1]), p[..., 2] - p[..., 0])
+    Cos, Sin = np.cos(theta), np.sin(theta)
+    M = np.stack([Cos, -Sin, Sin, Cos], -1).reshape(p.shape[:-1] + (2, 2))
+    x, y = p[..., 0::2].mean(-1), p[..., 1::2].mean(-1)
+    cp = p.reshape(p.shape[:-1] + (4, 2)) - np.stack([x, y], -1)[..., None, :]
+    rp = cp @ np.swapaxes(M, -1, -2)
+    w = rp[..., 0].max(-1) - rp[..., 0].min(-1)
+    h = rp[..., 1].max(-1) - rp[..., 1].min(-1)
+    return regular_obb(np.stack([x, y, w, h, theta], -1))
+
+
+def midpoint_offset_encode(anchors, gt, means, stds):
+    """MidpointOffsetCoder.encode, models/boxes/coder.py:L332-372"""
+    a, g = np.asarray(anchors, np.float32), np.asarray(gt, np.float32)
+    px, py = (a[:, 0] + a[:, 2]) * 0.5, (a[:, 1] + a[:, 3]) * 0.5
+    pw, ph = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+    hbb, poly = obb2hbb(g), obb2poly(g)
+    gx, gy = (hbb[:, 0] + hbb[:, 2]) * 0.5, (hbb[:, 1] + hbb[:, 3]) * 0.5
+    gw, gh = hbb[:, 2] - hbb[:, 0], hbb[:, 3] - hbb[:, 1]
+    xc, yc = poly[:, 0::2], poly[:, 1::2]
+    y_min, x_max = yc.min(1, keepdims=True), xc.max(1, keepdims=True)
+    _x = xc.copy()
+    _x[np.abs(yc - y_min) > 0.1] = -1000
+    ga = _x.max(1)
+    _y = yc.copy()
+    _y[np.abs(xc - x_max) > 0.1] = -1000
+    gb = _y.max(1)
+    d = np.stack([(gx - px) / pw, (gy - py) / ph, np.log(gw / pw), np.log(gh / ph), (ga - gx) / gw, (gb - gy) / gh], -1)
+    return ((d - np.asarray(means, np.float32)[None]) / np.asarray(stds, np.float32)[None]).astype(np.float32)
+
+
+def midpoint_offset_decode(anchors, deltas, means, stds, wh_ratio_clip=16 / 1000):
+    """MidpointOffsetCoder.decode, models/boxes/coder.py:L374-437 (one box per row)"""
+    a = np.asarray(anchors, np.float32)
+    d = np.asarray(deltas, np.float32) * np.asarray(stds, np.float32)[None] + np.asarray(means, np.float32)[None]
+    dx, dy, dw, dh, da, db = [d[:, i] for i in range(6)]
+    mr = np.float32(abs(math.log(wh_ratio_clip)))
+    dw, dh = np.clip(dw, -mr, mr), np.clip(dh, -mr, mr)
+    px, py = (a[:, 0] + a[:, 2]) * 0.5, (a[:, 1] + a[:, 3]) * 0.5
+    pw, ph = a[:, 2] - a[:, 0], a[:, 3] - a[:, 1]
+    gw, gh = pw * np.exp(dw), ph * np.exp(dh)
+    gx, gy = px + pw * dx, py + ph * dy
+    x1, y1, x2, y2 = gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5
+    da, db = np.clip(da, -0.5, 0.5), np.clip(db, -0.5, 0.5)
+    ga, _ga, gb, _gb = gx + da * gw, gx - da * gw, gy + db * gh, gy - db * gh
+    polys = np.stack([ga, y1, x2, gb, _ga, y2, x1, _gb], -1)
+    center = np.stack([gx, gy] * 4, -1)
+    cp = polys - center
+    diag = np.sqrt(cp[:, 0::2] ** 2 + cp[:, 1::2] ** 2)
+    scale = diag.max(-1, keepdims=True) / diag
+    cp = cp * np.repeat(scale, 2, axis=-1)
+    return rectpoly2obb((cp + center).astype(np.float32))
+
+
+def oriented_delta_encode(rois, gt, means, stds):
+    """OrientedDeltaXYWHTCoder.encode, models/boxes/coder.py:L449-479"""
+    p, g = np.asarray(rois, np.float32), np.asarray(gt, np.float32)
+    px, py, pw, ph, pt = [p[:, i] for i in range(5)]
+    gx, gy, gw, gh, gt_ = [g[:, i] for i in range(5)]
+    d1, d2 = regular_theta(gt_ - pt), regular_theta(gt_ - pt + np.float32(math.pi / 2))
+    m = (np.abs(d1) < np.abs(d2)).astype(np.float32)
+    gwr, ghr, dt = gw * m + gh * (1 - m), gh * m + gw * (1 - m), d1 * m + d2 * (1 - m)
+    dx = (np.cos(-pt) * (gx - px) + np.sin(-pt) * (gy - py)) / pw
+    dy = (-np.sin(-pt) * (gx - px) + np.cos(-pt) * (gy - py)) / ph
+    d = np.stack([dx, dy, np.log(gwr / pw), np.log(ghr / ph), dt], -1)
+    return ((d - np.asarray(means, np.float32)[None]) / np.asarray(stds, np.float32)[None]).astype(np.float32)
+
+
+def oriented_delta_decode(rois, deltas, means, stds, wh_ratio_clip=16 / 1000):
+    """OrientedDeltaXYWHTCoder.decode, models/boxes/coder.py:L481-518; deltas (n, ncls*5) -> (n, ncls*5)"""
+    r, d = np.asarray(rois, np.float32), np.asarray(deltas, np.float32)
+    k = d.shape[1] // 5
+    d = d * np.tile(np.asarray(stds, np.float32), k)[None] + np.tile(np.asarray(means, np.float32), k)[None]
+    dx, dy, dw, dh, dt = d[:, 0::5], d[:, 1::5], d[:, 2::5], d[:, 3::5], d[:, 4::5]
+    mr = np.float32(abs(math.log(wh_ratio_clip)))
+    dw, dh = np.clip(dw, -mr, mr), np.clip(dh, -mr, mr)
+    px, py, pw, ph, pt = [r[:, i:i + 1] for i in range(5)]
+    gx = dx * pw * np.cos(-pt) - dy * ph * np.sin(-pt) + px
+    gy = dx * pw * np.sin(-pt) + dy * ph * np.cos(-pt) + py
+    gw, gh = pw * np.exp(dw), ph * np.exp(dh)
+    out = regular_obb(np.stack([gx, gy, gw, gh, regular_theta(dt + pt)], -1))
+    return out.reshape(d.shape).astype(np.float32)

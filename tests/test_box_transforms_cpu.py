@@ -186,3 +186,56 @@ def test_roitrans_modules_build():
     assert outs[0][0].shape == (1, 3, 16, 16) and outs[1][1].shape == (1, 12, 8, 8)
     a = rpn.anchor_generators[0].grid_anchors((2, 3), 4)
     assert a.shape == (18, 4) and a[0].tolist() == [-21.0, -9.0, 24.0, 12.0]   # base 4, scale 8, ratio 0.5, ctr 1.5
+
+
+# ---- Oriented R-CNN codecs: numpy restatement (oracle/box_oracle.py) vs closed forms and vs the torch host code ------
+def test_oriented_codec_oracle_closed_forms():
+    from oracle import box_oracle as BO
+    # an axis-aligned gt and the anchor equal to its enclosing box: all six midpoint-offset deltas vanish except
+    # da = +-0.5 / db = +-0.5 (top-most vertex at the right end of the top edge, right-most at the bottom end)
+    gt = np.array([[100., 80., 40., 20., 0.]], np.float32)
+    anchor = BO.obb2hbb(gt)
+    d = BO.midpoint_offset_encode(anchor, gt, [0.] * 6, [1.] * 6)
+    np.testing.assert_allclose(d[0, :4], 0, atol=1e-6)
+    assert abs(abs(d[0, 4]) - 0.5) < 1e-6 and abs(abs(d[0, 5]) - 0.5) < 1e-6
+    back = BO.midpoint_offset_decode(anchor, d, [0.] * 6, [1.] * 6)
+    np.testing.assert_allclose(back[0, :4], gt[0, :4], atol=1e-4)
+    assert abs(math.sin(back[0, 4] - gt[0, 4])) < 1e-5
+    # a gt rotated by 30 degrees: decode(encode) returns the regular form of the same rectangle
+    gt = np.array([[300., 200., 120., 50., math.pi / 6]], np.float32)
+    d = BO.midpoint_offset_encode(BO.obb2hbb(gt) + 3.0, gt, [0.] * 6, [1., 1., 1., 1., .5, .5])
+    back = BO.midpoint_offset_decode(BO.obb2hbb(gt) + 3.0, d, [0.] * 6, [1., 1., 1., 1., .5, .5], wh_ratio_clip=1e-6)
+    np.testing.assert_allclose(np.sort(BO.obb2poly(back).reshape(4, 2), 0), np.sort(BO.obb2poly(gt).reshape(4, 2), 0), atol=2e-2)
+    # OrientedDeltaXYWHT: a gt that is the RoI turned by 90 degrees encodes as (0, 0, log(h/w)... swapped) with dtheta 0
+    roi = np.array([[50., 60., 30., 10., 0.2]], np.float32)
+    gt = np.array([[50., 60., 10., 30., 0.2 + math.pi / 2]], np.float32)
+    e = BO.oriented_delta_encode(roi, gt, [0.] * 5, [1.] * 5)
+    np.testing.assert_allclose(e, 0, atol=2e-6)
+    # regular_theta / regular_obb wrap cases (bbox_transforms.py:L499-517)
+    np.testing.assert_allclose(BO.regular_theta(np.array([math.pi / 2, -math.pi / 2, 2.0, -2.0], np.float32)),
+                               [-math.pi / 2, -math.pi / 2, 2.0 - math.pi, math.pi - 2.0], atol=1e-6)
+    np.testing.assert_allclose(BO.regular_obb(np.array([[0, 0, 2, 5, 0.3]], np.float32)),
+                               [[0, 0, 5, 2, 0.3 + math.pi / 2 - math.pi]], atol=1e-6)
+
+
+def test_oriented_codecs_torch_equals_oracle():
+    from oracle import box_oracle as BO
+    p, g = _rand_obbs(300, 4).numpy(), _rand_obbs(300, 5).numpy()
+    p[:, 4] = np.random.default_rng(6).uniform(-3, 3, 300)      # proposals with unregularised angles
+    means, stds = [0.] * 5, [0.1, 0.1, 0.2, 0.2, 0.1]
+    coder = OrientedDeltaXYWHTCoder(target_means=means, target_stds=stds)
+    e = coder.encode(torch.from_numpy(p), torch.from_numpy(g)).numpy()
+    np.testing.assert_allclose(e, BO.oriented_delta_encode(p, g, means, stds), rtol=1e-4, atol=1e-4)
+    d = np.random.default_rng(7).normal(0, 1, (300, 15)).astype(np.float32)
+    dec = coder.decode(torch.from_numpy(p), torch.from_numpy(d)).numpy()
+    np.testing.assert_allclose(dec, BO.oriented_delta_decode(p, d, means, stds), rtol=1e-4, atol=2e-3)
+    m6, s6 = [0.] * 6, [1., 1., 1., 1., .5, .5]
+    anchors = BO.obb2hbb(g) + np.random.default_rng(8).uniform(-8, 8, (300, 4)).astype(np.float32)
+    mc = MidpointOffsetCoder(target_means=m6, target_stds=s6)
+    e6 = mc.encode(torch.from_numpy(anchors), torch.from_numpy(g)).numpy()
+    np.testing.assert_allclose(e6, BO.midpoint_offset_encode(anchors, g, m6, s6), rtol=1e-4, atol=1e-4)
+    d6 = np.random.default_rng(9).normal(0, 0.4, (300, 6)).astype(np.float32)
+    dec6 = mc.decode(torch.from_numpy(anchors), torch.from_numpy(d6)).numpy()
+    ref6 = BO.midpoint_offset_decode(anchors, d6, m6, s6)
+    np.testing.assert_allclose(dec6[:, :4], ref6[:, :4], rtol=1e-4, atol=2e-3)
+    assert np.abs(np.sin(dec6[:, 4] - ref6[:, 4])).max() < 1e-3

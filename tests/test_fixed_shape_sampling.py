@@ -1,0 +1,107 @@
+"""CPU: the fixed-shape samplers (models/boxes/fixed_shape.py) draw what RandomSampler / RandomSamplerRotated draw
+(python/jdet/models/boxes/sampler.py:L133-233) -- counts, classes, no duplicates, neg_pos_ub, add_gt_as_proposals
+layout, seeding -- without data-dependent shapes."""
+import numpy as np
+import pytest
+import torch
+
+from jdet_amd.models.boxes.fixed_shape import sample_fixed, sample_rows, scatter_rows
+
+
+def _gt_inds(n, n_pos, n_ign, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.zeros(n, dtype=torch.int32)
+    perm = torch.randperm(n, generator=g)
+    v[perm[:n_pos]] = torch.randint(1, 9, (n_pos,), generator=g, dtype=torch.int32)
+    v[perm[n_pos:n_pos + n_ign]] = -1
+    return v
+
+
+@pytest.mark.parametrize("n,n_pos,n_ign,num,frac,ub", [
+    (5000, 40, 100, 256, 0.5, -1),      # fewer positives than asked: negatives fill up to num
+    (5000, 400, 100, 256, 0.5, -1),     # more positives than asked: exactly num * frac
+    (5000, 0, 0, 256, 0.5, -1),         # no positive
+    (300, 10, 280, 256, 0.5, -1),       # negatives run out
+    (5000, 30, 0, 512, 0.25, 3),        # neg_pos_ub: at most 3 * n_pos negatives
+    (5000, 0, 0, 512, 0.25, 3),         # ... with no positive: int(ub * max(1, 0)) = ub
+    (100, 60, 0, 512, 0.25, -1),        # fewer candidates than num
+])
+def test_counts_classes_and_uniqueness(n, n_pos, n_ign, num, frac, ub):
+    gi = _gt_inds(n, n_pos, n_ign)
+    g = torch.Generator().manual_seed(5)
+    pi, pv, ni, nv = sample_fixed(gi, num, frac, ub, generator=g)
+    P = int(num * frac)
+    exp_pos = min(n_pos, P)
+    n_neg_avail = n - n_pos - n_ign
+    exp_neg = num - exp_pos
+    if ub >= 0:
+        exp_neg = min(exp_neg, int(ub * max(1, exp_pos)))
+    exp_neg = min(exp_neg, n_neg_avail)
+    assert pi.numel() == min(P, n) and ni.numel() == min(num, n)
+    assert int(pv.sum()) == exp_pos and int(nv.sum()) == exp_neg
+    sp, sn = pi[pv], ni[nv]
+    assert (gi[sp] > 0).all() and (gi[sn] == 0).all()
+    assert sp.unique().numel() == sp.numel() and sn.unique().numel() == sn.numel()
+    rows, valid, is_pos = sample_rows(gi, num, frac, ub, generator=torch.Generator().manual_seed(5))
+    assert rows.numel() == valid.numel() == is_pos.numel() == num
+    assert int(valid.sum()) == exp_pos + exp_neg and int(is_pos.sum()) == exp_pos
+    assert is_pos[:exp_pos].all() and not is_pos[exp_pos:].any()          # positives first, then negatives
+    assert valid[:exp_pos + exp_neg].all() and not valid[exp_pos + exp_neg:].any()
+    assert set(rows[is_pos].tolist()) == set(sp.tolist())
+    assert (rows >= 0).all() and (rows < n).all()
+
+
+def test_seeded_and_uniform():
+    gi = _gt_inds(2000, 500, 0, seed=3)
+    a = sample_fixed(gi, 128, 0.5, generator=torch.Generator().manual_seed(11))
+    b = sample_fixed(gi, 128, 0.5, generator=torch.Generator().manual_seed(11))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    c = sample_fixed(gi, 128, 0.5, generator=torch.Generator().manual_seed(12))
+    assert not torch.equal(a[0], c[0])
+    # every positive is picked with probability 64 / 500: the empirical frequencies are flat
+    hits = torch.zeros(2000)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(400):
+        pi, pv, _, _ = sample_fixed(gi, 128, 0.5, generator=g)
+        hits[pi[pv]] += 1
+    f = hits[gi > 0] / 400
+    assert abs(float(f.mean()) - 64 / 500) < 1e-6 and float(f.std()) < 0.03 and float(f.min()) > 0.05
+
+
+def test_add_gt_as_proposals_layout():
+    """gts are prepended with gt_inds 1..K (AssignResult.add_gt_, sampler.py:L92-99): all of them are positives and
+    (being at most num * frac) all of them are sampled"""
+    K = 12
+    gi = torch.cat([torch.arange(1, K + 1, dtype=torch.int32), _gt_inds(2000, 30, 50)])
+    rows, valid, is_pos = sample_rows(gi, 512, 0.25, generator=torch.Generator().manual_seed(1))
+    assert set(range(K)) <= set(rows[is_pos].tolist())
+    assert int(is_pos.sum()) == K + 30 and int(valid.sum()) == 512
+
+
+def test_scatter_rows_ignores_invalid_rows():
+    dst = torch.zeros(10, 3)
+    idx = torch.tensor([2, 5, 5, 9])
+    valid = torch.tensor([True, False, True, False])
+    out = scatter_rows(dst, idx, valid, torch.arange(12.).view(4, 3))
+    assert torch.equal(out[2], torch.tensor([0., 1., 2.])) and torch.equal(out[5], torch.tensor([6., 7., 8.]))
+    assert float(out[9].abs().sum()) == 0 and float(out.sum()) == 3 + 21
+    lab = scatter_rows(torch.zeros(10, dtype=torch.long), idx, valid, 1)
+    assert lab.tolist() == [0, 0, 1, 0, 0, 1, 0, 0, 0, 0]
+
+
+def test_roi_feature_linear_keeps_reference_checkpoint_order():
+    """the first FC layer of the RoI heads stores its weight for channels-last features; state dicts carry the
+    reference's (c, ph, pw) column order in both directions"""
+    from jdet_amd.models.roi_heads.oriented_head import RoIFeatureLinear
+    torch.manual_seed(0)
+    C, O, R = 6, 5, 3
+    ref = torch.nn.Linear(C * 4, O)
+    m = RoIFeatureLinear(C, 4, O)
+    m.load_state_dict(ref.state_dict())
+    x = torch.randn(R, C, 2, 2)
+    y_ref = ref(x.flatten(1))
+    assert torch.allclose(m(x), y_ref, atol=1e-6)
+    assert torch.allclose(m(x.contiguous(memory_format=torch.channels_last)), y_ref, atol=1e-6)
+    sd = m.state_dict()
+    assert torch.equal(sd["weight"], ref.weight) and torch.equal(sd["bias"], ref.bias)
+    assert not torch.equal(m.weight, ref.weight)       # ... while the parameter itself is stored permuted

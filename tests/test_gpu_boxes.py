@@ -249,3 +249,57 @@ def test_fused_smooth_l1_matches_tensor_program(dev):
     q = torch.randn(10, 5, device=dev, requires_grad=True)
     a = SmoothL1Loss(beta=1.0)(q, torch.zeros(10, 5, device=dev))
     torch.testing.assert_close(a, smooth_l1_loss(q.detach(), torch.zeros(10, 5, device=dev), beta=1.0), rtol=1e-5, atol=1e-6)
+
+
+# ---- fused Oriented R-CNN codecs (csrc/box_codec_oriented.hip) vs the numpy restatement -----------------------
+def _obbs(n, seed, regular=True):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(50, 950, (n, 2))
+    wh = np.exp(rng.uniform(np.log(8), np.log(300), (n, 2)))
+    if regular:
+        wh = np.stack([wh.max(1), wh.min(1)], 1)
+    th = rng.uniform(-math.pi / 2, math.pi / 2, (n, 1)) if regular else rng.uniform(-4, 4, (n, 1))
+    return np.concatenate([c, wh, th], 1).astype(np.float32)
+
+
+def test_fused_oriented_codecs_vs_oracle(dev):
+    """MidpointOffsetCoder / OrientedDeltaXYWHTCoder on the device = one launch each; values = the numpy restatement
+    of coder.py:L332-518 (tolerances: libm differences of cos / sin / exp / log / atan2 between numpy and HIP)"""
+    from jdet_amd.models.boxes.coder import MidpointOffsetCoder, OrientedDeltaXYWHTCoder
+    from oracle import box_oracle as BO
+    n = 4000
+    g = _obbs(n, 1)
+    anchors = BO.obb2hbb(g) + np.random.default_rng(2).uniform(-12, 12, (n, 4)).astype(np.float32)
+    m6, s6 = [0.] * 6, [1., 1., 1., 1., .5, .5]
+    mc = MidpointOffsetCoder(target_means=m6, target_stds=s6)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    e = mc.encode(t(anchors), t(g)).cpu().numpy()
+    np.testing.assert_allclose(e, BO.midpoint_offset_encode(anchors, g, m6, s6), rtol=2e-5, atol=2e-5)
+    d6 = np.random.default_rng(3).normal(0, 0.5, (n, 6)).astype(np.float32)
+    dec = mc.decode(t(anchors), t(d6)).cpu().numpy()
+    ref = BO.midpoint_offset_decode(anchors, d6, m6, s6)
+    assert dec.shape == (n, 5)
+    np.testing.assert_allclose(dec[:, :4], ref[:, :4], rtol=1e-4, atol=5e-3)
+    assert np.abs(np.sin(dec[:, 4] - ref[:, 4])).max() < 2e-4          # angles equal modulo pi (wrap at the interval end)
+    assert (dec[:, 2] >= dec[:, 3]).all() and (dec[:, 4] >= -math.pi / 2 - 1e-6).all() and (dec[:, 4] < math.pi / 2 + 1e-6).all()
+    m5, s5 = [0.] * 5, [0.1, 0.1, 0.2, 0.2, 0.1]
+    oc = OrientedDeltaXYWHTCoder(target_means=m5, target_stds=s5)
+    p = _obbs(n, 4, regular=False)
+    e5 = oc.encode(t(p), t(g)).cpu().numpy()
+    r5 = BO.oriented_delta_encode(p, g, m5, s5)
+    # rows where |dtheta1| and |dtheta2| tie within rounding may pick the other branch: exclude exact ties only
+    d1 = np.abs(BO.regular_theta(g[:, 4] - p[:, 4]))
+    d2 = np.abs(BO.regular_theta(g[:, 4] - p[:, 4] + np.float32(math.pi / 2)))
+    ok = np.abs(d1 - d2) > 1e-4
+    assert ok.mean() > 0.999
+    np.testing.assert_allclose(e5[ok], r5[ok], rtol=2e-4, atol=2e-4)
+    d15 = np.random.default_rng(5).normal(0, 1, (n, 15)).astype(np.float32)
+    dec15 = oc.decode(t(p), t(d15)).cpu().numpy().reshape(n, 3, 5)
+    ref15 = BO.oriented_delta_decode(p, d15, m5, s5).reshape(n, 3, 5)
+    np.testing.assert_allclose(dec15[..., :4], ref15[..., :4], rtol=1e-4, atol=5e-3)
+    assert np.abs(np.sin(dec15[..., 4] - ref15[..., 4])).max() < 2e-4
+    # round trip on the device: decode(encode(gt)) is the gt again (both regular)
+    back = oc.decode(t(p), oc.encode(t(p), t(g)), wh_ratio_clip=1e-6).cpu().numpy()
+    np.testing.assert_allclose(back[:, :4], g[:, :4], rtol=2e-4, atol=2e-2)
+    assert np.abs(np.sin(back[:, 4] - g[:, 4])).max() < 2e-4
+    assert mc.decode(t(anchors[:0]), t(d6[:0])).shape == (0, 5)

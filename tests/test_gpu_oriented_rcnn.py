@@ -145,3 +145,50 @@ def test_level_labels_equal_the_coordinate_offset_trick(dev):
     a = nms(boxes + off[:, None], scores, 0.7)
     b = nms(boxes, scores, 0.7, labels=ids)
     assert torch.equal(a, b) and 0 < a.numel() < n
+
+
+def test_train_step_runs_without_host_synchronisation(dev):
+    """the Oriented R-CNN train step (RPN targets, proposals, RCNN sampling / targets, RoIAlign, losses,
+    backward) has fixed shapes and no device -> host round trip: with PyTorch's sync debug mode set to "error" any
+    nonzero / boolean-mask indexing / .item() / bool(tensor) in the step raises."""
+    from jdet_amd.runner import synthetic_batch
+    from jdet_amd.utils.general import parse_losses
+    m = _orcnn(dev)
+    m.train()
+    images, targets = synthetic_batch(2, 256, dev, seed=5, num_gts=10)
+    total, _ = parse_losses(m(images, targets))      # warm-up: anchor caches, MIOpen workspaces
+    total.backward()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        total, parsed = parse_losses(m(images, targets))
+        total.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(total)
+
+
+def test_proposal_table_contract(dev):
+    """OrientedRPNHead hands over `nms_post` rows per image, sorted by score, padding rows with score -1; the kept rows
+    are what the reference's dynamic-shape pipeline keeps (same NMS on the same boxes)"""
+    from jdet_amd.models.roi_heads import OrientedRPNHead
+    from jdet_amd.ops.bbox_transforms import obb2hbb
+    from jdet_amd.ops.nms import nms
+    torch.manual_seed(3)
+    rpn = OrientedRPNHead(in_channels=16, feat_channels=16, nms_pre=300, nms_post=200).to(dev).eval()
+    feats = [torch.randn(2, 16, 128 // s, 128 // s, device=dev) for s in (4, 8, 16, 32, 64)]
+    targets = [dict(img_size=(128, 128), pad_shape=(128, 128))] * 2
+    with torch.no_grad():
+        tables, losses = rpn(feats, targets)
+    assert losses == {} and len(tables) == 2
+    for tab in tables:
+        assert tab.shape == (200, 6)
+        s = tab[:, 5]
+        alive = s >= 0
+        n = int(alive.sum())
+        assert 0 < n <= 200 and bool(alive[:n].all()) and not bool(alive[n:].any())
+        assert bool((s[:n - 1] >= s[1:n]).all())
+        # idempotence: the survivors do not suppress each other under the same rule (per level unknown here, so
+        # check with the plain rule on all: a subset of what per-level NMS allows may remain -> only sanity bounds)
+        keep = nms(obb2hbb(tab[:n, :5]), s[:n], 0.8)
+        assert keep.numel() <= n
