@@ -24,6 +24,7 @@ from torch import nn
 from jdet_amd.models.boxes.fixed_shape import sample_rows
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.ops.bbox_transforms import get_bbox_dim, obb2poly
+from jdet_amd.utils.general import const_like
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, ROI_EXTRACTORS, build_from_cfg
 
 
@@ -163,7 +164,7 @@ class OrientedHead(nn.Module):
     # ------------------------------------------------------------------ training
     @staticmethod
     def _dummy_box(like):
-        return like.new_tensor([8.0, 8.0, 4.0, 4.0, 0.0])
+        return const_like([8.0, 8.0, 4.0, 4.0, 0.0], like)
 
     def _image_samples(self, table, target):
         """proposal table (P, 6) of one image -> the image's `num` sampled rows:
@@ -241,7 +242,7 @@ class OrientedHead(nn.Module):
             scores = F.softmax(cls_score, dim=1) * alive[:, None].float()       # padding rows score 0 everywhere
             decoded = self.bbox_coder.decode(boxes, bbox_pred, max_shape=target["img_size"])
             sf = target["scale_factor"]
-            sf = decoded.new_tensor([sf] * 4 if isinstance(sf, float) else sf)
+            sf = const_like([sf] * 4 if isinstance(sf, (int, float)) else sf, decoded)
             decoded = decoded.view(decoded.size(0), -1, 5)
             decoded = torch.cat([decoded[..., :4] / sf, decoded[..., 4:]], dim=-1).view(decoded.size(0), -1)
             dets, labels = self.get_results(decoded, scores)

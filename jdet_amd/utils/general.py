@@ -60,3 +60,17 @@ def sync(data, reduce_mode="mean", to_numpy=True):
         return d
 
     return _sync(data)
+
+
+_CONST_CACHE = {}
+
+
+def const_like(values, like):
+    """small constant tensor on `like`'s device / dtype, uploaded once and cached: `like.new_tensor([...])` in a step
+    is a synchronous host -> device copy (and cannot be captured in a HIP graph)"""
+    key = (tuple(float(v) for v in values), like.device, like.dtype)
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        t = torch.tensor(key[0], dtype=like.dtype, device=like.device)
+        _CONST_CACHE[key] = t
+    return t
