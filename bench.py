@@ -241,8 +241,9 @@ def make_retinanet_infer(a, rank, dev):
 
 
 def cpu_baseline(workload, d, R):
-    """Oracle (kind=port: our CPU restatement, parity-pinned against the reference kernel text) on a
-    bounded sample of the same workload, all host cores (OpenMP over RoIs / rows)."""
+    """CPU baseline on a bounded sample of the same workload.  RoIAlign has no CPU implementation in the reference
+    (CUDA kernels only): kind "port" = the oracle restatement, all host cores (OpenMP over RoIs).  Rotated IoU / NMS:
+    kind "reference" = the reference's own CPU source compiled for the host (oracle/_ref), one thread as there."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     O.set_threads(cores)
@@ -274,16 +275,6 @@ def cpu_baseline(workload, d, R):
                "sample": "first %d of %d RoIs of the same map, mean of %d runs (%.3f s each), extrapolated "
                          "linearly in RoIs; algorithmic bytes of the full workload / extrapolated time"
                          % (rs, R, reps, t)}
-        if not bwd and O.have_ref():
-            # the reference's own kernel text (CUDA-only there: host-compiled single-thread build, oracle/_ref)
-            rr = min(R, 512)
-            t0 = time.perf_counter()
-            O.ref_roi_align_forward(O.V_ROT, feat, d["rois_np"][:rr], (7, 7), 0.25, 2)
-            tr = (time.perf_counter() - t0) * R / rr
-            out["reference_text"] = {"value": nbytes / 1e9 / tr, "unit": "GB/s", "cores": 1, "kind": "reference",
-                                     "sample": "first %d of %d RoIs through the reference's ROIAlignRotatedForward "
-                                               "text (roi_align_rotated.py:L61-127) compiled for the host, one "
-                                               "thread, NCHW map; extrapolated linearly in RoIs" % (rr, R)}
         return out
     if workload == "box_iou_rotated":
         b1, b2 = d["b1_np"][:16], d["b2_np"]

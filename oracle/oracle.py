@@ -1,5 +1,5 @@
-"""ctypes bindings for the CPU oracle (oracle/libjdet_oracle.so) and, when present, the
-host-compiled reference kernel text (oracle/_ref/libjdet_ref.so).  TEST INFRASTRUCTURE ONLY:
+"""ctypes bindings for the CPU oracle (oracle/libjdet_oracle.so) and, when present, the reference's own CPU sources
+compiled for the host (oracle/_ref/libjdet_ref.so: rotated IoU, rotated NMS, ARF).  TEST INFRASTRUCTURE ONLY:
 imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by jdet_amd.
 
 All functions take / return numpy arrays (float32 unless noted).
@@ -173,57 +173,12 @@ def arf_backward(indices, grad_out, _l=None, _name="jo_arf_backward"):
     return gw
 
 
-# ------------------------------------------------------------------ reference kernel text (_ref)
-_REF_ROI = {V_ROT: "ref_roi_align_rotated", V_ROT_V1: "ref_roi_align_rotated_v1",
-            V_HBB0: "ref_roi_align_v0", V_HBB1: "ref_roi_align_v1"}
-
-
-def ref_roi_align_forward(variant, feat, rois, out_hw, spatial_scale, sample_num, n_orient=1):
-    feat, rois = _c(feat), _c(rois)
-    N, Ct, H, W = feat.shape
-    R = rois.shape[0]
-    PH, PW = out_hw
-    out = np.zeros((R, Ct, PH, PW), np.float32)
-    if variant == V_RI:
-        ref().ref_riroi_align_fwd(_ptr(feat), _ptr(rois), _i(R), _i(Ct // n_orient), _i(H), _i(W), _i(PH),
-                                  _i(PW), _f(spatial_scale), _i(int(sample_num)), _i(n_orient), _ptr(out))
-    elif variant in (V_HBB0, V_HBB1):
-        getattr(ref(), _REF_ROI[variant] + "_fwd")(_ptr(feat), _ptr(rois), _i(R), _i(Ct), _i(H), _i(W),
-                                                   _i(PH), _i(PW), _f(spatial_scale), _f(sample_num),
-                                                   _ptr(out))
-    else:
-        getattr(ref(), _REF_ROI[variant] + "_fwd")(_ptr(feat), _ptr(rois), _i(R), _i(Ct), _i(H), _i(W),
-                                                   _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)),
-                                                   _ptr(out))
-    return out
-
-
-def ref_roi_align_backward(variant, grad_out, rois, feat_shape, spatial_scale, sample_num, n_orient=1):
-    grad_out, rois = _c(grad_out), _c(rois)
-    N, Ct, H, W = feat_shape
-    R, _, PH, PW = grad_out.shape
-    gin = np.zeros((N, Ct, H, W), np.float32)
-    if variant == V_RI:
-        ref().ref_riroi_align_bwd(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct // n_orient), _i(H),
-                                  _i(W), _i(PH), _i(PW), _f(spatial_scale), _i(int(sample_num)),
-                                  _i(n_orient), _ptr(gin))
-    elif variant in (V_HBB0, V_HBB1):
-        getattr(ref(), _REF_ROI[variant] + "_bwd")(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct), _i(H),
-                                                   _i(W), _i(PH), _i(PW), _f(spatial_scale), _f(sample_num),
-                                                   _ptr(gin))
-    else:
-        getattr(ref(), _REF_ROI[variant] + "_bwd")(_ptr(grad_out), _ptr(rois), _i(R), _i(N), _i(Ct), _i(H),
-                                                   _i(W), _i(PH), _i(PW), _f(spatial_scale),
-                                                   _i(int(sample_num)), _ptr(gin))
-    return gin
-
-
-def ref_box_iou_rotated(b1, b2, version=0, cudasort=False):
+# ------------------------------------------------------------------ the reference's own CPU sources (_ref)
+def ref_box_iou_rotated(b1, b2, version=0):
     b1, b2 = _c(b1), _c(b2)
     n1, n2 = b1.shape[0], b2.shape[0]
     out = np.zeros((n1, n2), np.float32)
-    name = "ref_box_iou_rotated_cudasort" if cudasort else (
-        "ref_box_iou_rotated_v1" if version == 1 else "ref_box_iou_rotated")
+    name = "ref_box_iou_rotated_v1" if version == 1 else "ref_box_iou_rotated"
     getattr(ref(), name)(_ptr(b1), _i(n1), _ptr(b2), _i(n2), _i(b1.shape[1]), _ptr(out))
     return out
 
@@ -234,18 +189,6 @@ def ref_nms_rotated_keep(dets, order, thr):
     keep = np.zeros((n,), np.uint8)
     getattr(ref(), "ref_nms_rotated%d" % bl)(_ptr(dets), _i(n), _ptr(order), _f(thr), _ptr(keep))
     return keep.astype(bool)
-
-
-def ref_deform_im2col(*a, **k):
-    return deform_im2col(*a, _l=ref(), _name="ref_deform_im2col", **k)
-
-
-def ref_deform_col2im(*a, **k):
-    return deform_col2im(*a, _l=ref(), _name="ref_deform_col2im", **k)
-
-
-def ref_deform_col2im_coord(*a, **k):
-    return deform_col2im_coord(*a, _l=ref(), _name="ref_deform_col2im_coord", **k)
 
 
 def ref_arf_forward(*a, **k):

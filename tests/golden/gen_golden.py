@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/*.npz from the reference's own kernel text (oracle/_ref).
+"""Generate tests/golden/*.npz.
 
 Run in the build container only (needs /root/reference):
     python oracle/build_ref.py && python tests/golden/gen_golden.py
-Each .npz holds seeded inputs and the outputs of the host-compiled reference kernels
-(see oracle/build_ref.py for exactly what "host-compiled" means).  The fixtures are data:
-no reference source text is stored.  While generating, the CPU restatement in
-oracle/jdet_oracle.cpp is checked against the same outputs (bit-exact for forward / IoU /
-NMS / im2col / ARF; backward kernels are order-dependent sums so 1e-5 there) -- that is
-how the oracle is pinned.
+Each .npz holds seeded inputs and expected outputs.  The fixtures are data: no reference source text is stored.
+Two kinds of expected outputs, said per file:
+  * box_iou_rotated.npz (v0, v1), nms_rotated.npz, arf.npz: outputs of the reference's OWN CPU sources compiled here
+    (oracle/_ref, see oracle/build_ref.py).  While generating, the restatement oracle/jdet_oracle.cpp is checked
+    against them bit for bit -- that is how those parts of the oracle are pinned.  (`iou_cudasort` in
+    box_iou_rotated.npz, the reference's CUDA exchange-sort ordering, is restatement output: CUDA-only source.)
+  * roi_align.npz, riroi_align.npz, deform_conv.npz: the reference has these operators as CUDA kernels only, which
+    cannot be built in this image without stand-ins for the CUDA built-ins (not done: build_ref.py).  The expected
+    outputs are those of the restatement oracle/jdet_oracle.cpp, written only AFTER the restatement has passed the
+    closed-form pins (tests/closed_form.py: affine-map RoIAlign for all five dialects, integer-offset DeformConv --
+    neither involves the restatement's own arithmetic).  They serve the GPU box, where they are the regression
+    vectors of the HIP kernels.
 """
 import os
 import sys
@@ -56,11 +62,9 @@ def gen_roi_align():
         rr = hrois if variant in (O.V_HBB0, O.V_HBB1) else rois
         for (ph, pw), s in (((7, 7), 2), ((3, 5), 0), ((2, 2), 3)):
             key = "%s_%dx%d_s%d" % (nm, ph, pw, s)
-            y = O.ref_roi_align_forward(variant, feat, rr, (ph, pw), scale, s)
-            exact(O.roi_align_forward(variant, feat, rr, (ph, pw), scale, s), y, "fwd " + key)
+            y = O.roi_align_forward(variant, feat, rr, (ph, pw), scale, s)
             g = rng.standard_normal(y.shape).astype(np.float32)
-            gi = O.ref_roi_align_backward(variant, g, rr, feat.shape, scale, s)
-            close(O.roi_align_backward(variant, g, rr, feat.shape, scale, s), gi, "bwd " + key)
+            gi = O.roi_align_backward(variant, g, rr, feat.shape, scale, s)
             out["y_" + key] = y
             out["g_" + key] = g
             out["gi_" + key] = gi
@@ -74,11 +78,9 @@ def gen_roi_align():
     out = {"feat": feat, "rois": rois_ri, "scale": np.float32(scale), "nO": np.int32(nO)}
     for (ph, pw), s in (((7, 7), 2), ((3, 5), 0)):
         key = "ri_%dx%d_s%d" % (ph, pw, s)
-        y = O.ref_roi_align_forward(O.V_RI, feat, rois_ri, (ph, pw), scale, s, nO)
-        exact(O.roi_align_forward(O.V_RI, feat, rois_ri, (ph, pw), scale, s, nO), y, "fwd " + key)
+        y = O.roi_align_forward(O.V_RI, feat, rois_ri, (ph, pw), scale, s, nO)
         g = rng.standard_normal(y.shape).astype(np.float32)
-        gi = O.ref_roi_align_backward(O.V_RI, g, rois_ri, feat.shape, scale, s, nO)
-        close(O.roi_align_backward(O.V_RI, g, rois_ri, feat.shape, scale, s, nO), gi, "bwd " + key)
+        gi = O.roi_align_backward(O.V_RI, g, rois_ri, feat.shape, scale, s, nO)
         out["y_" + key] = y
         out["g_" + key] = g
         out["gi_" + key] = gi
@@ -91,10 +93,9 @@ def gen_iou_nms():
     b2 = np.concatenate([I.clustered_obbs(rng, 30), I.special_obbs()[::-1]], 0)
     iou = O.ref_box_iou_rotated(b1, b2, 0)
     iou_v1 = O.ref_box_iou_rotated(b1, b2, 1)
-    iou_cs = O.ref_box_iou_rotated(b1, b2, 0, cudasort=True)
+    iou_cs = O.box_iou_rotated(b1, b2, 0, 1)     # CUDA exchange-sort ordering: restatement (CUDA-only source)
     exact(O.box_iou_rotated(b1, b2, 0, 0), iou, "iou v0")
     exact(O.box_iou_rotated(b1, b2, 1, 0), iou_v1, "iou v1")
-    exact(O.box_iou_rotated(b1, b2, 0, 1), iou_cs, "iou v0 cuda-sort")
     # reference literal (box_iou_rotated.py:L513-516): analytically [[1,0.2],[0.2,1]]
     lit = np.asarray([[0, 0, 1, 1, 0], [0.5, 0.5, 1, 2, 0]], np.float32)
     iou_lit = O.ref_box_iou_rotated(lit, lit, 0)
@@ -148,13 +149,10 @@ def gen_dcn_arf():
         off = (rng.standard_normal((B, dg * 2 * k * k, Ho, Wo)) * 2.0).astype(np.float32)
         off.flat[::7] = np.round(off.flat[::7])  # integer offsets hit the floor()/edge branches
         a = (k, k, (pad, pad), (stride, stride), (dil, dil), dg)
-        col = O.ref_deform_im2col(im, off, *a)
-        exact(O.deform_im2col(im, off, *a), col, "im2col " + nm)
+        col = O.deform_im2col(im, off, *a)
         gcol = rng.standard_normal(col.shape).astype(np.float32)
-        gim = O.ref_deform_col2im(gcol, off, im.shape, *a)
-        close(O.deform_col2im(gcol, off, im.shape, *a), gim, "col2im " + nm)
-        goff = O.ref_deform_col2im_coord(gcol, im, off, *a)
-        exact(O.deform_col2im_coord(gcol, im, off, *a), goff, "col2im_coord " + nm)
+        gim = O.deform_col2im(gcol, off, im.shape, *a)
+        goff = O.deform_col2im_coord(gcol, im, off, *a)
         out.update({"im_" + nm: im, "off_" + nm: off, "cfg_" + nm: np.asarray([k, pad, stride, dil, dg]),
                     "col_" + nm: col, "gcol_" + nm: gcol, "gim_" + nm: gim, "goff_" + nm: goff})
     save("deform_conv", **out)
@@ -178,7 +176,13 @@ if __name__ == "__main__":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import build_ref
         build_ref.build()
+    # the restatement-generated fixtures are written only behind the closed-form pins
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_closed_form_cpu.py"), "-q", "-x"],
+                       cwd=ROOT)
+    if r.returncode != 0:
+        raise SystemExit("closed-form pins failed: not writing restatement fixtures")
     gen_roi_align()
     gen_iou_nms()
     gen_dcn_arf()
-    print("all oracle-vs-reference checks passed")
+    print("all checks passed")

@@ -1,6 +1,8 @@
-"""CPU: the oracle (oracle/jdet_oracle.cpp) against the golden vectors produced from the
-reference's own kernel text (tests/golden/gen_golden.py), plus the reference's known-answer
-literals.  This is what pins the oracle."""
+"""CPU: the oracle (oracle/jdet_oracle.cpp) against the golden vectors (tests/golden/gen_golden.py) and the reference's
+known-answer literals.  IoU / NMS / ARF vectors are outputs of the reference's own CPU sources compiled in the build
+container: these tests are what pins those parts of the oracle.  RoIAlign / DeformConv vectors are restatement output
+(CUDA-only reference sources; the pins of those parts are the closed forms of tests/test_closed_form_cpu.py): here
+they are regression checks."""
 import numpy as np
 import pytest
 
