@@ -139,18 +139,19 @@ def make_step(workload, d):
         gp, rp, ip = grad.data_ptr(), rois.data_ptr(), gin.data_ptr()
         use_ws = os.environ.get("JDET_BENCH_BWD_ATOMIC", "0") != "1"
         wsb = lib.jdet_roi_align_backward_workspace(0, R, 1, 256, 256, 256, 7, 7, 2) if use_ws else 0
-        ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=feat.device)
+        # kept workspace, zero-filled once: the call hands its counters back zeroed (what the autograd path does)
+        ws = torch.zeros((max(wsb, 8),), dtype=torch.uint8, device=feat.device)
         wp = ws.data_ptr() if wsb else None
 
         def step():
             if cl and wsb:
-                L.check(lib.jdet_roi_align_backward_cl(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, ip, wp, wsb,
+                L.check(lib.jdet_roi_align_backward_cl(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, ip, wp, wsb, 1,
                                                        L.stream_ptr(feat)), "bwd_cl")
             else:
                 L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, None, ip,
                                                     wp, wsb, L.stream_ptr(feat)), "bwd")
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
-        return step, nbytes / 1e9, "GB", nbytes, "roi_align backward (geom+taps+scan+fill%s+gather | atomic)" % ("" if cl else "+transpose"), "f32"
+        return step, nbytes / 1e9, "GB", nbytes, "roi_align backward (taps+scan+fill%s+gather | atomic)" % ("" if cl else "+zero+transpose"), "f32"
     if workload == "box_iou_rotated":
         from jdet_amd.ops import box_iou_rotated
         b1, b2 = d["b1"], d["b2"]

@@ -141,10 +141,16 @@ int jdet_roi_align_backward(int variant, const float* grad_out, const float* roi
 
 /* Same as jdet_roi_align_backward for a channels-last gradient grad_out_cl (R, PH, PW, C): the sorted gather
  * reads it directly (no (R,C,bin) -> (R,bin,C) transpose pass).  Needs the workspace of
- * jdet_roi_align_backward_workspace(); returns JDET_E_UNSUPPORTED where that query returns 0. */
+ * jdet_roi_align_backward_workspace(); returns JDET_E_UNSUPPORTED where that query returns 0.
+ * workspace_clean != 0: the caller keeps this workspace between calls and guarantees that its first
+ * jdet_roi_align_backward_clean_bytes() bytes are zero on entry (zero-fill it once); the call hands them back zeroed
+ * (stream order), so no memset launch is needed.  workspace_clean == 0: any content, the call zeroes what it needs. */
+size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, int C, int H, int W, int PH, int PW,
+                                           int sample_num);
 int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N, int C,
                                int H, int W, int PH, int PW, float spatial_scale, int sample_num,
-                               float* grad_in_nhwc, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+                               float* grad_in_nhwc, void* workspace, size_t workspace_bytes, int workspace_clean,
+                               jdet_stream_t stream);
 
 /* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and
  * box_iou_rotated_v1.py:L512 (the python-side "too small" zeroing L515-523 stays in the

@@ -166,9 +166,9 @@ JDET_API int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset
   CsrWs w = csr_carve(workspace, npix, ntaps);
   if (workspace_bytes < w.bytes) return JDET_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  int he = jdet_zero_async(w.counts, sizeof(int) * npix, st);
+  int he = jdet_zero_async(w.counts, csr_zero_bytes(npix), st);
   if (he) return he;
   hipLaunchKernelGGL(deform_taps_kernel, dim3((unsigned)((nitems + 255) / 256)), dim3(256), 0, st, offset, p, nitems,
                      w.tap_key, w.tap_pos, w.tap_w, w.counts);
-  return csr_finish_and_gather(w, npix, ntaps, 4, grad_cols, C, grad_x_nhwc, st);
+  return csr_finish_and_gather(w, npix, ntaps, 4, grad_cols, C, grad_x_nhwc, W, B * H, st);
 }

@@ -8,15 +8,18 @@
 // Every contribution is  grad_in[pixel, c] += w * grad_out[roi, c, bin]  with (pixel, w) independent
 // of c.  So the scatter is inverted once per launch on the (roi, sample, tap) index space -- 1.57 M
 // entries instead of 401 M atomics -- and then GATHERED:
-//   K0  per-RoI geometry (double-precision trig) once per RoI
-//   K1  tap list: one lane per (roi, sample): pixel key + weight/count of its 4 taps; integer
-//       atomicAdd into a per-pixel counter (CSR row lengths) whose return value is the tap's place in its row
-//   K2  exclusive scan of the N*H*W counters (two launches)
+//   K1  tap list, one workgroup per RoI: geometry (double-precision trig) once, then one lane per (bin, sample):
+//       pixel key + weight/count of its 4 taps; integer atomicAdd into a per-pixel counter (CSR row lengths)
+//       whose return value is the tap's place in its row
+//   K2  exclusive scan of the N*H*W counters (one launch; the last workgroup scans the tile totals)
 //   K3  fill: entry = (roi*nbins + bin, w) written at row offset + place (no second round of atomics)
-//   K4  grad_out (R,C,PH,PW) -> gT (R, PH*PW, C): makes a contribution's channel vector contiguous
+//   K4  (only for an (R,C,PH,PW) gradient) grad_out -> gT (R, PH*PW, C): a contribution's channel vector becomes
+//       contiguous; a channels-last gradient (jdet_roi_align_backward_cl) is that matrix already
 //   K5  gather: one wave per pixel, lanes = channels (dwordx4), loop over the pixel's entries,
 //       acc += w * gT[entry]; ONE coalesced store per pixel (zeros for untouched pixels, so no
-//       memset pass).  fp32 adds happen in registers.
+//       memset pass).  fp32 adds happen in registers.  2x2 pixel patches per workgroup, 8-row stripes round-robin
+//       over the XCDs (csr_gather.h); the counters are zeroed again on the way out, so a caller that keeps the
+//       workspace (workspace_clean) pays no memset launch.
 // Summation order inside a pixel follows slot order (integer-atomic order), i.e. it is as
 // order-nondeterministic in the last bits as the reference's atomics; values agree to fp32 tolerance.
 // RiRoIAlign and adaptive sampling (sample_num <= 0, unbounded samples per bin) keep the atomic path.
@@ -28,74 +31,76 @@ namespace {
 using namespace jdet_roi;
 using namespace jdet_csr;
 
-// per-RoI geometry once (double-precision trig included) instead of once per sample
+// One workgroup per RoI: thread 0 does the geometry (double-precision trig included) once, then one lane per
+// (bin, sample) lists its 4 taps.
 template <int VARIANT>
-__global__ __launch_bounds__(256) void bwd_geom_kernel(const float* __restrict__ rois, int R, int PH, int PW,
+__global__ __launch_bounds__(256) void bwd_taps_kernel(const float* __restrict__ rois, int H, int W, int PH, int PW,
                                                       float spatial_scale, int sample_num,
-                                                      RoiGeom* __restrict__ geoms) {
-  constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < R) geoms[r] = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
-}
-
-template <int VARIANT>
-__global__ __launch_bounds__(256) void bwd_taps_kernel(const RoiGeom* __restrict__ geoms, int R, int H, int W,
-                                                      int PH, int PW, int sample_num,
                                                       int* __restrict__ tap_key, int* __restrict__ tap_pos,
                                                       float* __restrict__ tap_w, int* __restrict__ counts) {
+  constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
+  __shared__ RoiGeom s_geom;
+  const int r = blockIdx.x;
+  if (threadIdx.x == 0)
+    s_geom = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
+  __syncthreads();
+  const RoiGeom g = s_geom;
   const int nbins = PH * PW, spb = sample_num * sample_num, S = nbins * spb;
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)R * S) return;
-  const int r = (int)(t / S), s = (int)(t % S);
-  const int bin = s / spb, rr = s % spb;
-  const RoiGeom g = geoms[r];
-  const Sample sm = make_sample<VARIANT>(g, bin / PW, bin % PW, rr / sample_num, rr % sample_num, H, W);
-  const int o[4] = {sm.o1, sm.o2, sm.o3, sm.o4};
-  float w[4] = {sm.w1 / g.count, sm.w2 / g.count, sm.w3 / g.count, sm.w4 / g.count};
-  bool first[4] = {true, true, true, true};
-  if (spb == 4) {
-    // the 4 samples of a bin are 4 consecutive lanes (R*S and S are multiples of 4): taps of the bin that hit the
-    // same pixel read the same grad_out row -> one entry with the summed weight (as in the forward kernel; 58 % of
-    // the taps survive on the bench RoIs), fewer rows for the gather to fetch
-    const int lane = threadIdx.x & 63, q = lane & 3, qbase = lane & ~3;
-    const float w0[4] = {w[0], w[1], w[2], w[3]};
+  const int base = g.batch * H * W;
+  for (int s = threadIdx.x; s < S; s += 256) {   // S % 4 == 0 when spb == 4: a quad of lanes enters or leaves together
+    const int bin = s / spb, rr = s % spb;
+    const long t = (long)r * S + s;
+    const Sample sm = make_sample<VARIANT>(g, bin / PW, bin % PW, rr / sample_num, rr % sample_num, H, W);
+    const int o[4] = {sm.o1, sm.o2, sm.o3, sm.o4};
+    float w[4] = {sm.w1 / g.count, sm.w2 / g.count, sm.w3 / g.count, sm.w4 / g.count};
+    bool first[4] = {true, true, true, true};
+    if (spb == 4) {
+      // the 4 samples of a bin are 4 consecutive lanes: taps of the bin that hit the same pixel read the same
+      // grad_out row -> one entry with the summed weight (as in the forward kernel; 58 % of the taps survive on the
+      // bench RoIs), fewer rows for the gather to fetch
+      const int lane = threadIdx.x & 63, q = lane & 3, qbase = lane & ~3;
+      const float w0[4] = {w[0], w[1], w[2], w[3]};
 #pragma unroll
-    for (int k = 1; k < 4; k++)
+      for (int k = 1; k < 4; k++)
 #pragma unroll
-      for (int j = 0; j < k; j++)
-        if (o[j] == o[k]) {
-          w[j] += w0[k];
-          first[k] = false;
-        }
+        for (int j = 0; j < k; j++)
+          if (o[j] == o[k]) {
+            w[j] += w0[k];
+            first[k] = false;
+          }
 #pragma unroll
-    for (int d = 1; d < 4; d++) {
-      const int src = qbase | ((q + d) & 3);
-      const bool earlier = ((q + d) & 3) < q;
-      const int ov = __shfl(sm.valid, src, 64);
+      for (int d = 1; d < 4; d++) {
+        const int src = qbase | ((q + d) & 3);
+        const bool earlier = ((q + d) & 3) < q;
+        const int ov = __shfl(sm.valid, src, 64);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int oo = __shfl(o[j], src, 64);
-        const float ww = __shfl(w0[j], src, 64);
+        for (int j = 0; j < 4; j++) {
+          const int oo = __shfl(o[j], src, 64);
+          const float ww = __shfl(w0[j], src, 64);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const bool same = ov && oo == o[k];
-          w[k] += same ? ww : 0.f;
-          first[k] = first[k] && !(same && earlier);
+          for (int k = 0; k < 4; k++) {
+            const bool same = ov && oo == o[k];
+            w[k] += same ? ww : 0.f;
+            first[k] = first[k] && !(same && earlier);
+          }
         }
       }
     }
-  }
-  const int base = g.batch * H * W;
+    int4 key4, pos4;
+    int* key = &key4.x;
+    int* pos = &pos4.x;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    int key = -1, pos = 0;
-    if (sm.valid && first[k] && w[k] != 0.f && g.batch >= 0) {  // batch < 0: masked RoI
-      key = base + o[k];
-      pos = atomicAdd(&counts[key], 1);
+    for (int k = 0; k < 4; k++) {
+      key[k] = -1;
+      pos[k] = 0;
+      if (sm.valid && first[k] && w[k] != 0.f && g.batch >= 0) {  // batch < 0: masked RoI
+        key[k] = base + o[k];
+        pos[k] = atomicAdd(&counts[key[k]], 1);
+      }
     }
-    tap_key[t * 4 + k] = key;
-    tap_pos[t * 4 + k] = pos;
-    tap_w[t * 4 + k] = w[k];
+    reinterpret_cast<int4*>(tap_key)[t] = key4;
+    reinterpret_cast<int4*>(tap_pos)[t] = pos4;
+    reinterpret_cast<float4*>(tap_w)[t] = make_float4(w[0], w[1], w[2], w[3]);
   }
 }
 
@@ -121,24 +126,23 @@ __global__ __launch_bounds__(256) void bwd_transpose_kernel(const float* __restr
 
 template <int VARIANT>
 int run_gather(const float* grad_out, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,
-               float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, hipStream_t st) {
+               float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, bool ws_clean,
+               hipStream_t st) {
   const int nbins = PH * PW, spb = sample_num * sample_num;
   const long npix = (long)N * H * W, ntaps = (long)R * nbins * spb * 4;
   CsrWs w = csr_carve(ws, npix, ntaps);
   float* gT = (float*)((char*)ws + w.bytes);
-  RoiGeom* geoms = (RoiGeom*)((char*)gT + align256(sizeof(float) * (size_t)R * nbins * C));
-  int he = jdet_zero_async(w.counts, sizeof(int) * npix, st);
-  if (he) return he;
-  hipLaunchKernelGGL((bwd_geom_kernel<VARIANT>), dim3((R + 255) / 256), dim3(256), 0, st, rois, R, PH, PW, scale,
-                     sample_num, geoms);
-  const long nsamp = (long)R * nbins * spb;
-  hipLaunchKernelGGL((bwd_taps_kernel<VARIANT>), dim3((unsigned)((nsamp + 255) / 256)), dim3(256), 0, st, geoms, R,
-                     H, W, PH, PW, sample_num, w.tap_key, w.tap_pos, w.tap_w, w.counts);
+  if (!ws_clean) {   // workspace of unknown content: zero the row counters + ticket (a clean one is handed back clean)
+    int he = jdet_zero_async(w.counts, csr_zero_bytes(npix), st);
+    if (he) return he;
+  }
+  hipLaunchKernelGGL((bwd_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale, sample_num,
+                     w.tap_key, w.tap_pos, w.tap_w, w.counts);
   if (grad_out_cl)   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
-    return csr_finish_and_gather(w, npix, ntaps, spb * 4, grad_out, C, grad_in, st);
+    return csr_finish_and_gather(w, npix, ntaps, spb * 4, grad_out, C, grad_in, W, N * H, st);
   dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
   hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
-  return csr_finish_and_gather(w, npix, ntaps, spb * 4, gT, C, grad_in, st);
+  return csr_finish_and_gather(w, npix, ntaps, spb * 4, gT, C, grad_in, W, N * H, st);
 }
 
 }  // namespace
@@ -159,22 +163,29 @@ JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int
                                                  int sample_num) {
   if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
   const long npix = (long)N * H * W, ntaps = (long)R * PH * PW * sample_num * sample_num * 4;
-  return csr_carve(nullptr, npix, ntaps).bytes + align256(sizeof(float) * (size_t)R * PH * PW * C) +
-         align256(sizeof(RoiGeom) * (size_t)R);
+  return csr_carve(nullptr, npix, ntaps).bytes + align256(sizeof(float) * (size_t)R * PH * PW * C);
+}
+
+// Bytes at the start of the workspace that the gather path needs zero on entry and leaves zero on return (the row
+// counters + the scan's ticket); 0 when the shape is served by the atomic path.
+JDET_API size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, int C, int H, int W, int PH, int PW,
+                                                   int sample_num) {
+  if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
+  return csr_zero_bytes((long)N * H * W);
 }
 
 static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,
                            int PH, int PW, float spatial_scale, int sample_num, float* grad_in, void* workspace,
-                           bool grad_out_cl, hipStream_t st) {
+                           bool grad_out_cl, bool ws_clean, hipStream_t st) {
   switch (variant) {
     case JDET_ROI_ROTATED:
-      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
     case JDET_ROI_ROTATED_V1:
-      return run_gather<JDET_ROI_ROTATED_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+      return run_gather<JDET_ROI_ROTATED_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
     case JDET_ROI_HBB_V0:
-      return run_gather<JDET_ROI_HBB_V0>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+      return run_gather<JDET_ROI_HBB_V0>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
     default:
-      return run_gather<JDET_ROI_HBB_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, st);
+      return run_gather<JDET_ROI_HBB_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
   }
 }
 
@@ -192,13 +203,13 @@ JDET_API int jdet_roi_align_backward(int variant, const float* grad_out, const f
       !rois || !grad_in)
     return JDET_E_BADARG;
   return backward_gather(variant, grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
-                         workspace, false, st);
+                         workspace, false, false, st);
 }
 
 JDET_API int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N,
                                         int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
                                         float* grad_in, void* workspace, size_t workspace_bytes,
-                                        jdet_stream_t stream) {
+                                        int workspace_clean, jdet_stream_t stream) {
   if (variant < 0 || variant > 4 || N < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || R < 0)
     return JDET_E_BADARG;
   const size_t need = jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num);
@@ -206,5 +217,5 @@ JDET_API int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, c
   if (!workspace || workspace_bytes < need) return JDET_E_WORKSPACE;
   if (!grad_out_cl || !rois || !grad_in) return JDET_E_BADARG;
   return backward_gather(variant, grad_out_cl, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
-                         workspace, true, (hipStream_t)stream);
+                         workspace, true, workspace_clean != 0, (hipStream_t)stream);
 }

@@ -71,3 +71,96 @@ def scatter_rows(dst, idx, valid, values):
         values = torch.full((idx.numel(),) + tuple(dst.shape[1:]), values, dtype=dst.dtype, device=dst.device)
     buf[tgt] = values.to(dst.dtype)
     return buf[:A]
+
+
+def masked_overlaps(iou_calculator, gts, boxes, alive):
+    """IoU matrix (K, A) with the columns of dead candidates (padding rows, anchors outside the image) at -1: the
+    assigner ignores them and they can neither be sampled nor decide a low-quality match -- the same set the
+    reference reaches by removing those candidates first."""
+    overlaps = iou_calculator(gts, boxes)
+    return torch.where(alive[None, :], overlaps, torch.full_like(overlaps, -1.0))
+
+
+def dense_anchor_targets(anchors, inside, gts_for_assign, gts_for_encode, assigner, sampler, encode, reg_dim,
+                         background_label, pos_weight):
+    """RPN targets of one image, dense over ALL anchors (anchor_target.py:L96-160 with the index lists replaced by
+    masks): labels (A,) long [1 on sampled positives, `background_label` elsewhere], label_weights (A,), bbox_targets
+    (A, reg_dim), bbox_weights (A, reg_dim), number of sampled positives / negatives (0-d device tensors).
+    `encode(anchors (P, .), gts (P, .))` is the head's coder."""
+    assign = assigner.assign_wrt_overlaps(masked_overlaps(assigner.iou_calculator, gts_for_assign, anchors, inside),
+                                          None)
+    pos_idx, pos_valid, neg_idx, neg_valid = sample_fixed(assign.gt_inds, sampler.num, sampler.pos_fraction,
+                                                          sampler.neg_pos_ub)
+    matched = (assign.gt_inds[pos_idx].long() - 1).clamp(min=0)
+    pos_targets = encode(anchors[pos_idx], gts_for_encode[matched])
+    A, dev = anchors.shape[0], anchors.device
+    labels = scatter_rows(torch.full((A,), background_label, dtype=torch.long, device=dev), pos_idx, pos_valid, 1)
+    pw = 1.0 if pos_weight <= 0 else pos_weight
+    label_weights = scatter_rows(torch.zeros((A,), device=dev), pos_idx, pos_valid, pw)
+    label_weights = scatter_rows(label_weights, neg_idx, neg_valid, 1.0)
+    bbox_targets = scatter_rows(torch.zeros((A, reg_dim), device=dev), pos_idx, pos_valid, pos_targets)
+    bbox_weights = scatter_rows(torch.zeros((A, reg_dim), device=dev), pos_idx, pos_valid, 1.0)
+    return labels, label_weights, bbox_targets, bbox_weights, pos_valid.sum(), neg_valid.sum()
+
+
+def proposal_table(boxes, scores, level_ids, level_sizes, alive, nms_thresh, nms_post_per_level, rows,
+                   nms_across_levels=False, invalid_score=-1.0, payload=None):
+    """Candidates of all levels (each level's slice sorted by descending score) -> a table of exactly `rows` rows
+    [box..., score] sorted by score; rows beyond the survivors carry `invalid_score`.  Per-level NMS is ONE launch
+    (the level id as label); `nms_post_per_level` caps the survivors of each level (None: no cap); with
+    `nms_across_levels` a second, label-free pass runs over the survivors.  `boxes`: horizontal (x1,y1,x2,y2), what
+    the NMS sees; `payload` (default: the boxes): what the table rows carry."""
+    from jdet_amd.ops.nms import nms_keep_mask
+    low = torch.full_like(scores, -2.0)
+    # dropped boxes get the lowest scores: visited last, they suppress nothing that is kept, and are removed below
+    keep, _ = nms_keep_mask(boxes, torch.where(alive, scores, low), nms_thresh, labels=level_ids)
+    ok = keep & alive
+    if nms_post_per_level is not None:
+        ranks, start = [], 0
+        for n in level_sizes:
+            ranks.append(torch.cumsum(ok[start:start + n].to(torch.int32), 0))
+            start += n
+        ok = ok & (torch.cat(ranks) <= nms_post_per_level)
+    if nms_across_levels:
+        keep2, _ = nms_keep_mask(boxes, torch.where(ok, scores, low), nms_thresh)
+        ok = ok & keep2
+    ranked = torch.where(ok, scores, torch.full_like(scores, invalid_score))
+    k = min(rows, ranked.shape[0])
+    top_scores, top = torch.topk(ranked, k)
+    table = torch.cat([(boxes if payload is None else payload)[top], top_scores[:, None]], dim=1)
+    if k < rows:
+        pad = table.new_zeros((rows - k, table.shape[1]))
+        pad[:, -1] = invalid_score
+        table = torch.cat([table, pad])
+    return table
+
+
+class StageRows:
+    """The sampled rows of one image for one R-CNN stage, always `num` of them (SamplingResult of the reference,
+    sampler.py:L6-38, with masks instead of index lists): boxes (num, D) [invalid rows: a small dummy box],
+    valid / is_pos / is_gt (num,) bool, labels (num,) long [background 0 off the positives], matched (num,) long
+    [index of the assigned gt, 0 off the positives]."""
+
+    def __init__(self, boxes, valid, is_pos, is_gt, labels, matched):
+        self.boxes, self.valid, self.is_pos, self.is_gt, self.labels, self.matched = \
+            boxes, valid, is_pos, is_gt, labels, matched
+
+
+def sample_stage_rows(cands, alive, gts, gt_labels, assigner, sampler, dummy_box, background_label=0):
+    """assign + sample one image's candidates (P, D) against its gts (K, D) with fixed shapes; `alive` (P,) marks
+    the real candidates.  `sampler.add_gt_as_proposals`: the gts join the candidates, matched to themselves."""
+    assign = assigner.assign_wrt_overlaps(masked_overlaps(assigner.iou_calculator, gts, cands, alive), gt_labels)
+    gt_inds, labels = assign.gt_inds.long(), assign.labels.long()
+    is_gt = torch.zeros_like(alive)
+    boxes = cands
+    if sampler.add_gt_as_proposals:
+        k = gts.shape[0]
+        boxes = torch.cat([gts.to(cands.dtype), cands])
+        gt_inds = torch.cat([torch.arange(1, k + 1, device=gts.device), gt_inds])
+        labels = torch.cat([gt_labels.long(), labels])
+        is_gt = torch.cat([torch.ones((k,), dtype=torch.bool, device=gts.device), is_gt])
+    rows, valid, is_pos = sample_rows(gt_inds, sampler.num, sampler.pos_fraction, sampler.neg_pos_ub)
+    sel = torch.where(valid[:, None], boxes[rows], dummy_box[None, :])
+    matched = torch.where(is_pos, gt_inds[rows] - 1, torch.zeros_like(rows))
+    row_labels = torch.where(is_pos, labels[rows], torch.full_like(rows, background_label))
+    return StageRows(sel, valid, is_pos, is_gt[rows] & valid, row_labels, matched)

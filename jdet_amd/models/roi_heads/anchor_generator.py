@@ -57,10 +57,14 @@ class AnchorGenerator:
         feat_h, feat_w = featmap_size
         valid_h, valid_w = valid_size
         assert valid_h <= feat_h and valid_w <= feat_w
+        key = ("valid", tuple(featmap_size), tuple(valid_size), str(device))
+        if key in self._cache:
+            return self._cache[key]
         valid_x = torch.zeros(feat_w, dtype=torch.bool, device=device)
         valid_y = torch.zeros(feat_h, dtype=torch.bool, device=device)
         valid_x[:valid_w] = True
         valid_y[:valid_h] = True
         valid_xx, valid_yy = self._meshgrid(valid_x, valid_y)
         valid = valid_xx & valid_yy
-        return valid[:, None].expand(valid.shape[0], self.num_base_anchors).reshape(-1)
+        self._cache[key] = valid[:, None].expand(valid.shape[0], self.num_base_anchors).reshape(-1)
+        return self._cache[key]

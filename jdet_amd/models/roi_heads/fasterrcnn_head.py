@@ -1,40 +1,47 @@
-"""Anchor head and the Faster R-CNN RPN head used by RoI-Transformer.  Mirrors
-python/jdet/models/roi_heads/fasterrcnn_head.py: `AnchorHead` L15-244, `FasterrcnnHead` L247-329.
-Proposals: per level sigmoid scores -> top nms_pre -> delta2bbox -> horizontal NMS (`jt.nms`, parity
-unpinned, see ops/nms.py) -> nms_post; levels concatenated -> top max_num by score."""
+"""The RPN of RoI-Transformer (horizontal anchors, horizontal proposals).
+
+Contract of python/jdet/models/roi_heads/fasterrcnn_head.py (`AnchorHead` L15-244, `FasterrcnnHead` L247-329):
+constructor arguments, parameter names `rpn_conv / rpn_cls / rpn_reg`, loss keys, per-level single-level anchor
+generators; targets = MaxIoUAssigner on the anchors inside the image (+ `allowed_border`) vs the horizontal gts,
+RandomSampler(256), `bbox2delta`; proposals = per level sigmoid score -> top `nms_pre` -> `delta2bbox` -> horizontal
+NMS -> best `nms_post` of the level; all levels -> best `max_num` by score (or a second NMS with `nms_across_levels`).
+
+The execution is fixed-shape and never waits for the device (the reference builds index lists per image with
+nonzero / boolean masks / randperm, L281-329 and anchor_target.py:L96-160):
+  * targets are dense over ALL anchors of an image (models/boxes/fixed_shape.py: `dense_anchor_targets`);
+  * `get_bboxes` returns one (max_num, 5) table per image, [x1, y1, x2, y2, score] sorted by score, rows beyond the
+    survivors of the NMS carry score -1 (`INVALID_SCORE`); per-level NMS is one launch with the level as label.
+"""
 import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
 
-from jdet_amd.ops.bbox_transforms import delta2bbox
-from jdet_amd.ops.nms import nms_dets
-from jdet_amd.utils.general import multi_apply
-from jdet_amd.utils.registry import HEADS, LOSSES, build_from_cfg
+from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
+from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
+from jdet_amd.ops.bbox_transforms import bbox2delta, delta2bbox
+from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
 
 from .anchor_generator import AnchorGenerator
-from .anchor_target import anchor_target
+
+INVALID_SCORE = -1.0   # score of a padding row in a proposal table
 
 
 @HEADS.register_module()
 class AnchorHead(nn.Module):
+    """Per-level anchors + a (cls, reg) 1x1 pair; the dense targets / losses every subclass shares."""
+
     def __init__(self, num_classes, in_channels, feat_channels=256, anchor_scales=[8, 16, 32],
                  anchor_ratios=[0.5, 1.0, 2.0], anchor_strides=[4, 8, 16, 32, 64], anchor_base_sizes=None,
                  target_means=(.0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0),
                  loss_cls=dict(type="CrossEntropyLoss", loss_weight=1.0, use_sigmoid=True),
                  loss_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0)):
         super().__init__()
-        self.in_channels = in_channels
-        self.num_classes = num_classes
-        self.feat_channels = feat_channels
-        self.anchor_scales = anchor_scales
-        self.anchor_ratios = anchor_ratios
-        self.anchor_strides = anchor_strides
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, num_classes, feat_channels
+        self.anchor_scales, self.anchor_ratios, self.anchor_strides = anchor_scales, anchor_ratios, anchor_strides
         self.anchor_base_sizes = list(anchor_strides) if anchor_base_sizes is None else anchor_base_sizes
-        self.target_means = target_means
-        self.target_stds = target_stds
+        self.target_means, self.target_stds = target_means, target_stds
         self.use_sigmoid_cls = loss_cls.get("use_sigmoid", False)
-        self.sampling = loss_cls["type"] not in ["FocalLoss", "GHMC"]
         self.cls_out_channels = num_classes - 1 if self.use_sigmoid_cls else num_classes
         self.loss_cls = build_from_cfg(loss_cls, LOSSES)
         self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
@@ -58,77 +65,92 @@ class AnchorHead(nn.Module):
         return self.conv_cls(x), self.conv_reg(x)
 
     def forward(self, feats):
-        return multi_apply(self.forward_single, feats)
+        outs = [self.forward_single(f) for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs]
 
     execute = forward
 
-    def get_anchors(self, featmap_sizes, img_metas, device=None):
-        num_imgs, num_levels = len(img_metas), len(featmap_sizes)
-        multi_level_anchors = [self.anchor_generators[i].grid_anchors(featmap_sizes[i], self.anchor_strides[i], device)
-                               for i in range(num_levels)]
-        anchor_list = [list(multi_level_anchors) for _ in range(num_imgs)]
-        valid_flag_list = []
-        for img_meta in img_metas:
-            multi_level_flags = []
-            for i in range(num_levels):
-                stride = self.anchor_strides[i]
-                feat_h, feat_w = featmap_sizes[i]
-                h, w = img_meta["pad_shape"][0], img_meta["pad_shape"][1]
-                valid_feat_h = min(int(np.ceil(h / stride)), feat_h)
-                valid_feat_w = min(int(np.ceil(w / stride)), feat_w)
-                multi_level_flags.append(self.anchor_generators[i].valid_flags((feat_h, feat_w),
-                                                                               (valid_feat_h, valid_feat_w), device))
-            valid_flag_list.append(multi_level_flags)
-        return anchor_list, valid_flag_list
+    # ------------------------------------------------------------------ anchors
+    def level_anchors(self, sizes, device):
+        return [g.grid_anchors(size, stride, device)
+                for g, size, stride in zip(self.anchor_generators, sizes, self.anchor_strides)]
 
-    def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_total_samples,
-                    cfg):
-        labels = labels.reshape(-1)
-        label_weights = label_weights.reshape(-1)
-        cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
-        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
-        bbox_targets = bbox_targets.reshape(-1, 4)
-        bbox_weights = bbox_weights.reshape(-1, 4)
-        bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 4)
-        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
-        return loss_cls, loss_bbox
+    def valid_flags(self, sizes, pad_shape, device):
+        """anchors whose cell lies inside the padded image (L87-100)"""
+        flags = []
+        for g, (fh, fw), stride in zip(self.anchor_generators, sizes, self.anchor_strides):
+            vh = min(int(np.ceil(pad_shape[0] / stride)), fh)
+            vw = min(int(np.ceil(pad_shape[1] / stride)), fw)
+            flags.append(g.valid_flags((fh, fw), (vh, vw), device))
+        return torch.cat(flags)
 
+    @staticmethod
+    def _per_anchor(t, width):
+        """(N, A*width, H, W) -> (N, H*W*A, width): the anchor order of grid_anchors (location-major, A fastest)"""
+        return t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, width)
+
+    # ------------------------------------------------------------------ loss
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, cfg, gt_bboxes_ignore=None):
-        featmap_sizes = [tuple(featmap.shape[-2:]) for featmap in cls_scores]
-        assert len(featmap_sizes) == len(self.anchor_generators)
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, cls_scores[0].device)
-        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
-        cls_reg_targets = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas, self.target_means,
-                                        self.target_stds, cfg, gt_bboxes_ignore_list=gt_bboxes_ignore,
-                                        gt_labels_list=gt_labels, label_channels=label_channels,
-                                        sampling=self.sampling)
-        if cls_reg_targets is None:
-            return None
-        (labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos,
-         num_total_neg) = cls_reg_targets
-        num_total_samples = num_total_pos + num_total_neg if self.sampling else num_total_pos
-        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, labels_list,
-                                              label_weights_list, bbox_targets_list, bbox_weights_list,
-                                              num_total_samples=num_total_samples, cfg=cfg)
+        """sampled RPN loss; cfg = train_cfg.rpn (assigner, sampler, allowed_border, pos_weight)"""
+        assert self.use_sigmoid_cls and self.cls_out_channels == 1 and gt_labels is None, \
+            "objectness head: one sigmoid per anchor"
+        sizes = [tuple(c.shape[-2:]) for c in cls_scores]
+        assert len(sizes) == len(self.anchor_generators)
+        dev = cls_scores[0].device
+        per_level = self.level_anchors(sizes, dev)
+        anchors = torch.cat(per_level)
+        assigner = build_from_cfg(cfg["assigner"], BOXES)
+        sampler = build_from_cfg(cfg["sampler"], BOXES)
+        assert assigner.ignore_iof_thr <= 0, "ignore regions are not part of any shipped RPN configuration"
+        encode = lambda a, g: bbox2delta(a, g, self.target_means, self.target_stds)   # noqa: E731
+        per_image = []
+        for gt, meta in zip(gt_bboxes, img_metas):
+            inside = anchor_inside_flags(anchors, self.valid_flags(sizes, meta["pad_shape"], dev),
+                                         meta["img_shape"][:2], cfg.get("allowed_border", -1))
+            per_image.append(dense_anchor_targets(anchors, inside, gt, gt, assigner, sampler, encode, 4, 0,
+                                                  cfg.get("pos_weight", -1)))
+        labels, label_w, box_t, box_w = (torch.stack([p[k] for p in per_image]) for k in range(4))
+        # sum over images of max(#pos, 1) + max(#neg, 1) (anchor_target.py:L77-78), kept on the device
+        n_samples = sum(torch.clamp(p[4], min=1) + torch.clamp(p[5], min=1) for p in per_image).float()
+        losses_cls, losses_bbox, start = [], [], 0
+        for cls, reg, lvl in zip(cls_scores, bbox_preds, per_level):
+            sl = slice(start, start + lvl.shape[0])
+            start += lvl.shape[0]
+            losses_cls.append(self.loss_cls(self._per_anchor(cls, 1).reshape(-1, 1), labels[:, sl].reshape(-1),
+                                            label_w[:, sl].reshape(-1), avg_factor=n_samples))
+            losses_bbox.append(self.loss_bbox(self._per_anchor(reg, 4).reshape(-1, 4), box_t[:, sl].reshape(-1, 4),
+                                              box_w[:, sl].reshape(-1, 4), avg_factor=n_samples))
         return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
 
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale=False):
-        assert len(cls_scores) == len(bbox_preds)
-        num_levels = len(cls_scores)
-        dev = cls_scores[0].device
-        mlvl_anchors = [self.anchor_generators[i].grid_anchors(tuple(cls_scores[i].shape[-2:]),
-                                                               self.anchor_strides[i], dev) for i in range(num_levels)]
-        result_list = []
-        for img_id in range(len(img_metas)):
-            cls_score_list = [cls_scores[i][img_id].detach() for i in range(num_levels)]
-            bbox_pred_list = [bbox_preds[i][img_id].detach() for i in range(num_levels)]
-            result_list.append(self.get_bboxes_single(cls_score_list, bbox_pred_list, mlvl_anchors,
-                                                      img_metas[img_id]["img_shape"],
-                                                      img_metas[img_id]["scale_factor"], cfg, rescale))
-        return result_list
+    # ------------------------------------------------------------------ proposals
+    def _image_proposals(self, level_scores, level_deltas, level_anchors, img_shape, cfg):
+        scores, boxes, ids, sizes = [], [], [], []
+        for lvl, (s, d, a) in enumerate(zip(level_scores, level_deltas, level_anchors)):
+            s = s.sigmoid() if self.use_sigmoid_cls else s.softmax(dim=1)[:, 1]
+            n = s.shape[0] if cfg["nms_pre"] <= 0 else min(cfg["nms_pre"], s.shape[0])
+            s, top = torch.topk(s, n)                          # descending; equal scores: lowest index first
+            scores.append(s)
+            boxes.append(delta2bbox(a[top], d[top], self.target_means, self.target_stds, img_shape))
+            ids.append(torch.full((n,), lvl, dtype=torch.long, device=s.device))
+            sizes.append(n)
+        scores, boxes, ids = torch.cat(scores), torch.cat(boxes), torch.cat(ids)
+        alive = torch.ones_like(scores, dtype=torch.bool)
+        if cfg["min_bbox_size"] > 0:
+            alive = ((boxes[:, 2] - boxes[:, 0] + 1 >= cfg["min_bbox_size"]) &
+                     (boxes[:, 3] - boxes[:, 1] + 1 >= cfg["min_bbox_size"]))
+        return proposal_table(boxes, scores, ids, sizes, alive, cfg["nms_thr"], cfg["nms_post"], cfg["max_num"],
+                              nms_across_levels=cfg["nms_across_levels"], invalid_score=INVALID_SCORE)
 
-    def get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape, scale_factor, cfg, rescale=False):
-        raise NotImplementedError
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, rescale=False):
+        """one (max_num, 5) proposal table per image"""
+        assert len(cls_scores) == len(bbox_preds) and not rescale
+        width = 1 if self.use_sigmoid_cls else 2
+        anchors = self.level_anchors([tuple(c.shape[-2:]) for c in cls_scores], cls_scores[0].device)
+        scores = [self._per_anchor(c.detach(), width) for c in cls_scores]
+        scores = [s[..., 0] if self.use_sigmoid_cls else s for s in scores]
+        deltas = [self._per_anchor(r.detach(), 4) for r in bbox_preds]
+        return [self._image_proposals([s[i] for s in scores], [d[i] for d in deltas], anchors, meta["img_shape"], cfg)
+                for i, meta in enumerate(img_metas)]
 
 
 @HEADS.register_module()
@@ -152,39 +174,3 @@ class FasterrcnnHead(AnchorHead):
         losses = super().loss(cls_scores, bbox_preds, gt_bboxes, None, img_metas, cfg,
                               gt_bboxes_ignore=gt_bboxes_ignore)
         return dict(loss_rpn_cls=losses["loss_cls"], loss_rpn_bbox=losses["loss_bbox"])
-
-    def get_bboxes_single(self, cls_scores, bbox_preds, mlvl_anchors, img_shape, scale_factor, cfg, rescale=False):
-        mlvl_proposals = []
-        for idx in range(len(cls_scores)):
-            rpn_cls_score, rpn_bbox_pred = cls_scores[idx], bbox_preds[idx]
-            assert rpn_cls_score.shape[-2:] == rpn_bbox_pred.shape[-2:]
-            anchors = mlvl_anchors[idx]
-            rpn_cls_score = rpn_cls_score.permute(1, 2, 0)
-            if self.use_sigmoid_cls:
-                scores = rpn_cls_score.reshape(-1).sigmoid()
-            else:
-                scores = rpn_cls_score.reshape(-1, 2).softmax(dim=1)[:, 1]
-            rpn_bbox_pred = rpn_bbox_pred.permute(1, 2, 0).reshape(-1, 4)
-            if cfg["nms_pre"] > 0 and scores.shape[0] > cfg["nms_pre"]:
-                _, topk_inds = scores.topk(cfg["nms_pre"])
-                rpn_bbox_pred = rpn_bbox_pred[topk_inds, :]
-                anchors = anchors[topk_inds, :]
-                scores = scores[topk_inds]
-            proposals = delta2bbox(anchors, rpn_bbox_pred, self.target_means, self.target_stds, img_shape)
-            if cfg["min_bbox_size"] > 0:
-                w = proposals[:, 2] - proposals[:, 0] + 1
-                h = proposals[:, 3] - proposals[:, 1] + 1
-                valid = (w >= cfg["min_bbox_size"]) & (h >= cfg["min_bbox_size"])
-                proposals, scores = proposals[valid, :], scores[valid]
-            proposals = torch.cat([proposals, scores.unsqueeze(-1)], dim=-1)
-            proposals = proposals[nms_dets(proposals, cfg["nms_thr"])]
-            mlvl_proposals.append(proposals[:cfg["nms_post"], :])
-        proposals = torch.cat(mlvl_proposals, 0)
-        if cfg["nms_across_levels"]:
-            proposals = proposals[nms_dets(proposals, cfg["nms_thr"])]
-            proposals = proposals[:cfg["max_num"], :]
-        else:
-            num = min(cfg["max_num"], proposals.shape[0])
-            _, topk_inds = proposals[:, 4].topk(num)
-            proposals = proposals[topk_inds, :]
-        return proposals

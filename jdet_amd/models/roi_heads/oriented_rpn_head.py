@@ -22,9 +22,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
-from jdet_amd.models.boxes.fixed_shape import sample_fixed, scatter_rows
+from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
 from jdet_amd.ops.bbox_transforms import obb2hbb
-from jdet_amd.ops.nms import nms_keep_mask
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
 
 INVALID_SCORE = -1.0   # score of a padding row in a proposal table
@@ -82,23 +81,8 @@ class OrientedRPNHead(nn.Module):
         gt_obb = target["rboxes"].clone()
         gt_obb[:, -1] *= -1                      # Oriented R-CNN angle convention
         gt_hbb = obb2hbb(gt_obb)                 # the assigner sees the anchors' box type (L308-312)
-        overlaps = self.assigner.iou_calculator(gt_hbb, anchors)
-        overlaps = torch.where(inside[None, :], overlaps, torch.full_like(overlaps, -1.0))
-        assign = self.assigner.assign_wrt_overlaps(overlaps, None)
-        s = self.sampler
-        pos_idx, pos_valid, neg_idx, neg_valid = sample_fixed(assign.gt_inds, s.num, s.pos_fraction, s.neg_pos_ub)
-        matched = (assign.gt_inds[pos_idx].long() - 1).clamp(min=0)
-        pos_targets = self.bbox_coder.encode(anchors[pos_idx], gt_obb[matched])
-        A = anchors.shape[0]
-        dev = anchors.device
-        labels = scatter_rows(torch.full((A,), self.background_label, dtype=torch.long, device=dev), pos_idx,
-                              pos_valid, 1)
-        pw = 1.0 if self.pos_weight <= 0 else self.pos_weight
-        label_weights = scatter_rows(torch.zeros((A,), device=dev), pos_idx, pos_valid, pw)
-        label_weights = scatter_rows(label_weights, neg_idx, neg_valid, 1.0)
-        bbox_targets = scatter_rows(torch.zeros((A, self.reg_dim), device=dev), pos_idx, pos_valid, pos_targets)
-        bbox_weights = scatter_rows(torch.zeros((A, self.reg_dim), device=dev), pos_idx, pos_valid, 1.0)
-        return labels, label_weights, bbox_targets, bbox_weights, pos_valid.sum(), neg_valid.sum()
+        return dense_anchor_targets(anchors, inside, gt_hbb, gt_obb, self.assigner, self.sampler,
+                                    self.bbox_coder.encode, self.reg_dim, self.background_label, self.pos_weight)
 
     def loss(self, cls_scores, bbox_preds, targets):
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]
@@ -144,19 +128,8 @@ class OrientedRPNHead(nn.Module):
         alive = torch.ones_like(scores, dtype=torch.bool)
         if self.min_bbox_size >= 0:
             alive = (boxes[:, 2] > self.min_bbox_size) & (boxes[:, 3] > self.min_bbox_size)
-        # dropped boxes get the lowest scores: they are visited last, suppress nothing that is kept, and are
-        # removed again below (the reference filters them out before the NMS, L207-212)
-        keep, _ = nms_keep_mask(obb2hbb(boxes), torch.where(alive, scores, torch.full_like(scores, -2.0)),
-                                self.nms_thresh, labels=ids)
-        ranked = torch.where(keep & alive, scores, torch.full_like(scores, INVALID_SCORE))
-        k = min(self.nms_post, ranked.shape[0])
-        top_scores, top = torch.topk(ranked, k)
-        table = torch.cat([boxes[top], top_scores[:, None]], dim=1)
-        if k < self.nms_post:
-            pad = table.new_zeros((self.nms_post - k, 6))
-            pad[:, 5] = INVALID_SCORE
-            table = torch.cat([table, pad])
-        return table
+        return proposal_table(obb2hbb(boxes), scores, ids, [int(x.shape[0]) for x in anchors], alive, self.nms_thresh,
+                              None, self.nms_post, invalid_score=INVALID_SCORE, payload=boxes)
 
     def get_bboxes(self, cls_scores, bbox_preds, targets):
         sizes = [tuple(c.shape[-2:]) for c in cls_scores]

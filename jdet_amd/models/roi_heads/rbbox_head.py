@@ -1,6 +1,11 @@
 """RoI-Transformer box heads (stage 1: horizontal RoI -> rotated RoI; stage 2: rotated RoI -> detection).
-Mirrors python/jdet/models/roi_heads/rbbox_head.py: target builders L9-146, `accuracy` L148-167,
-`BBoxHeadRbbox` L169-448."""
+Contract of python/jdet/models/roi_heads/rbbox_head.py: target builders L9-146, `accuracy` L148-167,
+`BBoxHeadRbbox` L169-448 (constructor arguments, parameter names, loss keys, decode functions).
+
+Training runs on fixed-size row sets (models/boxes/fixed_shape.py: `StageRows`, always `sampler.num` rows per image
+with valid / positive masks) instead of the reference's positives-first variable-length lists: targets, losses and
+the stage-1 -> stage-2 refinement are masked dense arithmetic, no boolean indexing, no device -> host round trip.
+"""
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -9,7 +14,6 @@ from jdet_amd.models.boxes.box_ops import rotated_box_to_poly
 from jdet_amd.ops.bbox_transforms import (best_match_dbbox2delta, choose_best_obb_batch, choose_best_Rroi_batch,
                                           dbbox2delta_v3, delta2dbbox_v2, delta2dbbox_v3, hbb2obb_v2)
 from jdet_amd.ops.nms_rotated import multiclass_nms_rotated
-from jdet_amd.utils.general import multi_apply
 from jdet_amd.utils.registry import HEADS, LOSSES, build_from_cfg
 
 
@@ -17,81 +21,51 @@ def _get(cfg, key):
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
 
 
-def bbox_target_rbbox_single(pos_bboxes, neg_bboxes, pos_assigned_gt_inds, gt_obbs, pos_gt_labels, cfg, reg_classes=1,
-                             target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0),
-                             with_module=True, hbb_trans="hbb2obb_v2"):
-    num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
-    num_samples = num_pos + num_neg
-    dev = pos_bboxes.device
-    labels = torch.zeros(num_samples, dtype=torch.int32, device=dev)
-    label_weights = torch.zeros(num_samples, device=dev)
-    bbox_targets = torch.zeros((num_samples, 5), device=dev)
-    bbox_weights = torch.zeros((num_samples, 5), device=dev)
-    pos_gt_obbs = choose_best_obb_batch(gt_obbs[pos_assigned_gt_inds])
-    pos_ext_bboxes = hbb2obb_v2(pos_bboxes) if pos_bboxes.size(1) == 4 else pos_bboxes
-    if num_pos > 0:
-        labels[:num_pos] = pos_gt_labels.to(labels.dtype)
-        pos_weight = 1.0 if _get(cfg, "pos_weight") <= 0 else _get(cfg, "pos_weight")
-        label_weights[:num_pos] = pos_weight
-        if with_module:
-            # rbbox_head.py:L76 calls `dbbox2delta`, a name the reference never imports: unreachable there
-            raise NameError("dbbox2delta (with_module=True) is not defined in the reference either")
-        bbox_targets[:num_pos, :] = dbbox2delta_v3(pos_ext_bboxes, pos_gt_obbs, target_means, target_stds)
-        bbox_weights[:num_pos, :] = 1
-    if num_neg > 0:
-        label_weights[-num_neg:] = 1.0
-    return labels, label_weights, bbox_targets, bbox_weights
+def _row_targets(rows, deltas, pos_weight):
+    """the four target tensors of one image's StageRows (rbbox_head.py:L40-62 / L101-121 with masks instead of the
+    positives-first slices): labels (num,) long, label_weights (num,), bbox_targets (num,5), bbox_weights (num,5)"""
+    pw = 1.0 if pos_weight <= 0 else pos_weight
+    valid, pos = rows.valid.float(), rows.is_pos.float()
+    label_weights = valid * (pos * pw + (1.0 - pos))
+    bbox_targets = torch.where(rows.is_pos[:, None], deltas, torch.zeros_like(deltas))
+    return rows.labels, label_weights, bbox_targets, pos[:, None].expand(-1, 5)
 
 
-def rbbox_target_rbbox_single(pos_rbboxes, neg_rbboxes, pos_gt_rbboxes, pos_gt_labels, cfg, reg_classes=1,
-                              target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0)):
-    assert pos_rbboxes.size(1) == 5
-    num_pos, num_neg = pos_rbboxes.size(0), neg_rbboxes.size(0)
-    num_samples = num_pos + num_neg
-    dev = pos_rbboxes.device
-    labels = torch.zeros(num_samples, dtype=torch.int32, device=dev)
-    label_weights = torch.zeros(num_samples, device=dev)
-    bbox_targets = torch.zeros((num_samples, 5), device=dev)
-    bbox_weights = torch.zeros((num_samples, 5), device=dev)
-    if num_pos > 0:
-        labels[:num_pos] = pos_gt_labels.to(labels.dtype)
-        pos_weight = 1.0 if _get(cfg, "pos_weight") <= 0 else _get(cfg, "pos_weight")
-        label_weights[:num_pos] = pos_weight
-        bbox_targets[:num_pos, :] = best_match_dbbox2delta(pos_rbboxes, pos_gt_rbboxes, target_means, target_stds)
-        bbox_weights[:num_pos, :] = 1
-    if num_neg > 0:
-        label_weights[-num_neg:] = 1.0
-    return labels, label_weights, bbox_targets, bbox_weights
+def hbb_row_targets(rows, gt_obbs, cfg, target_means, target_stds, with_module=False):
+    """stage 1 of RoI-Transformer: horizontal sampled boxes regress to the gt in its near-(-90 degree) form
+    (`bbox_target_rbbox_single`, L9-63): dbbox2delta_v3(hbb2obb_v2(box), choose_best_obb_batch(gt))"""
+    if with_module:
+        # rbbox_head.py:L76 calls `dbbox2delta`, a name the reference never imports: unreachable there
+        raise NameError("dbbox2delta (with_module=True) is not defined in the reference either")
+    gts = choose_best_obb_batch(gt_obbs[rows.matched])
+    boxes = hbb2obb_v2(rows.boxes) if rows.boxes.size(1) == 4 else rows.boxes
+    return _row_targets(rows, dbbox2delta_v3(boxes, gts, target_means, target_stds), _get(cfg, "pos_weight"))
 
 
-def _concat_targets(parts, concat):
-    return tuple(torch.cat(p, 0) for p in parts) if concat else parts
+def obb_row_targets(rows, gt_rbboxes, cfg, target_means, target_stds):
+    """stage 2: rotated sampled boxes regress to the best-matching of the gt's four equivalent forms
+    (`rbbox_target_rbbox_single`, L88-121)"""
+    assert rows.boxes.size(1) == 5
+    deltas = best_match_dbbox2delta(rows.boxes, gt_rbboxes[rows.matched], target_means, target_stds)
+    return _row_targets(rows, deltas, _get(cfg, "pos_weight"))
 
 
-def bbox_target_rbbox(pos_bboxes_list, neg_bboxes_list, pos_assigned_gt_inds_list, gt_obbs_list, pos_gt_labels_list,
-                      cfg, reg_classes=1, target_means=(.0, .0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0),
-                      concat=True, with_module=True, hbb_trans="hbb2obb_v2"):
-    parts = multi_apply(bbox_target_rbbox_single, pos_bboxes_list, neg_bboxes_list, pos_assigned_gt_inds_list,
-                        gt_obbs_list, pos_gt_labels_list, cfg=cfg, reg_classes=reg_classes,
-                        target_means=target_means, target_stds=target_stds, with_module=with_module,
-                        hbb_trans=hbb_trans)
-    return _concat_targets(parts, concat)
+def _cat_images(parts):
+    return tuple(torch.cat([p[k] for p in parts]) for k in range(4))
 
 
-def rbbox_target_rbbox(pos_rbboxes_list, neg_rbboxes_list, pos_gt_rbboxes_list, pos_gt_labels_list, cfg, reg_classes=1,
-                       target_means=(.0, .0, .0, .0, 0), target_stds=(1.0, 1.0, 1.0, 1.0, 1.0), concat=True):
-    parts = multi_apply(rbbox_target_rbbox_single, pos_rbboxes_list, neg_rbboxes_list, pos_gt_rbboxes_list,
-                        pos_gt_labels_list, cfg=cfg, reg_classes=reg_classes, target_means=target_means,
-                        target_stds=target_stds)
-    return _concat_targets(parts, concat)
-
-
-def accuracy(pred, target, topk=1):
+def accuracy(pred, target, topk=1, valid=None):
+    """top-k accuracy in percent over the rows marked valid (all rows by default; L148-167)"""
     return_single = isinstance(topk, int)
     topk = (topk,) if return_single else topk
     _, pred_label = pred.topk(max(topk), 1, True, True)
     correct = pred_label.t() == target.view(1, -1).to(pred_label.dtype)
-    res = [correct[:k].reshape(-1).float().sum(0, keepdim=True) * (100.0 / pred.shape[0]) for k in topk]
+    if valid is None:
+        n = float(pred.shape[0])
+    else:
+        correct = correct & valid.view(1, -1)
+        n = torch.clamp(valid.sum().float(), min=1.0)
+    res = [correct[:k].reshape(-1).float().sum(0, keepdim=True) * (100.0 / n) for k in topk]
     return res[0] if return_single else res
 
 
@@ -150,20 +124,15 @@ class BBoxHeadRbbox(nn.Module):
 
     execute = forward
 
-    def get_target(self, sampling_results, gt_obbs, gt_labels, rcnn_train_cfg):
-        reg_classes = 1 if self.reg_class_agnostic else self.num_classes
-        return bbox_target_rbbox([r.pos_bboxes for r in sampling_results], [r.neg_bboxes for r in sampling_results],
-                                 [r.pos_assigned_gt_inds for r in sampling_results], gt_obbs,
-                                 [r.pos_gt_labels for r in sampling_results], rcnn_train_cfg, reg_classes,
-                                 target_means=self.target_means, target_stds=self.target_stds,
-                                 with_module=self.with_module, hbb_trans=self.hbb_trans)
+    def get_target(self, stage_rows, gt_obbs, gt_labels, rcnn_train_cfg):
+        """stage_rows: one StageRows per image (horizontal boxes) -> targets of all images, concatenated"""
+        return _cat_images([hbb_row_targets(r, g, rcnn_train_cfg, self.target_means, self.target_stds,
+                                            self.with_module) for r, g in zip(stage_rows, gt_obbs)])
 
-    def get_target_rbbox(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg):
-        reg_classes = 1 if self.reg_class_agnostic else self.num_classes
-        return rbbox_target_rbbox([r.pos_bboxes for r in sampling_results], [r.neg_bboxes for r in sampling_results],
-                                  [r.pos_gt_bboxes for r in sampling_results],
-                                  [r.pos_gt_labels for r in sampling_results], rcnn_train_cfg, reg_classes,
-                                  target_means=self.target_means, target_stds=self.target_stds)
+    def get_target_rbbox(self, stage_rows, gt_rbboxes, gt_labels, rcnn_train_cfg):
+        """stage_rows: one StageRows per image (rotated boxes); gt_rbboxes: what they were assigned against"""
+        return _cat_images([obb_row_targets(r, g, rcnn_train_cfg, self.target_means, self.target_stds)
+                            for r, g in zip(stage_rows, gt_rbboxes)])
 
     def _finish_dets(self, dbboxes, scores, scale_factor, rescale, cfg):
         if rescale:
@@ -187,42 +156,49 @@ class BBoxHeadRbbox(nn.Module):
         assert cfg is not None
         return self._finish_dets(dbboxes, scores, scale_factor, rescale, cfg)
 
-    def get_det_rbboxes(self, rrois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+    def get_det_rbboxes(self, rrois, cls_score, rbbox_pred, img_shape, scale_factor, rescale=False, cfg=None,
+                        alive=None):
+        """`alive` (R,) bool: rows of a padded proposal table that are real; the others score 0 in every class"""
         if isinstance(cls_score, list):
             cls_score = sum(cls_score) / float(len(cls_score))
         scores = F.softmax(cls_score, dim=1) if cls_score is not None else None
+        if alive is not None and scores is not None:
+            scores = scores * alive[:, None].to(scores.dtype)
         dbboxes = rrois[:, 1:] if rbbox_pred is None else delta2dbbox_v2(rrois[:, 1:], rbbox_pred, self.target_means,
                                                                          self.target_stds, img_shape)
         return self._finish_dets(dbboxes, scores, scale_factor, rescale, cfg)
 
     def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, reduce=True):
+        """Rows with label_weight 0 are padding (fewer candidates than the sampler's `num`): they count nowhere.
+        Classification = mean over the sampled rows; regression = positives only (bbox_weights), normalised by the
+        number of sampled rows (L398-423, where every row is a sampled one and the positives are picked with a
+        boolean index)."""
         losses = dict()
+        sampled = label_weights > 0
+        n_rows = torch.clamp(sampled.sum().float(), min=1.0)
         if cls_score is not None:
             losses["rbbox_loss_cls"] = self.loss_cls(cls_score, labels, label_weights, reduce=reduce)
-            losses["rbbox_acc"] = accuracy(cls_score, labels)
+            losses["rbbox_acc"] = accuracy(cls_score, labels, valid=sampled)
         if bbox_pred is not None:
-            pos_inds = labels > 0
             if self.reg_class_agnostic:
-                pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), 5)[pos_inds]
+                pred = bbox_pred.view(bbox_pred.size(0), 5)
             else:
-                pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), -1, 5)[pos_inds, labels[pos_inds].long()]
-            losses["rbbox_loss_bbox"] = self.loss_bbox(pos_bbox_pred, bbox_targets[pos_inds], bbox_weights[pos_inds],
-                                                       avg_factor=bbox_targets.size(0))
+                pred = bbox_pred.view(bbox_pred.size(0), -1, 5)
+                pred = pred.gather(1, labels.long()[:, None, None].expand(-1, 1, 5))[:, 0]
+            losses["rbbox_loss_bbox"] = self.loss_bbox(pred, bbox_targets, bbox_weights, avg_factor=n_rows)
         return losses
 
-    def refine_rbboxes(self, rois, labels, bbox_preds, pos_is_gts, img_metas):
-        """regress every sampled RoI by its label's deltas, drop the gts that were added as proposals"""
-        img_ids = rois[:, 0].long().unique()
-        assert img_ids.numel() == len(img_metas)
-        bboxes_list = []
-        for i in range(len(img_metas)):
-            inds = torch.nonzero(rois[:, 0] == i)[:, 0]
-            num_rois = inds.numel()
-            bboxes = self.regress_by_class_rbbox(rois[inds, 1:], labels[inds], bbox_preds[inds], img_metas[i])
-            keep = torch.ones(num_rois, dtype=torch.bool, device=rois.device)
-            keep[:len(pos_is_gts[i])] = ~pos_is_gts[i].bool()
-            bboxes_list.append(bboxes[keep])
-        return bboxes_list
+    def refine_rbboxes(self, rois, labels, bbox_preds, stage_rows, img_metas):
+        """every sampled row regressed by its label's deltas (L425-448).  rois (B*num, 6) [img, obb]; returns per
+        image (boxes (num,5), alive (num,)): the gts that were added as proposals and the padding rows are dead
+        (the reference drops the former with a boolean index)."""
+        num = rois.shape[0] // len(img_metas)
+        out = []
+        for i, (rows, meta) in enumerate(zip(stage_rows, img_metas)):
+            sl = slice(i * num, (i + 1) * num)
+            boxes = self.regress_by_class_rbbox(rois[sl, 1:], labels[sl], bbox_preds[sl], meta)
+            out.append((boxes, rows.valid & ~rows.is_gt))
+        return out
 
     def regress_by_class_rbbox(self, rois, label, bbox_pred, img_meta):
         assert rois.size(1) == 5 or rois.size(1) == 6

@@ -89,6 +89,21 @@ def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
                                               ws.numel(), L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
 
 
+_BWD_WS = {}
+
+
+def _kept_backward_workspace(dev, npix, nbytes):
+    """Workspace of the channels-last backward, kept per (device, stream, map size): zero-filled once; the call hands
+    its counters back zeroed (`workspace_clean` contract of jdet_roi_align_backward_cl), so no memset launch per
+    step.  One buffer per map size: the zeroed region's length depends on it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, npix)
+    ws = _BWD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        _BWD_WS[key] = ws
+    return ws, key
+
+
 def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order):
     """grad w.r.t. one feature map (NHWC memory).  A channels-last grad_out (what a channels-last forward result
     gets back from a layout-preserving consumer) feeds the sorted gather directly: no transpose pass."""
@@ -99,12 +114,17 @@ def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_o
     if g_out.dtype != torch.float32:
         g_out = g_out.float()
     wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
-    ws = torch.empty((wsb,), dtype=torch.uint8, device=g_out.device) if wsb else None
     if wsb and R and g_out.is_contiguous(memory_format=torch.channels_last) and not g_out.is_contiguous():
-        L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
-                                                   scale, sample_num, L.ptr(grad_in), L.ptr(ws), wsb,
-                                                   L.stream_ptr(g_out)), "jdet_roi_align_backward_cl")
+        ws, key = _kept_backward_workspace(g_out.device, N * H * W, wsb)
+        try:
+            L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
+                                                       scale, sample_num, L.ptr(grad_in), L.ptr(ws), ws.numel(), 1,
+                                                       L.stream_ptr(g_out)), "jdet_roi_align_backward_cl")
+        except Exception:
+            _BWD_WS.pop(key, None)      # state unknown after a failed call: start from a fresh zeroed buffer
+            raise
         return grad_in
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=g_out.device) if wsb else None
     g = g_out.contiguous()
     L.check(L.lib().jdet_roi_align_backward(variant, L.ptr(g), L.ptr(rois_c), R, N, C, H, W, PH, PW,
                                             scale, sample_num, n_orient, L.ptr(order), L.ptr(grad_in),

@@ -9,6 +9,8 @@ import math
 
 import torch
 
+from jdet_amd.utils.general import const_like
+
 
 def regular_theta(theta, mode="180", start=-math.pi / 2):
     assert mode in ["360", "180"]
@@ -134,7 +136,7 @@ def get_bbox_areas(bboxes):
 # `%` on float tensors is Python-style floor-mod in the reference = torch.remainder.
 # ------------------------------------------------------------------------------------------------
 def _row(v, like):
-    return torch.as_tensor(v, dtype=like.dtype, device=like.device)[None, :]
+    return const_like(v, like)[None, :]      # cached on the device: no host -> device copy inside a step
 
 
 def dbbox2delta_v3(proposals, gt, means=(0, 0, 0, 0, 0), stds=(1, 1, 1, 1, 1)):

@@ -16,6 +16,7 @@ Both compute the same per-element arithmetic.
 import math
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .. import _lib as L
@@ -97,6 +98,17 @@ def _nhwc(t):
 SAVE_COLUMNS = True
 
 
+def _weight_grad(g, cols, split_rows=16384, splits=4):
+    """g (M, Cout)^T @ cols (M, K): 256 x 2304 outputs over a reduction of M = B*Ho*Wo rows.  At the finest FPN level
+    (M = 32768) the library's single-pass kernel has 36 workgroups for 256 CUs (612 us, 40 % MFMA busy,
+    profiles/r02_s2anet_mfma_utilisation.txt); as a 4-way split over M (batched GEMM + sum of the partials) it runs
+    311 us.  Smaller M: the plain GEMM is faster (measured 97 vs 110 us at M = 8192)."""
+    M = g.shape[0]
+    if M >= split_rows and M % splits == 0:
+        return torch.bmm(g.view(splits, M // splits, -1).transpose(1, 2), cols.view(splits, M // splits, -1)).sum(0)
+    return torch.mm(g.t(), cols)
+
+
 class DeformConvFunction(torch.autograd.Function):
     @staticmethod
     def _forward_nhwc(ctx, input, off, weight, stride, padding, dilation):
@@ -106,7 +118,7 @@ class DeformConvFunction(torch.autograd.Function):
         x = _nhwc(input)
         wt = L.f32c(weight.permute(0, 2, 3, 1)).view(Cout, kh * kw * Cin)   # K index = tap*Cin + c
         cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
-        out = torch.mm(cols, wt.t())                                          # (B*Ho*Wo, Cout) == NHWC
+        out = F.linear(cols, wt)                                              # (B*Ho*Wo, Cout) == NHWC
         keep = SAVE_COLUMNS and weight.requires_grad
         ctx.save_for_backward(x, off, wt, cols if keep else None)
         return out.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
@@ -132,7 +144,7 @@ class DeformConvFunction(torch.autograd.Function):
         if need_w:
             if cols is None:
                 cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
-            grad_weight = torch.mm(g.t(), cols).view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
+            grad_weight = _weight_grad(g, cols).view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)
         return grad_input, None, grad_weight, None, None, None, None, None, None
 
     @staticmethod

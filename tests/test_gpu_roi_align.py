@@ -136,6 +136,39 @@ def test_channels_last_result_and_gradient(dev, variant, fwd_mode):
     np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
 
 
+def test_backward_cl_kept_workspace_contract(dev):
+    """jdet_roi_align_backward_cl with workspace_clean=1 on ONE kept workspace, three different RoI sets in a row:
+    each result equals the oracle and the first jdet_roi_align_backward_clean_bytes() bytes are zero again after every
+    call; workspace_clean=0 on a workspace full of garbage gives the same result.  Odd map sizes: the 2x2 patch /
+    XCD stripe mapping of the gather has to cover partial patches and stripes."""
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    N, C, H, W, scale, R = 2, 32, 37, 45, 0.25, 150
+    wsb = lib.jdet_roi_align_backward_workspace(O.V_ROT, R, N, C, H, W, 7, 7, 2)
+    clean = lib.jdet_roi_align_backward_clean_bytes(O.V_ROT, R, N, C, H, W, 7, 7, 2)
+    assert 0 < clean < wsb
+    ws = torch.zeros((wsb,), dtype=torch.uint8, device=dev)
+    gin = torch.empty((N, H, W, C), device=dev)
+    for rep in range(3):
+        rois = I.rois_from_obbs(I.random_obbs(rng, R, extent=W / scale, wh=(4.0, 160.0)), rng.integers(0, N, R))
+        grad = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+        live = np.ones(R, dtype=bool)
+        live[::11] = False
+        ref = O.roi_align_backward(O.V_ROT, grad[live], rois[live], (N, C, H, W), scale, 2)
+        rois[~live, 0] = -1         # masked RoIs (padding rows of the fixed-shape heads) contribute nothing
+        g_cl = torch.from_numpy(np.ascontiguousarray(grad.transpose(0, 2, 3, 1))).to(dev)     # (R, PH, PW, C)
+        r = torch.from_numpy(rois).to(dev)
+        tol = BWD_ATOL * max(1.0, np.abs(ref).max())
+        for ws_call, flag in ((ws, 1), (torch.full((wsb,), 0xA5, dtype=torch.uint8, device=dev), 0)):
+            gin.fill_(float("nan"))
+            L.check(lib.jdet_roi_align_backward_cl(O.V_ROT, L.ptr(g_cl), L.ptr(r), R, N, C, H, W, 7, 7, scale, 2,
+                                                   L.ptr(gin), L.ptr(ws_call), wsb, flag, L.stream_ptr(gin)), "bwd_cl")
+            got = gin.permute(0, 3, 1, 2).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+            assert int(ws_call[:clean].max()) == 0
+
+
 def test_tile_path_many_rois_and_big_rois(dev):
     """the batching paths of the tile kernel: > 128 candidate RoIs per tile (several candidate batches), > 224 owned
     bins per tile (several bin passes), RoIs far larger than the halo (per-bin global fallback), a masked RoI

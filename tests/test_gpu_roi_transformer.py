@@ -49,20 +49,124 @@ def test_roi_transformer_train_step_and_inference(dev):
 
 
 def test_rpn_proposals_contract(dev):
-    """FasterrcnnHead.get_bboxes: (<= max_num, 5) proposals inside the image, scores descending"""
+    """FasterrcnnHead.get_bboxes: a (max_num, 5) table per image, boxes inside the image, scores descending, padding
+    rows (score -1) last; the survivors equal the reference-shaped pipeline (per-level NMS on the level's sorted
+    candidates, first nms_post of each level, best max_num overall) computed with dynamic shapes"""
     from jdet_amd.models.roi_heads import FasterrcnnHead
+    from jdet_amd.ops.bbox_transforms import delta2bbox
+    from jdet_amd.ops.nms import nms
     torch.manual_seed(1)
     rpn = FasterrcnnHead(in_channels=16, feat_channels=16, anchor_scales=[8], anchor_ratios=[0.5, 1.0, 2.0],
                          anchor_strides=[4, 8, 16, 32, 64],
                          loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=True)).to(dev)
     feats = [torch.randn(2, 16, 256 // s, 256 // s, device=dev) for s in (4, 8, 16, 32, 64)]
     metas = [dict(img_shape=(256, 256), pad_shape=(256, 256), scale_factor=1.0)] * 2
-    cfg = dict(nms_across_levels=False, nms_pre=500, nms_post=300, max_num=400, nms_thr=0.7, min_bbox_size=0)
+    cfg = dict(nms_across_levels=False, nms_pre=500, nms_post=120, max_num=400, nms_thr=0.7, min_bbox_size=0)
     with torch.no_grad():
-        props = rpn.get_bboxes(*rpn(feats), metas, cfg)
-    assert len(props) == 2
-    for p in props:
-        assert p.shape[1] == 5 and 0 < p.shape[0] <= 400
-        assert float(p[:, :4].min()) >= 0 and float(p[:, :4].max()) <= 255
-        s = p[:, 4].cpu().numpy()
-        assert np.all(np.diff(s) <= 1e-7)
+        cls_scores, bbox_preds = rpn(feats)
+        tables = rpn.get_bboxes(cls_scores, bbox_preds, metas, cfg)
+    assert len(tables) == 2
+    anchors = rpn.level_anchors([tuple(c.shape[-2:]) for c in cls_scores], dev)
+    for i, tab in enumerate(tables):
+        assert tab.shape == (400, 5)
+        s = tab[:, 4]
+        alive = s >= 0
+        n = int(alive.sum())
+        assert 0 < n <= 400 and bool(alive[:n].all()) and not bool(alive[n:].any())
+        assert float(tab[:n, :4].min()) >= 0 and float(tab[:n, :4].max()) <= 255
+        assert bool((s[:n - 1] >= s[1:n]).all())
+        expect = []
+        for lvl in range(5):
+            sc = cls_scores[lvl][i].permute(1, 2, 0).reshape(-1).sigmoid()
+            de = bbox_preds[lvl][i].permute(1, 2, 0).reshape(-1, 4)
+            sc, top = sc.topk(min(500, sc.numel()))
+            boxes = delta2bbox(anchors[lvl][top], de[top], rpn.target_means, rpn.target_stds, (256, 256))
+            keep = nms(boxes, sc, 0.7)[:120]
+            expect.append(torch.cat([boxes[keep], sc[keep, None]], 1))
+        expect = torch.cat(expect)
+        expect = expect[expect[:, 4].topk(min(400, expect.shape[0])).indices]
+        assert expect.shape[0] == n
+        assert torch.equal(expect[:, 4], s[:n])
+        assert torch.allclose(expect[:, :4], tab[:n, :4])
+
+
+def test_train_step_runs_without_host_synchronisation(dev):
+    """the RoI-Transformer train step (RPN targets, proposal tables, two sampled R-CNN stages, both RoIAligns, losses,
+    backward) has fixed shapes and no device -> host round trip: PyTorch's sync debug mode "error" raises on any
+    nonzero / boolean-mask indexing / .item() / bool(tensor)"""
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.runner import synthetic_batch
+    from jdet_amd.utils.general import parse_losses
+    from jdet_amd.utils.registry import MODELS, build_from_cfg
+    torch.manual_seed(0)
+    m = build_from_cfg(roitrans_cfg(), MODELS).to(dev)
+    m.train()
+    images, targets = synthetic_batch(2, 256, dev, seed=5, num_gts=10)
+    total, _ = parse_losses(m(images, targets))      # warm-up: anchor caches, constant rows, MIOpen workspaces
+    total.backward()
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        total, parsed = parse_losses(m(images, targets))
+        total.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(total)
+
+
+def test_stage_rows_contract(dev):
+    """sample_stage_rows: exactly `num` rows; positives first, then negatives, then padding; positives carry their
+    gt's label and index, the gts added as proposals are flagged; dead candidates are never sampled"""
+    from jdet_amd.models.boxes.fixed_shape import sample_stage_rows
+    from jdet_amd.utils.registry import BOXES, build_from_cfg
+    import jdet_amd.models  # noqa: F401
+    g = torch.Generator().manual_seed(4)
+    K, P = 6, 300
+    ctr = torch.rand((K, 2), generator=g) * 200 + 20
+    wh = torch.rand((K, 2), generator=g) * 40 + 10
+    gts = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).to(dev)
+    labels = torch.randint(1, 16, (K,), generator=g).to(dev)
+    jit = (torch.rand((P, 4), generator=g) - 0.5) * 12
+    cands = (gts.cpu()[torch.randint(0, K, (P,), generator=g)] + jit).to(dev)
+    cands[150:] = torch.rand((150, 4), generator=g).to(dev) * 3          # far-away negatives
+    cands[150:, 2:] += cands[150:, :2] + 5
+    alive = torch.ones((P,), dtype=torch.bool, device=dev)
+    alive[::7] = False
+    assigner = build_from_cfg(dict(type="MaxIoUAssigner", pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5,
+                                   ignore_iof_thr=-1, iou_calculator=dict(type="BboxOverlaps2D_v1")), BOXES)
+    sampler = build_from_cfg(dict(type="RandomSampler", num=128, pos_fraction=0.25, neg_pos_ub=-1,
+                                  add_gt_as_proposals=True), BOXES)
+    dummy = torch.tensor([4.0, 4.0, 12.0, 12.0], device=dev)
+    rows = sample_stage_rows(cands, alive, gts, labels, assigner, sampler, dummy)
+    assert rows.boxes.shape == (128, 4)
+    v, p = rows.valid.cpu(), rows.is_pos.cpu()
+    n_pos, n_val = int(p.sum()), int(v.sum())
+    assert 0 < n_pos <= 32 and n_val == 128
+    assert bool(p[:n_pos].all()) and not bool(p[n_pos:].any())
+    assert torch.equal(rows.labels[rows.is_pos], labels[rows.matched[rows.is_pos]])
+    assert bool((rows.labels[~rows.is_pos] == 0).all())
+    # a sampled gt row is the gt itself
+    isgt = rows.is_gt
+    assert bool((rows.boxes[isgt] == gts[rows.matched[isgt]]).all())
+    # no dead candidate among the rows: every non-gt row equals some alive candidate
+    live = cands[alive]
+    non_gt = rows.boxes[rows.valid & ~isgt]
+    assert bool(((non_gt[:, None, :] == live[None, :, :]).all(-1).any(1)).all())
+    dead = cands[~alive]
+    assert not bool(((non_gt[:, None, :] == dead[None, :, :]).all(-1).any(1)).any())
+
+
+@pytest.mark.parametrize("name", ["orcnn", "roitrans"])
+def test_two_stage_train_step_replays_as_hip_graph(dev, name):
+    """the fixed-shape two-stage steps are capturable: Runner(graph=True) captures once and replays; losses stay finite
+    and fall on a repeated batch; the random sampling advances between replays (graph-safe Philox offsets)"""
+    from jdet_amd.config.named import ORCNN_CFG, roitrans_train_cfg
+    from jdet_amd.runner import Runner, synthetic_batch
+    cfg = ORCNN_CFG if name == "orcnn" else roitrans_train_cfg()
+    torch.manual_seed(0)
+    r = Runner(cfg, device=dev, conv_autotune=False, graph=True)
+    images, targets = synthetic_batch(2, 256, dev, seed=3, num_gts=12)
+    hist = [float(r.train_step(images, targets)[0]) for _ in range(8)]
+    assert r.use_graph and len(r._graphs) == 1
+    assert np.all(np.isfinite(hist)) and min(hist[4:]) < hist[0]
+    assert len(set(hist)) == len(hist)
