@@ -224,4 +224,159 @@ inline int csr_finish_and_gather(const CsrWs& w, long nkeys, long ntaps, int tap
   return jdet_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Patch-keyed variant.  The four taps of a bilinear sample are a 2x2 pixel block, and neighbouring samples of a bin
+// overlap: keyed by PIXEL, every source row is fetched once per pixel it touches (~10x on the RoIAlign bench, 1 GB
+// through the vector L1 for a 100 MB gradient -- the gather ran at 56 % of the L1's bandwidth, i.e. it was bound by
+// that).  Keyed by the aligned 2x2 PATCH (key = image * ceil(H/2) * ceil(W/2) + (y >> 1) * ceil(W/2) + (x >> 1)), an
+// entry carries one source row and the four weights of the patch's pixels: the taps of one source row that fall into
+// one patch merge into ONE entry, one wave accumulates the four pixels of a patch from one row load per entry.
+// Fewer entries (0.46 x), fewer counter atomics, and the L1 traffic of the gather drops with them.
+struct TapRec {      // written by the producer kernel (compacted: kept taps only), consumed by csr_fill_patch_kernel
+  int key;           // patch
+  int pos;           // place in the patch's row = return value of the atomicAdd that counted it
+  int src;           // source row
+  float w[4];        // weights of pixels (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
+  int pad;
+};
+struct PatchEntry {
+  int src;
+  float w[4];
+  int pad[3];
+};
+static_assert(sizeof(TapRec) == 32 && sizeof(PatchEntry) == 32, "32-byte records: aligned vector / scalar accesses");
+
+struct PatchWs {
+  int* counts;      // nkeys row counters, [nkeys] = scan ticket: patch_zero_bytes()
+  int* offsets;
+  int* tile_sum;
+  int* tile_base;
+  int* seg_n;       // records per producer segment (one segment per producer workgroup, seg_cap records each)
+  TapRec* recs;
+  PatchEntry* entries;
+  size_t bytes;
+};
+
+inline size_t patch_zero_bytes(long nkeys) { return sizeof(int) * (size_t)(nkeys + 1); }
+
+inline PatchWs patch_carve(void* ws, long nkeys, long nsegs, long seg_cap) {
+  const long max_recs = nsegs * seg_cap;
+  PatchWs w;
+  char* p = (char*)ws;
+  size_t off = 0;
+  const long ntiles = (nkeys + kScanTile - 1) / kScanTile;
+  w.counts = (int*)(p + off);    off += align256(sizeof(int) * (nkeys + 1));
+  w.offsets = (int*)(p + off);   off += align256(sizeof(int) * (nkeys + 1));
+  w.tile_sum = (int*)(p + off);  off += align256(sizeof(int) * (ntiles + 1));
+  w.tile_base = (int*)(p + off); off += align256(sizeof(int) * (ntiles + 1));
+  w.seg_n = (int*)(p + off);     off += align256(sizeof(int) * nsegs);
+  w.recs = (TapRec*)(p + off);   off += align256(sizeof(TapRec) * max_recs);
+  w.entries = (PatchEntry*)(p + off); off += align256(sizeof(PatchEntry) * max_recs);
+  w.bytes = off;
+  return w;
+}
+
+static __global__ __launch_bounds__(256) void csr_fill_patch_kernel(const TapRec* __restrict__ recs,
+                                                                    const int* __restrict__ seg_n, int seg_cap,
+                                                                    const int* __restrict__ offsets,
+                                                                    const int* __restrict__ tile_base,
+                                                                    PatchEntry* __restrict__ entries) {
+  const int n = seg_n[blockIdx.x];
+  const TapRec* __restrict__ seg = recs + (size_t)blockIdx.x * seg_cap;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int4 a = reinterpret_cast<const int4*>(seg + e)[0];   // key, pos, src, w0
+    const int4 b = reinterpret_cast<const int4*>(seg + e)[1];   // w1, w2, w3, pad
+    const int dst = row_begin(offsets, tile_base, a.x) + a.y;
+    reinterpret_cast<int4*>(entries + dst)[0] = make_int4(a.z, a.w, b.x, b.y);
+    reinterpret_cast<int4*>(entries + dst)[1] = make_int4(b.z, 0, 0, 0);
+  }
+}
+
+// One wave per patch; lane owns 4 consecutive channels of a 256-channel chunk; 4 accumulators (the patch's pixels).
+// Workgroup = 2x2 patches; stripes of 8 patch rows go round-robin to the XCDs (see csr_gather_kernel).
+// img_h / img_w: pixel size of one image; keys = images x ceil(img_h/2) x ceil(img_w/2) patches.
+// A patch's entries are fetched 64 at a time, one per lane (one coalesced 2 KiB read), and handed round by readlane:
+// no scalar-load latency inside the loop, UNROLL row loads issued back to back (the row loads are L2 latency bound:
+// with 4 in flight behind a scalar entry load per iteration this kernel ran 46 us, patch-keyed or not).
+template <int UNROLL>
+static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const float* __restrict__ gT,
+                                                              const int* __restrict__ offsets,
+                                                              const int* __restrict__ tile_base, int ntiles,
+                                                              const PatchEntry* __restrict__ entries, int nkeys,
+                                                              int C, int n_img, int img_h, int img_w,
+                                                              int* __restrict__ counts, float* __restrict__ grad_in) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int php = (img_h + 1) >> 1, pwp = (img_w + 1) >> 1;
+  const int bw = (pwp + 1) >> 1;                               // workgroups per row of patches
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int stripe = xcd + 8 * (j / (4 * bw));                 // 4 workgroup rows = 8 patch rows per stripe
+  const int local = j % (4 * bw);
+  const int prow = (stripe * 4 + local / bw) * 2 + (wave >> 1);   // over all images stacked
+  const int pcol = (local % bw) * 2 + (wave & 1);
+  if (prow >= n_img * php || pcol >= pwp) return;
+  const int p = prow * pwp + pcol;
+  const int img = prow / php, py = prow - img * php;
+  const int beg = __builtin_amdgcn_readfirstlane(row_begin(offsets, tile_base, p));
+  const int end = __builtin_amdgcn_readfirstlane(p + 1 < nkeys ? row_begin(offsets, tile_base, p + 1)
+                                                               : tile_base[ntiles]);
+  if (lane == 0) counts[p] = 0;
+  const int y0 = py * 2, x0 = pcol * 2;
+  const bool has_y1 = y0 + 1 < img_h, has_x1 = x0 + 1 < img_w;
+  float* __restrict__ out0 = grad_in + ((size_t)(img * img_h + y0) * img_w + x0) * C;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + lane * 4;
+    const bool ok = c < C;                       // C % 4 == 0 on this path
+    const float* __restrict__ col = gT + (ok ? c : 0);
+    v4f acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int base = beg; base < end; base += 64) {
+      const int n = min(64, end - base);
+      // lane l: entry base + l; lanes past the end: the batch's first source row with zero weights (a cached address)
+      const int4 a = reinterpret_cast<const int4*>(entries + base + (lane < n ? lane : 0))[0];
+      const float w3 = reinterpret_cast<const float*>(entries + base + (lane < n ? lane : 0))[4];
+      const int e_src = a.x;
+      const float e_w[4] = {lane < n ? __int_as_float(a.y) : 0.f, lane < n ? __int_as_float(a.z) : 0.f,
+                            lane < n ? __int_as_float(a.w) : 0.f, lane < n ? w3 : 0.f};
+      for (int i = 0; i < n; i += UNROLL) {
+        v4f v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          const int src = __builtin_amdgcn_readlane(e_src, (i + u) & 63);
+          v[u] = *reinterpret_cast<const v4f*>(col + (size_t)src * C);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_w[q]), (i + u) & 63));
+            acc[q] += w * v[u];
+          }
+      }
+    }
+    if (ok) {
+      *reinterpret_cast<v4f*>(out0 + c) = acc[0];
+      if (has_x1) *reinterpret_cast<v4f*>(out0 + C + c) = acc[1];
+      if (has_y1) *reinterpret_cast<v4f*>(out0 + (size_t)img_w * C + c) = acc[2];
+      if (has_y1 && has_x1) *reinterpret_cast<v4f*>(out0 + (size_t)(img_w + 1) * C + c) = acc[3];
+    }
+  }
+}
+
+// counts[] hold the row lengths, segment g of recs its seg_n[g] kept taps, counts[nkeys] (ticket) is zero.
+// On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
+inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
+                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
+  const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
+                     w.tile_sum, w.tile_base, w.counts + nkeys);
+  hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
+                     w.offsets, w.tile_base, w.entries);
+  const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
+  const int wg_rows = (n_img * php + 1) / 2, stripes = (wg_rows + 3) / 4;
+  const unsigned blocks = 8u * (unsigned)((stripes + 7) / 8) * 4u * (unsigned)bw;
+  hipLaunchKernelGGL((csr_gather_patch_kernel<8>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
+                     ntiles, w.entries, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
+  return jdet_launch_status();
+}
+
 }  // namespace jdet_csr

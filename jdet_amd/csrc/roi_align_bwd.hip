@@ -31,77 +31,104 @@ namespace {
 using namespace jdet_roi;
 using namespace jdet_csr;
 
+long patch_keys(int N, int H, int W) { return (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
+
 // One workgroup per RoI: thread 0 does the geometry (double-precision trig included) once, then one lane per
-// (bin, sample) lists its 4 taps.
+// (bin, sample) turns its 4 taps into patch entries (csr_gather.h: key = aligned 2x2 pixel patch, 4 weights), merges
+// the entries of its bin that share a patch (the 4 samples of a bin are 4 consecutive lanes), counts the survivors in
+// their patch's row (integer atomic, the return value is the place in the row) and writes them, compacted through an
+// LDS counter, into the RoI's own record segment (no global cursor: the fill launch walks the segments).
 template <int VARIANT>
-__global__ __launch_bounds__(256) void bwd_taps_kernel(const float* __restrict__ rois, int H, int W, int PH, int PW,
-                                                      float spatial_scale, int sample_num,
-                                                      int* __restrict__ tap_key, int* __restrict__ tap_pos,
-                                                      float* __restrict__ tap_w, int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __restrict__ rois, int H, int W, int PH,
+                                                            int PW, float spatial_scale, int sample_num,
+                                                            TapRec* __restrict__ recs, int* __restrict__ seg_n,
+                                                            int* __restrict__ counts) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
   __shared__ RoiGeom s_geom;
+  __shared__ int s_n;
   const int r = blockIdx.x;
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
     s_geom = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
+    s_n = 0;
+  }
   __syncthreads();
   const RoiGeom g = s_geom;
   const int nbins = PH * PW, spb = sample_num * sample_num, S = nbins * spb;
-  const int base = g.batch * H * W;
-  for (int s = threadIdx.x; s < S; s += 256) {   // S % 4 == 0 when spb == 4: a quad of lanes enters or leaves together
+  const int php = (H + 1) >> 1, pwp = (W + 1) >> 1;
+  const int kbase = g.batch * php * pwp;
+  const int lane = threadIdx.x & 63, q = lane & 3, qbase = lane & ~3;
+  for (int s0 = 0; s0 < S; s0 += 256) {       // a quad of lanes is active or idle together (S % 4 == 0 when spb == 4)
+    const bool active = s0 + (int)threadIdx.x < S;
+    const int s = active ? s0 + threadIdx.x : S - 1;
     const int bin = s / spb, rr = s % spb;
-    const long t = (long)r * S + s;
-    const Sample sm = make_sample<VARIANT>(g, bin / PW, bin % PW, rr / sample_num, rr % sample_num, H, W);
-    const int o[4] = {sm.o1, sm.o2, sm.o3, sm.o4};
-    float w[4] = {sm.w1 / g.count, sm.w2 / g.count, sm.w3 / g.count, sm.w4 / g.count};
+    const SamplePos sp = sample_pos<VARIANT>(g, bin / PW, bin % PW, rr / sample_num, rr % sample_num, H, W);
+    const int valid = active && sp.valid && g.batch >= 0;     // batch < 0: masked RoI
+    const float hy = (float)(1. - (double)sp.ly), hx = (float)(1. - (double)sp.lx);   // as make_sample
+    const float w0[4] = {(hy * hx) / g.count, (hy * sp.lx) / g.count, (sp.ly * hx) / g.count,
+                         (sp.ly * sp.lx) / g.count};
+    const int ys[4] = {sp.y_low, sp.y_low, sp.y_high, sp.y_high};
+    const int xs[4] = {sp.x_low, sp.x_high, sp.x_low, sp.x_high};
+    int key[4], slot[4];
+    float wv[4][4];
     bool first[4] = {true, true, true, true};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      key[k] = kbase + (ys[k] >> 1) * pwp + (xs[k] >> 1);
+      slot[k] = (ys[k] & 1) * 2 + (xs[k] & 1);
+#pragma unroll
+      for (int i = 0; i < 4; i++) wv[k][i] = slot[k] == i ? w0[k] : 0.f;
+    }
+    // own taps that share a patch: the first one collects
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < k; j++)
+        if (key[j] == key[k]) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) wv[j][i] += slot[k] == i ? w0[k] : 0.f;
+          first[k] = false;
+        }
     if (spb == 4) {
-      // the 4 samples of a bin are 4 consecutive lanes: taps of the bin that hit the same pixel read the same
-      // grad_out row -> one entry with the summed weight (as in the forward kernel; 58 % of the taps survive on the
-      // bench RoIs), fewer rows for the gather to fetch
-      const int lane = threadIdx.x & 63, q = lane & 3, qbase = lane & ~3;
-      const float w0[4] = {w[0], w[1], w[2], w[3]};
-#pragma unroll
-      for (int k = 1; k < 4; k++)
-#pragma unroll
-        for (int j = 0; j < k; j++)
-          if (o[j] == o[k]) {
-            w[j] += w0[k];
-            first[k] = false;
-          }
+      // the other three samples of the bin (same quad of lanes; S % 4 == 0, so a quad is active or idle together):
+      // every tap of theirs in one of my patches adds its weight; a tap of mine survives only if no lower lane of
+      // the quad has one in the same patch
 #pragma unroll
       for (int d = 1; d < 4; d++) {
         const int src = qbase | ((q + d) & 3);
         const bool earlier = ((q + d) & 3) < q;
-        const int ov = __shfl(sm.valid, src, 64);
+        const int ov = __shfl(valid, src, 64);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          const int oo = __shfl(o[j], src, 64);
-          const float ww = __shfl(w0[j], src, 64);
+          const int ok = __shfl(key[j], src, 64);
+          const int os = __shfl(slot[j], src, 64);
+          const float ow = __shfl(w0[j], src, 64);
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            const bool same = ov && oo == o[k];
-            w[k] += same ? ww : 0.f;
+            const bool same = ov && ok == key[k];
+#pragma unroll
+            for (int i = 0; i < 4; i++) wv[k][i] += (same && os == i) ? ow : 0.f;
             first[k] = first[k] && !(same && earlier);
           }
         }
       }
     }
-    int4 key4, pos4;
-    int* key = &key4.x;
-    int* pos = &pos4.x;
+    const int src_row = r * nbins + bin;
+    TapRec* __restrict__ seg = recs + (size_t)r * S * 4;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      key[k] = -1;
-      pos[k] = 0;
-      if (sm.valid && first[k] && w[k] != 0.f && g.batch >= 0) {  // batch < 0: masked RoI
-        key[k] = base + o[k];
-        pos[k] = atomicAdd(&counts[key[k]], 1);
+      const bool keep = valid && first[k] &&
+                        (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
+      if (keep) {
+        const int pos = atomicAdd(&counts[key[k]], 1);
+        const int local = atomicAdd(&s_n, 1);
+        int4* dst = reinterpret_cast<int4*>(seg + local);
+        dst[0] = make_int4(key[k], pos, src_row, __float_as_int(wv[k][0]));
+        dst[1] = make_int4(__float_as_int(wv[k][1]), __float_as_int(wv[k][2]), __float_as_int(wv[k][3]), 0);
       }
     }
-    reinterpret_cast<int4*>(tap_key)[t] = key4;
-    reinterpret_cast<int4*>(tap_pos)[t] = pos4;
-    reinterpret_cast<float4*>(tap_w)[t] = make_float4(w[0], w[1], w[2], w[3]);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) seg_n[r] = s_n;
 }
 
 // (R, C, nbins) -> (R, nbins, C), 32x32 LDS tiles
@@ -129,20 +156,22 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
                float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, bool ws_clean,
                hipStream_t st) {
   const int nbins = PH * PW, spb = sample_num * sample_num;
-  const long npix = (long)N * H * W, ntaps = (long)R * nbins * spb * 4;
-  CsrWs w = csr_carve(ws, npix, ntaps);
+  const long nkeys = patch_keys(N, H, W), seg_cap = (long)nbins * spb * 4;
+  PatchWs w = patch_carve(ws, nkeys, R, seg_cap);
   float* gT = (float*)((char*)ws + w.bytes);
-  if (!ws_clean) {   // workspace of unknown content: zero the row counters + ticket (a clean one is handed back clean)
-    int he = jdet_zero_async(w.counts, csr_zero_bytes(npix), st);
+  if (!ws_clean) {   // workspace of unknown content: zero the row counters and the ticket (a clean one is handed back clean)
+    int he = jdet_zero_async(w.counts, patch_zero_bytes(nkeys), st);
     if (he) return he;
   }
-  hipLaunchKernelGGL((bwd_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale, sample_num,
-                     w.tap_key, w.tap_pos, w.tap_w, w.counts);
-  if (grad_out_cl)   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
-    return csr_finish_and_gather(w, npix, ntaps, spb * 4, grad_out, C, grad_in, W, N * H, st);
-  dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
-  hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
-  return csr_finish_and_gather(w, npix, ntaps, spb * 4, gT, C, grad_in, W, N * H, st);
+  hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
+                     sample_num, w.recs, w.seg_n, w.counts);
+  const float* rows = grad_out;   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
+  if (!grad_out_cl) {
+    dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
+    hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
+    rows = gT;
+  }
+  return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st);
 }
 
 }  // namespace
@@ -162,8 +191,8 @@ static bool gather_ok(int variant, int R, int N, int C, int H, int W, int PH, in
 JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                                  int sample_num) {
   if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
-  const long npix = (long)N * H * W, ntaps = (long)R * PH * PW * sample_num * sample_num * 4;
-  return csr_carve(nullptr, npix, ntaps).bytes + align256(sizeof(float) * (size_t)R * PH * PW * C);
+  return patch_carve(nullptr, patch_keys(N, H, W), R, (long)PH * PW * sample_num * sample_num * 4).bytes +
+         align256(sizeof(float) * (size_t)R * PH * PW * C);
 }
 
 // Bytes at the start of the workspace that the gather path needs zero on entry and leaves zero on return (the row
@@ -171,7 +200,7 @@ JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int
 JDET_API size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                                    int sample_num) {
   if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
-  return csr_zero_bytes((long)N * H * W);
+  return patch_zero_bytes(patch_keys(N, H, W));
 }
 
 static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,

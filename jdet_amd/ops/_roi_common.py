@@ -92,11 +92,11 @@ def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
 _BWD_WS = {}
 
 
-def _kept_backward_workspace(dev, npix, nbytes):
+def _kept_backward_workspace(dev, map_shape, nbytes):
     """Workspace of the channels-last backward, kept per (device, stream, map size): zero-filled once; the call hands
     its counters back zeroed (`workspace_clean` contract of jdet_roi_align_backward_cl), so no memset launch per
     step.  One buffer per map size: the zeroed region's length depends on it."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, npix)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tuple(map_shape))
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
@@ -115,7 +115,7 @@ def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_o
         g_out = g_out.float()
     wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
     if wsb and R and g_out.is_contiguous(memory_format=torch.channels_last) and not g_out.is_contiguous():
-        ws, key = _kept_backward_workspace(g_out.device, N * H * W, wsb)
+        ws, key = _kept_backward_workspace(g_out.device, (N, H, W), wsb)
         try:
             L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
                                                        scale, sample_num, L.ptr(grad_in), L.ptr(ws), ws.numel(), 1,

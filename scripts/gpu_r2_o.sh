@@ -4,7 +4,7 @@ set -u
 OUT=$PWD/gpurun_out/r2_o
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_closed_form.py tests/test_gpu_dcn_arf.py -x -q -m gpu > $OUT/pytest.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_closed_form.py tests/test_gpu_dcn_arf.py tests/test_gpu_oriented_rcnn.py -x -q -m gpu > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" >> $OUT/pytest.log
 tail -5 $OUT/pytest.log
 timeout 200 python bench.py --workload roi_align_rotated_bwd --no-cpu-baseline > $OUT/bench_bwd.json 2> $OUT/bench_bwd.err
