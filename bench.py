@@ -121,7 +121,7 @@ def make_step(workload, d):
             if use_order:
                 L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
             if cl:
-                L.check(lib.jdet_roi_align_forward_cl_roi(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2,
+                L.check(lib.jdet_roi_align_forward_cl_roi(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
                                                           o0 if use_order else None, op, st), "fwd_cl_roi")
             else:
                 L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
@@ -145,7 +145,7 @@ def make_step(workload, d):
 
         def step():
             if cl and wsb:
-                L.check(lib.jdet_roi_align_backward_cl(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, ip, wp, wsb, 1,
+                L.check(lib.jdet_roi_align_backward_cl(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, ip, wp, wsb, 1,
                                                        L.stream_ptr(feat)), "bwd_cl")
             else:
                 L.check(lib.jdet_roi_align_backward(0, gp, rp, R, 1, 256, 256, 256, 7, 7, 0.25, 2, 1, None, ip,

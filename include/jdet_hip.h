@@ -98,12 +98,12 @@ int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C,
 
 /* RoI-stationary forward (the kernels of jdet_roi_align_forward) with the channels-last result layout
  * out_cl (R, PH, PW, C): each wave stores a bin's channel chunk straight from registers (1 KiB contiguous,
- * non-temporal) instead of transposing the RoI's block through LDS.  Rotated v0 / v1 and horizontal v0 / v1,
- * C % 4 == 0, any sample_num (<= 0 adaptive); otherwise JDET_E_UNSUPPORTED.  `order` as in
- * jdet_roi_align_forward. */
+ * non-temporal) instead of transposing the RoI's block through LDS.  Rotated v0 / v1, horizontal v0 / v1 and
+ * RiRoIAlign with n_orient 4 or 8 (ignored for the other dialects), C % 4 == 0, any sample_num (<= 0 adaptive);
+ * otherwise JDET_E_UNSUPPORTED.  `order` as in jdet_roi_align_forward. */
 int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, int C, int H, int W,
                                   const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
-                                  const int32_t* order, float* out_cl, jdet_stream_t stream);
+                                  int n_orient, const int32_t* order, float* out_cl, jdet_stream_t stream);
 
 /* Profiling hook of the tile kernel (scripts/tile_timeline.py): buf = device array of 32 uint64 per workgroup
  * (s_memtime stamps at the phase boundaries, hardware id in slot 31), or NULL to switch it off. */
@@ -148,7 +148,7 @@ int jdet_roi_align_backward(int variant, const float* grad_out, const float* roi
 size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                            int sample_num);
 int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N, int C,
-                               int H, int W, int PH, int PW, float spatial_scale, int sample_num,
+                               int H, int W, int PH, int PW, float spatial_scale, int sample_num, int n_orient,
                                float* grad_in_nhwc, void* workspace, size_t workspace_bytes, int workspace_clean,
                                jdet_stream_t stream);
 

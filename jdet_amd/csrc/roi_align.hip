@@ -46,7 +46,68 @@ __device__ __forceinline__ void acc_sample4(float (&acc)[4], float w1, float w2,
   acc[3] += (w1 * lt.w + w2 * rt.w + w3 * lb.w + w4 * rb.w);
 }
 
-// ---- vector fast path: C % 4 == 0, every dialect except RiRoI, map < 2 GiB per image ----------
+// RiRoIAlign (riroi_align.py:L130-152): the channels are C/nO groups of nO orientation planes, and output plane o of
+// a group is  r_var * plane (o - ind) + l_var * plane (o - ind + 1)  (indices mod nO) of the sampled value, `ind` and
+// the two fractions being per-RoI constants.  Lane owns 4 consecutive channels: a whole group when nO == 4, half of
+// one when nO == 8 (the other half sits in the neighbouring lane).  IND is a template argument (the caller switches
+// on the wave-uniform `ind`), so every plane lookup is a static register pick -- plus one select on the lane's
+// parity when nO == 8, where the two lanes of a pair need planes 4 apart.  Accumulates in the reference's order:
+// acc += r_var * val + l_var * val_plus, once per sample.
+template <int NO, int IND>
+__device__ __forceinline__ void ri_accumulate(float (&acc)[4], const float (&val)[4], int lane, float r_var,
+                                              float l_var) {
+  if (NO == 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      acc[k] += r_var * val[(k - IND + 4) & 3] + l_var * val[(k - IND + 5) & 3];
+  } else {
+    const bool odd = lane & 1;
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float other = __shfl_xor(val[k], 1, 64);
+      a[k] = odd ? other : val[k];          // planes 0..3 of the group
+      a[4 + k] = odd ? val[k] : other;      // planes 4..7
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {           // this lane's output plane o = 4 * odd + k
+      const int i0 = (k - IND + 8) & 7, i1 = (k - IND + 9) & 7;
+      const float v = odd ? a[i0 ^ 4] : a[i0];
+      const float vp = odd ? a[i1 ^ 4] : a[i1];
+      acc[k] += r_var * v + l_var * vp;
+    }
+  }
+}
+
+template <int NO>
+__device__ __forceinline__ void ri_dispatch(float (&acc)[4], const float (&val)[4], int lane, int ind, float r_var,
+                                            float l_var) {
+  switch (ind) {   // wave-uniform
+    case 0: ri_accumulate<NO, 0>(acc, val, lane, r_var, l_var); break;
+    case 1: ri_accumulate<NO, 1>(acc, val, lane, r_var, l_var); break;
+    case 2: ri_accumulate<NO, 2>(acc, val, lane, r_var, l_var); break;
+    case 3: ri_accumulate<NO, 3>(acc, val, lane, r_var, l_var); break;
+    case 4: ri_accumulate<NO, 4 % NO>(acc, val, lane, r_var, l_var); break;
+    case 5: ri_accumulate<NO, 5 % NO>(acc, val, lane, r_var, l_var); break;
+    case 6: ri_accumulate<NO, 6 % NO>(acc, val, lane, r_var, l_var); break;
+    default: ri_accumulate<NO, 7 % NO>(acc, val, lane, r_var, l_var); break;
+  }
+}
+
+// one sample into the lane's 4 accumulators; NO == 0: plain RoIAlign, NO == 4 / 8: RiRoIAlign with that many planes
+template <int NO>
+__device__ __forceinline__ void acc_sample(float (&acc)[4], const RoiGeom& g, int lane, float w1, float w2, float w3,
+                                           float w4, const v4f& lt, const v4f& rt, const v4f& lb, const v4f& rb) {
+  if constexpr (NO == 0) {
+    acc_sample4(acc, w1, w2, w3, w4, lt, rt, lb, rb);
+  } else {
+    const float val[4] = {(w1 * lt.x + w2 * rt.x + w3 * lb.x + w4 * rb.x), (w1 * lt.y + w2 * rt.y + w3 * lb.y + w4 * rb.y),
+                          (w1 * lt.z + w2 * rt.z + w3 * lb.z + w4 * rb.z), (w1 * lt.w + w2 * rt.w + w3 * lb.w + w4 * rb.w)};
+    ri_dispatch<NO>(acc, val, lane, g.ind, g.r_var, g.l_var);
+  }
+}
+
+// ---- vector fast path: C % 4 == 0, map < 2 GiB per image; RiRoI with 4 or 8 orientation planes -------------
 // Lane owns 4 consecutive channels.  Taps are fetched with buffer_load_dwordx4 whose per-tap
 // pixel byte offset is an SGPR (soffset) -- no per-load 64-bit VALU address arithmetic -- and the
 // per-sample geometry is broadcast from the owning lane with v_readlane.
@@ -59,10 +120,11 @@ __device__ __forceinline__ void acc_sample4(float (&acc)[4], float w1, float w2,
 template <int VARIANT, bool TRIG = true>
 __device__ __forceinline__ RoiGeom vec_prologue(const float* feat, const float* rois, int r, int C, int H,
                                                 int W, int PH, int PW, float spatial_scale,
-                                                int sample_num, __amdgpu_buffer_rsrc_t& rsrc) {
+                                                int sample_num, __amdgpu_buffer_rsrc_t& rsrc, int nO = 1) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
-  RoiGeom g = roi_geom<VARIANT, TRIG>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, false);
+  RoiGeom g = roi_geom<VARIANT, TRIG>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, nO, false);
   g.batch = __builtin_amdgcn_readfirstlane(g.batch);
+  g.ind = __builtin_amdgcn_readfirstlane(g.ind);
   g.grid_h = __builtin_amdgcn_readfirstlane(g.grid_h);
   g.grid_w = __builtin_amdgcn_readfirstlane(g.grid_w);
   const float* img = feat + (size_t)g.batch * H * W * C;
@@ -79,7 +141,7 @@ __device__ __forceinline__ RoiGeom vec_prologue(const float* feat, const float* 
 // byte offset is an SGPR; results go to s_out[channel][bin].  NW waves split the bins.
 // OUT_CL: results go straight from registers to the channels-last output row (r, bin, c0 + 4*lane .. +3) -- one
 // contiguous 1 KiB non-temporal store per (wave, bin), no LDS staging; otherwise to s_out[channel][bin].
-template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false>
+template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false, int NO = 0>
 __device__ __forceinline__ void direct_chunk(const RoiGeom& g, const __amdgpu_buffer_rsrc_t rsrc, int c0,
                                              int cc, int C, int H, int W, int PW, int nbins, int wave,
                                              int lane, float* __restrict__ s_out, float* __restrict__ out_row = nullptr) {
@@ -148,19 +210,20 @@ __device__ __forceinline__ void direct_chunk(const RoiGeom& g, const __amdgpu_bu
             } else {
 #pragma unroll
               for (int u = 0; u < SG; u++)
-                acc_sample4(acc, sv[u].w1, sv[u].w2, sv[u].w3, sv[u].w4, t[u][0], t[u][1], t[u][2], t[u][3]);
+                acc_sample<NO>(acc, g, lane, sv[u].w1, sv[u].w2, sv[u].w3, sv[u].w4, t[u][0], t[u][1], t[u][2], t[u][3]);
             }
           } else {
 #pragma unroll
             for (int u = 0; u < SG; u++)
               if (sv[u].valid)
-                acc_sample4(acc, sv[u].w1, sv[u].w2, sv[u].w3, sv[u].w4, tap(sv[u].o1), tap(sv[u].o2),
-                            tap(sv[u].o3), tap(sv[u].o4));
+                acc_sample<NO>(acc, g, lane, sv[u].w1, sv[u].w2, sv[u].w3, sv[u].w4, tap(sv[u].o1), tap(sv[u].o2),
+                               tap(sv[u].o3), tap(sv[u].o4));
           }
         }
         for (; j < ns; j++) {
           const Sample s = bcast(mine, lane0 + j);
-          if (s.valid) acc_sample4(acc, s.w1, s.w2, s.w3, s.w4, tap(s.o1), tap(s.o2), tap(s.o3), tap(s.o4));
+          if (s.valid)
+            acc_sample<NO>(acc, g, lane, s.w1, s.w2, s.w3, s.w4, tap(s.o1), tap(s.o2), tap(s.o3), tap(s.o4));
         }
       }
       if (lane_ok) {
@@ -176,7 +239,7 @@ __device__ __forceinline__ void direct_chunk(const RoiGeom& g, const __amdgpu_bu
   }
 }
 
-template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false>
+template <int VARIANT, int NW, int SG, int ABL, bool OUT_CL = false, int NO = 0>
 __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
@@ -190,14 +253,15 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   __amdgpu_buffer_rsrc_t rsrc;
-  const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc);
+  const RoiGeom g = vec_prologue<VARIANT>(feat, rois, r, C, H, W, PH, PW, spatial_scale, sample_num, rsrc,
+                                          NO ? NO : 1);
   if (g.batch < 0) return;  // masked RoI (belongs to another pyramid level): its output rows are not ours
   if (OUT_CL) {
-    direct_chunk<VARIANT, NW, SG, ABL, true>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out,
-                                             out + (size_t)r * nbins * C);
+    direct_chunk<VARIANT, NW, SG, ABL, true, NO>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out,
+                                                 out + (size_t)r * nbins * C);
     return;
   }
-  direct_chunk<VARIANT, NW, SG, ABL>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out);
+  direct_chunk<VARIANT, NW, SG, ABL, false, NO>(g, rsrc, c0, cc, C, H, W, PW, nbins, wave, lane, s_out);
   __syncthreads();
   float* __restrict__ dst = out + ((size_t)r * C + c0) * nbins;
   if (ABL & 4) {
@@ -227,7 +291,9 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_vec_kernel(
 //   * sin/cos in double once per workgroup (wave 0) instead of once per wave.
 // Result = reference value up to fp32 re-association of the weights (<= a few ulp of sum|w.v|);
 // jdet_set_roi_forward_mode(1) selects the reference-order kernel above (bit-identical to the oracle).
-template <int VARIANT, int NW, int ABL = 0, bool OUT_CL = false>
+// NO = 4 / 8: RiRoIAlign -- VARIANT is the rotated geometry, the orientation planes are mixed once per bin on the
+// finished sum (the reference mixes per sample: equal up to fp32 re-association, like the merged weights).
+template <int VARIANT, int NW, int ABL = 0, bool OUT_CL = false, int NO = 0>
 __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
     const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
     int C, int H, int W, int PH, int PW, float spatial_scale, const int32_t* __restrict__ order, int abl_mask) {
@@ -304,6 +370,12 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
       }
     }
   }
+  int ri_ind = 0;
+  float ri_l = 0.f, ri_r = 1.f;
+  if (NO) {
+    ri_params(roi[5], NO, ri_ind, ri_l, ri_r);
+    ri_ind = __builtin_amdgcn_readfirstlane(ri_ind);
+  }
   const float inv_count = 1.f / g.count;   // count == 4 here: exact
   int keep[4], mycnt = 0;
 #pragma unroll
@@ -364,6 +436,12 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
           acc.w = __builtin_fmaf(wt, t[b][i].w, acc.w);
         }
       }
+    if constexpr (NO != 0) {
+      const float val[4] = {acc.x, acc.y, acc.z, acc.w};
+      float mixed[4] = {0.f, 0.f, 0.f, 0.f};
+      ri_dispatch<NO>(mixed, val, lane, ri_ind, ri_r, ri_l);
+      acc = v4f{mixed[0], mixed[1], mixed[2], mixed[3]};
+    }
     if (lane_ok) {
       if (OUT_CL) {   // channels-last row (r, bin, :): one contiguous 1 KiB store per wave, no LDS staging
         __builtin_nontemporal_store(acc, reinterpret_cast<v4f*>(out + ((size_t)r * nbins + bin) * C + c0 + lane * 4));
@@ -801,6 +879,32 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
   dim3 grid(R, chunks);
   const bool vec = (C % 4 == 0) && VARIANT != JDET_ROI_RIROI && (size_t)H * W * C * 4 < (1ull << 31);
   const int nbins = PH * PW;
+  const bool big_ok = (C % 4 == 0) && (size_t)H * W * C * 4 < (1ull << 31);
+  if (VARIANT == JDET_ROI_RIROI && big_ok && (nO == 4 || nO == 8)) {
+    // orientation planes mixed in registers.  Default: merged-tap kernel + one mix per bin; reference-order mode
+    // (or sampling other than 2x2): the per-sample kernel, bit-identical to the scalar one.
+    const bool merged = sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && (out_cl || lds >= 8 * 2048);
+    const size_t lds_m = out_cl ? 8 * 2048 : lds, lds_v = out_cl ? 16 : lds;
+#define JDET_RI(NO_)                                                                                              \
+  do {                                                                                                            \
+    if (merged && out_cl)                                                                                         \
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<JDET_ROI_ROTATED, 4, 0, true, NO_>), grid, dim3(256), lds_m, \
+                         st, feat, rois, out, C, H, W, PH, PW, scale, order, 0);                                  \
+    else if (merged)                                                                                              \
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<JDET_ROI_ROTATED, 4, 0, false, NO_>), grid, dim3(256), lds_m, \
+                         st, feat, rois, out, C, H, W, PH, PW, scale, order, 0);                                  \
+    else if (out_cl)                                                                                              \
+      hipLaunchKernelGGL((roi_align_fwd_vec_kernel<JDET_ROI_RIROI, 4, 4, 0, true, NO_>), grid, dim3(256), lds_v, st, \
+                         feat, rois, out, C, H, W, PH, PW, scale, sample_num, order);                             \
+    else                                                                                                          \
+      hipLaunchKernelGGL((roi_align_fwd_vec_kernel<JDET_ROI_RIROI, 4, 4, 0, false, NO_>), grid, dim3(256), lds_v, st, \
+                         feat, rois, out, C, H, W, PH, PW, scale, sample_num, order);                             \
+  } while (0)
+    if (nO == 8) JDET_RI(8);
+    else JDET_RI(4);
+#undef JDET_RI
+    return jdet_launch_status();
+  }
   if (out_cl) {   // channels-last output: vector kernels only (the callers check jdet_roi_align_forward_cl_supported)
     if (!vec) return JDET_E_UNSUPPORTED;
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
@@ -954,10 +1058,12 @@ JDET_API int jdet_roi_align_forward(int variant, const float* feat, int N, int C
 // registers (one contiguous 1 KiB row chunk per wave and bin) instead of being transposed through LDS.
 JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N, int C, int H, int W,
                                            const float* rois, int R, int PH, int PW, float spatial_scale,
-                                           int sample_num, const int32_t* order, float* out_cl, jdet_stream_t stream) {
-  int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, 1);
+                                           int sample_num, int n_orient, const int32_t* order, float* out_cl,
+                                           jdet_stream_t stream) {
+  int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, n_orient);
   if (e) return e;
-  if (variant == JDET_ROI_RIROI || C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
+  if (C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
+  if (variant == JDET_ROI_RIROI && n_orient != 4 && n_orient != 8) return JDET_E_UNSUPPORTED;
   if (R == 0) return JDET_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (variant) {
@@ -965,6 +1071,8 @@ JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N
       return launch_fwd<JDET_ROI_ROTATED>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
     case JDET_ROI_ROTATED_V1:
       return launch_fwd<JDET_ROI_ROTATED_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
+    case JDET_ROI_RIROI:
+      return launch_fwd<JDET_ROI_RIROI>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, n_orient, order, st, true);
     case JDET_ROI_HBB_V0:
       return launch_fwd<JDET_ROI_HBB_V0>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
     default:

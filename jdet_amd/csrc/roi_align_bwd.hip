@@ -22,7 +22,8 @@
 //       workspace (workspace_clean) pays no memset launch.
 // Summation order inside a pixel follows slot order (integer-atomic order), i.e. it is as
 // order-nondeterministic in the last bits as the reference's atomics; values agree to fp32 tolerance.
-// RiRoIAlign and adaptive sampling (sample_num <= 0, unbounded samples per bin) keep the atomic path.
+// RiRoIAlign runs the same gather on orientation-mixed gradient rows (riroi_mix_rows_kernel); adaptive sampling
+// (sample_num <= 0, unbounded samples per bin) keeps the atomic path.
 #include "csr_gather.h"
 #include "roi_geom.h"
 
@@ -151,10 +152,29 @@ __global__ __launch_bounds__(256) void bwd_transpose_kernel(const float* __restr
   }
 }
 
+// RiRoIAlign backward = rotated RoIAlign backward of the orientation-mixed gradient: with
+// out(c, o) = r * val(c, o - ind) + l * val(c, o - ind + 1)   (plane indices mod nO; riroi_align.py:L130-152),
+// d val(c, j) = r * G(c, j + ind) + l * G(c, j + ind - 1).  One thread per (row, channel group) of the (R, nbins, C)
+// row matrix; src == dst is fine: the nO planes of a group are read into registers before any is written.
+__global__ __launch_bounds__(256) void riroi_mix_rows_kernel(const float* src, float* dst,
+                                                            const float* __restrict__ rois, long n_groups, int nbins,
+                                                            int groups_per_row, int nO) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_groups) return;
+  const long row = t / groups_per_row;
+  const int r = (int)(row / nbins);
+  int ind;
+  float l_var, r_var;
+  ri_params(rois[(size_t)r * 6 + 5], nO, ind, l_var, r_var);
+  float v[16];
+  for (int j = 0; j < nO; j++) v[j] = src[t * nO + j];
+  for (int j = 0; j < nO; j++) dst[t * nO + j] = r_var * v[(j + ind) % nO] + l_var * v[(j + ind - 1 + nO) % nO];
+}
+
 template <int VARIANT>
 int run_gather(const float* grad_out, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,
                float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, bool ws_clean,
-               hipStream_t st) {
+               hipStream_t st, int n_orient = 0) {
   const int nbins = PH * PW, spb = sample_num * sample_num;
   const long nkeys = patch_keys(N, H, W), seg_cap = (long)nbins * spb * 4;
   PatchWs w = patch_carve(ws, nkeys, R, seg_cap);
@@ -171,6 +191,12 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
     hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
     rows = gT;
   }
+  if (n_orient > 1) {   // RiRoIAlign: the gather reads orientation-mixed rows (written to the workspace copy)
+    const long n_groups = (long)R * nbins * (C / n_orient);
+    hipLaunchKernelGGL(riroi_mix_rows_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, rows, gT,
+                       rois, n_groups, nbins, C / n_orient, n_orient);
+    rows = gT;
+  }
   return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st);
 }
 
@@ -182,7 +208,7 @@ int jdet_roi_align_backward_atomic(int variant, const float* grad_out, const flo
                                    int n_orient, const int32_t* order, float* grad_in, hipStream_t st);
 
 static bool gather_ok(int variant, int R, int N, int C, int H, int W, int PH, int PW, int sample_num) {
-  if (variant == JDET_ROI_RIROI || sample_num <= 0 || C % 4 != 0 || R <= 0) return false;
+  if (sample_num <= 0 || C % 4 != 0 || R <= 0) return false;
   const long npix = (long)N * H * W, ntaps = (long)R * PH * PW * sample_num * sample_num * 4;
   if (npix >= (1L << 30) || ntaps >= (1L << 31) || (long)R * PH * PW >= (1L << 31) || R > 65535) return false;
   return true;
@@ -205,8 +231,11 @@ JDET_API size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, i
 
 static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,
                            int PH, int PW, float spatial_scale, int sample_num, float* grad_in, void* workspace,
-                           bool grad_out_cl, bool ws_clean, hipStream_t st) {
+                           bool grad_out_cl, bool ws_clean, hipStream_t st, int n_orient = 1) {
   switch (variant) {
+    case JDET_ROI_RIROI:   // rotated geometry; the orientation mix is applied to the gradient rows first
+      if (n_orient < 1 || n_orient > 16 || C % n_orient != 0) return JDET_E_UNSUPPORTED;
+      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st, n_orient);
     case JDET_ROI_ROTATED:
       return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
     case JDET_ROI_ROTATED_V1:
@@ -231,20 +260,23 @@ JDET_API int jdet_roi_align_backward(int variant, const float* grad_out, const f
   if (variant < 0 || variant > 4 || N <= 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || !grad_out ||
       !rois || !grad_in)
     return JDET_E_BADARG;
+  if (variant == JDET_ROI_RIROI && (n_orient < 1 || n_orient > 16 || C % n_orient != 0))
+    return jdet_roi_align_backward_atomic(variant, grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale,
+                                          sample_num, n_orient, order, grad_in, st);
   return backward_gather(variant, grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
-                         workspace, false, false, st);
+                         workspace, false, false, st, n_orient);
 }
 
 JDET_API int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const float* rois, int R, int N,
                                         int C, int H, int W, int PH, int PW, float spatial_scale, int sample_num,
-                                        float* grad_in, void* workspace, size_t workspace_bytes,
+                                        int n_orient, float* grad_in, void* workspace, size_t workspace_bytes,
                                         int workspace_clean, jdet_stream_t stream) {
   if (variant < 0 || variant > 4 || N < 0 || C <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || R < 0)
     return JDET_E_BADARG;
   const size_t need = jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num);
-  if (need == 0) return JDET_E_UNSUPPORTED;   // RiRoIAlign, adaptive sampling, C % 4, R == 0: use the (R,C,PH,PW) entry
+  if (need == 0) return JDET_E_UNSUPPORTED;   // adaptive sampling, C % 4, R == 0: use the (R,C,PH,PW) entry
   if (!workspace || workspace_bytes < need) return JDET_E_WORKSPACE;
   if (!grad_out_cl || !rois || !grad_in) return JDET_E_BADARG;
   return backward_gather(variant, grad_out_cl, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in,
-                         workspace, true, workspace_clean != 0, (hipStream_t)stream);
+                         workspace, true, workspace_clean != 0, (hipStream_t)stream, n_orient);
 }

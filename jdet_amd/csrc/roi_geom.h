@@ -22,6 +22,15 @@ struct RoiGeom {
   int ind;
 };
 
+// RiRoIAlign's per-RoI orientation constants (riroi_align.py:L105-113, PI literal L8)
+__device__ __forceinline__ void ri_params(float theta, int nO, int& ind, float& l_var, float& r_var) {
+  const float ind_float = (float)((double)(theta * nO) / (2 * 3.141592653));
+  const int fl = (int)floor(ind_float);
+  l_var = ind_float - (float)fl;
+  r_var = (float)(1.0 - (double)l_var);
+  ind = (fl + nO) % nO;
+}
+
 template <int VARIANT, bool TRIG = true>
 __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float spatial_scale,
                                             int sample_num, int PH, int PW, int nO, bool backward) {
@@ -72,14 +81,7 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float
     } else {
       g.cosT = g.sinT = 0.f;   // caller fills them in (computed once per workgroup)
     }
-    if (VARIANT == JDET_ROI_RIROI) {
-      // riroi_align.py:L105-113, PI literal L8
-      float ind_float = (float)((double)(theta * nO) / (2 * 3.141592653));
-      int ind = (int)floor(ind_float);
-      g.l_var = ind_float - (float)ind;
-      g.r_var = (float)(1.0 - (double)g.l_var);
-      g.ind = (ind + nO) % nO;
-    }
+    if (VARIANT == JDET_ROI_RIROI) ri_params(theta, nO, g.ind, g.l_var, g.r_var);
   }
   g.bin_h = roi_height / (float)PH;
   g.bin_w = roi_width / (float)PW;

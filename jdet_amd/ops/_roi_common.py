@@ -57,8 +57,10 @@ def _tile_ok(variant, C, H, W, PH, PW, sample_num):
         L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
 
 
-def _roi_cl_ok(variant, C, H, W):
-    return _FORWARD_PATH[0] == "roi_cl" and variant != V_RI and C % 4 == 0 and H * W * C * 4 < (1 << 31)
+def _roi_cl_ok(variant, C, H, W, n_orient=1):
+    if variant == V_RI and n_orient not in (4, 8):
+        return False
+    return _FORWARD_PATH[0] == "roi_cl" and C % 4 == 0 and H * W * C * 4 < (1 << 31)
 
 
 _PLAN_WS = {}
@@ -118,8 +120,9 @@ def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_o
         ws, key = _kept_backward_workspace(g_out.device, (N, H, W), wsb)
         try:
             L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
-                                                       scale, sample_num, L.ptr(grad_in), L.ptr(ws), ws.numel(), 1,
-                                                       L.stream_ptr(g_out)), "jdet_roi_align_backward_cl")
+                                                       scale, sample_num, int(n_orient), L.ptr(grad_in), L.ptr(ws),
+                                                       ws.numel(), 1, L.stream_ptr(g_out)),
+                    "jdet_roi_align_backward_cl")
         except Exception:
             _BWD_WS.pop(key, None)      # state unknown after a failed call: start from a fresh zeroed buffer
             raise
@@ -162,13 +165,13 @@ class RoIAlignFunction(torch.autograd.Function):
             order = None
             _forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num,
                         1 if _FORWARD_PATH[0] == "tile_exact" else 0)
-        elif _roi_cl_ok(variant, C, H, W):
+        elif _roi_cl_ok(variant, C, H, W, n_orient):
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
                               memory_format=torch.channels_last)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
             L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                                          float(spatial_scale), int(sample_num), L.ptr(order),
-                                                          L.ptr(out), L.stream_ptr(feat)),
+                                                          float(spatial_scale), int(sample_num), int(n_orient),
+                                                          L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
                     "jdet_roi_align_forward_cl_roi")
         else:
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
@@ -208,7 +211,7 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
         R = rois_c.shape[0]
         C = feats[0].shape[1]
         tile = all(_tile_ok(variant, C, f.shape[2], f.shape[3], PH, PW, sample_num) for f in feats)
-        roi_cl = (not tile) and all(_roi_cl_ok(variant, C, f.shape[2], f.shape[3]) for f in feats)
+        roi_cl = (not tile) and all(_roi_cl_ok(variant, C, f.shape[2], f.shape[3], n_orient) for f in feats)
         out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device,
                           memory_format=torch.channels_last if (tile or roi_cl) else torch.contiguous_format)
         exact = 1 if _FORWARD_PATH[0] == "tile_exact" else 0
@@ -224,8 +227,9 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
                 _forward_cl(variant, fm, r_i, out, PH, PW, scales[i], sample_num, exact)
             elif R and roi_cl:
                 L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
-                                                              float(scales[i]), int(sample_num), None, L.ptr(out),
-                                                              L.stream_ptr(fm)), "jdet_roi_align_forward_cl_roi")
+                                                              float(scales[i]), int(sample_num), int(n_orient), None,
+                                                              L.ptr(out), L.stream_ptr(fm)),
+                        "jdet_roi_align_forward_cl_roi")
             elif R:
                 L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                        float(scales[i]), int(sample_num), int(n_orient), None,

@@ -136,6 +136,39 @@ def test_channels_last_result_and_gradient(dev, variant, fwd_mode):
     np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("nO,C", [(8, 264), (4, 36), (8, 16), (2, 12)])
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 0)])
+def test_riroi_vector_path_vs_oracle(dev, nO, C, hw, s):
+    """RiRoIAlign on the vector kernels: orientation planes mixed in registers (nO = 8: a plane group spans a lane
+    pair; nO = 4: one lane), 264 channels = two channel chunks with a partial second one; nO = 2 stays on the scalar
+    kernel.  Forward bit-identical to the oracle (reference accumulation order), backward (mixed rows + sorted gather
+    for fixed sampling, atomics for adaptive) to accumulation-order tolerance.  Angles cover every orientation index
+    incl. negative theta."""
+    rng = np.random.default_rng(100 * nO + C)
+    N, H, W, scale, R = 2, 28, 36, 0.25, 60
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    obbs = I.random_obbs(rng, R, extent=W / scale, wh=(6.0, 120.0))
+    obbs[:, 4] = np.linspace(-2 * np.pi, 2 * np.pi, R).astype(np.float32)
+    rois = I.rois_from_obbs(obbs, rng.integers(0, N, R))
+    grad = rng.standard_normal((R, C) + hw).astype(np.float32)
+    from jdet_amd import _lib as L
+    ref = O.roi_align_forward(O.V_RI, feat, rois, hw, scale, s, nO)
+    gref = O.roi_align_backward(O.V_RI, grad, rois, feat.shape, scale, s, nO)
+    prev = L.lib().jdet_set_roi_forward_mode(1)          # reference accumulation order: bit-identical
+    try:
+        y, gi = _run(O.V_RI, feat, rois, hw, scale, s, grad, dev, True, nO)
+    finally:
+        L.lib().jdet_set_roi_forward_mode(prev)
+    assert np.array_equal(y, ref)
+    np.testing.assert_allclose(gi, gref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(gref).max()))
+    # default mode: merged taps, one orientation mix per bin, channels-last result and gradient
+    x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y2 = _layer(O.V_RI, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
+    y2.backward(torch.from_numpy(grad).to(dev).contiguous(memory_format=torch.channels_last))
+    np.testing.assert_allclose(y2.detach().cpu().numpy(), ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), gref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(gref).max()))
+
+
 def test_backward_cl_kept_workspace_contract(dev):
     """jdet_roi_align_backward_cl with workspace_clean=1 on ONE kept workspace, three different RoI sets in a row:
     each result equals the oracle and the first jdet_roi_align_backward_clean_bytes() bytes are zero again after every
@@ -162,7 +195,7 @@ def test_backward_cl_kept_workspace_contract(dev):
         tol = BWD_ATOL * max(1.0, np.abs(ref).max())
         for ws_call, flag in ((ws, 1), (torch.full((wsb,), 0xA5, dtype=torch.uint8, device=dev), 0)):
             gin.fill_(float("nan"))
-            L.check(lib.jdet_roi_align_backward_cl(O.V_ROT, L.ptr(g_cl), L.ptr(r), R, N, C, H, W, 7, 7, scale, 2,
+            L.check(lib.jdet_roi_align_backward_cl(O.V_ROT, L.ptr(g_cl), L.ptr(r), R, N, C, H, W, 7, 7, scale, 2, 1,
                                                    L.ptr(gin), L.ptr(ws_call), wsb, flag, L.stream_ptr(gin)), "bwd_cl")
             got = gin.permute(0, 3, 1, 2).cpu().numpy()
             np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
