@@ -173,6 +173,16 @@ int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order
                      float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,
                      void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
+/* jdet_nms_rotated with two more switches (same workspace, same keep contract).
+ * horizontal != 0: the caller promises every angle is 0; the overlap is the rectangle formula
+ *   inter / (a + b - inter) instead of polygon clipping (the horizontal proposal NMS of the two-stage RPNs --
+ *   `jt.nms`, nms.py:L4-9 -- and of level-offset tricks such as oriented_rpn_head.py:L214-219).
+ * n_labels > 1 (box_len 6): the labels are the integers 0 .. n_labels-1 and `order` visits the boxes label by label
+ *   (descending score inside a label): each label is scanned by its own workgroup.  n_labels == 1: any labels. */
+int jdet_nms_labeled(const float* dets, int n, int box_len, const int32_t* order, float iou_threshold, int cmp_ge,
+                     int sort_mode, int horizontal, int n_labels, uint8_t* keep, void* workspace,
+                     size_t workspace_bytes, jdet_stream_t stream);
+
 /* Deformable-conv v1 sampling.  Replace dcn_v1.py:L309-338 (im2col), L374-410 (col2im),
  * L340-372 (col2im_coord).  im (B,C,H,W) NCHW; offset (B, dg*2*kh*kw, Ho, Wo) ordered
  * (dy,dx) per tap; col (C*kh*kw, B, Ho, Wo). */

@@ -298,6 +298,10 @@ __device__ __forceinline__ void tile_label_range(const float* __restrict__ dets,
 // `mask` and `tile_jmax` arrive zeroed.  Tiles whose label ranges are disjoint (ml_nms with the boxes visited
 // class by class: almost all of them) return at once; tile_jmax[r] = last column block of row block r that can hold
 // a set bit, so that the scan reads only those.
+// HBB: the boxes are (xc, yc, w, h, 0 [, label]) -- axis-aligned; the overlap is the rectangle formula
+// inter / (a + b - inter) instead of the polygon clipping (same value up to rounding, ~30x fewer instructions: the
+// RPN proposal NMS of the two-stage detectors, 8.7 k boxes per image, spent 0.55-0.74 ms here).
+template <bool HBB>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ dets, int n, int box_len,
                                                       const int32_t* __restrict__ order, float thr,
                                                       int cmp_ge, int sort_mode,
@@ -341,7 +345,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       // ml_nms: different labels -> IoU 0 (nms_rotated.py:L283-286); argument order is
       // (earlier, later) as in the CPU loop L443
       float ovr = 0.f;
-      if (!(box_len == 6 && rb[5] != cb[5])) ovr = iou_dispatch<64>(rb, cb, 0, sort_mode, q);
+      if (!(box_len == 6 && rb[5] != cb[5])) {
+        if (HBB) {
+          const float iw = fminf(rb[0] + 0.5f * rb[2], cb[0] + 0.5f * cb[2]) - fmaxf(rb[0] - 0.5f * rb[2], cb[0] - 0.5f * cb[2]);
+          const float ih = fminf(rb[1] + 0.5f * rb[3], cb[1] + 0.5f * cb[3]) - fmaxf(rb[1] - 0.5f * rb[3], cb[1] - 0.5f * cb[3]);
+          const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+          const float uni = rb[2] * rb[3] + cb[2] * cb[3] - inter;
+          ovr = uni > 0.f ? inter / uni : 0.f;
+        } else {
+          ovr = iou_dispatch<64>(rb, cb, 0, sort_mode, q);
+        }
+      }
       hit = cmp_ge ? (ovr >= thr) : (ovr > thr);
     }
     const unsigned long long word = __ballot(hit);
@@ -352,33 +366,59 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 constexpr int kScanBlock = 1024;
 constexpr int kScanMaxWords = 8192;  // n <= 524288
 
-// Greedy scan, one workgroup.  Per 64-row block: wave 0 resolves the diagonal tile (readlane chain), then all 16
-// waves OR the rows of the kept boxes into the running `removed` words of the column blocks that can be affected
-// (<= tile_jmax): the (kept row, column) pairs are flattened over the 1024 threads, 8 independent loads in flight
-// per thread.
+// Greedy scan.  Boxes of different labels never interact and are visited label by label, so every label is its own
+// greedy problem: workgroup g scans the positions [seg_begin, seg_end) whose label is g (n_labels == 1: everything).
+// Per 64-row block: wave 0 resolves the diagonal tile (readlane chain), then all 16 waves OR the rows of the kept
+// boxes into the running `removed` words of the column blocks that can be affected (<= tile_jmax): the (kept row,
+// column) pairs are flattened over the 1024 threads, 8 independent loads in flight per thread.  Row blocks that
+// straddle two labels are visited by both workgroups, each touching only its own rows.
 __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                               int n, const int32_t* __restrict__ order,
                                                               const int* __restrict__ tile_jmax,
+                                                              const float* __restrict__ dets, int n_labels,
                                                               uint8_t* __restrict__ keep) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // col_blocks words
   __shared__ int s_rows[64];
   __shared__ int s_nkept;
+  __shared__ int s_seg[2];
   const int col_blocks = (n + 63) >> 6;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int j = threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
+  if (threadIdx.x == 0) {
+    s_seg[0] = n_labels > 1 ? n : 0;
+    s_seg[1] = n;
+  }
   __syncthreads();
-  for (int c = 0; c < col_blocks; c++) {
+  if (n_labels > 1) {
+    // positions are sorted by label: the segment of label g starts at the first position whose label is >= g and
+    // ends where the first label >= g + 1 sits; every boundary is found by exactly one thread
+    const float g = (float)blockIdx.x;
+    for (int pos = threadIdx.x; pos < n; pos += kScanBlock) {
+      const float l = dets[(size_t)order[pos] * 6 + 5];
+      const float lp = pos > 0 ? dets[(size_t)order[pos - 1] * 6 + 5] : -INFINITY;
+      if (lp < g && l >= g) s_seg[0] = pos;
+      if (lp < g + 1.f && l >= g + 1.f) s_seg[1] = pos;
+    }
+    __syncthreads();
+  }
+  const int seg_lo = s_seg[0], seg_hi = min(s_seg[1], n);
+  if (seg_lo >= seg_hi) return;
+  const int c_lo = seg_lo >> 6, c_hi = (seg_hi + 63) >> 6;
+  for (int j = c_lo + threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
+  __syncthreads();
+  for (int c = c_lo; c < c_hi; c++) {
     const int rows = min(64, n - c * 64);
     if (wave == 0) {
       // diagonal tile: lane = row; resolve the within-tile greedy dependency with readlanes
       const int row = c * 64 + lane;
+      const bool own = row >= seg_lo && row < seg_hi;
       unsigned long long d = 0ull;
-      if (lane < rows) d = mask[(size_t)row * col_blocks + c];
+      if (own) d = mask[(size_t)row * col_blocks + c];
       unsigned long long removed = s_remv[c];
       unsigned long long keepbits = 0ull;
+      const unsigned long long ownbits = __ballot(own);
       const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
       for (int i = 0; i < rows; i++) {
-        if (!((removed >> i) & 1ull)) {
+        if (((ownbits >> i) & 1ull) && !((removed >> i) & 1ull)) {
           keepbits |= 1ull << i;
           const unsigned long long di =
               ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
@@ -387,12 +427,13 @@ __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned lon
         }
       }
       const bool mine = (keepbits >> lane) & 1ull;
-      if (lane < rows) keep[order[row]] = (uint8_t)mine;
+      if (own) keep[order[row]] = (uint8_t)mine;
       if (mine) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;   // k-th kept row of the block
       if (lane == 0) s_nkept = __popcll(keepbits);
     }
     __syncthreads();
-    const int ncols = tile_jmax[c] - c;          // column blocks c+1 .. tile_jmax[c]
+    const int jmax = min(tile_jmax[c], c_hi - 1);   // later labels' columns hold no bit of these rows
+    const int ncols = max(jmax - c, 0);             // column blocks c+1 .. jmax
     const int items = s_nkept * ncols;
     for (int it0 = threadIdx.x; it0 < items; it0 += kScanBlock * 8) {
       unsigned long long w[8];
@@ -444,10 +485,15 @@ JDET_API size_t jdet_nms_rotated_workspace(int n) {
   return nms_mask_bytes(n) + ((col_blocks * sizeof(int) + 255) & ~(size_t)255);
 }
 
-JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
-                              float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,
+// horizontal != 0: every angle is 0 (the caller's promise): rectangle overlap instead of polygon clipping.
+// n_labels > 1 (box_len 6 only): the labels are the integers 0 .. n_labels-1 and `order` visits the boxes label by
+// label -- one scan workgroup per label instead of one for all.
+JDET_API int jdet_nms_labeled(const float* dets, int n, int box_len, const int32_t* order, float iou_threshold,
+                              int cmp_ge, int sort_mode, int horizontal, int n_labels, uint8_t* keep,
                               void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
-  if (n < 0 || (box_len != 5 && box_len != 6) || (sort_mode != 0 && sort_mode != 1)) return JDET_E_BADARG;
+  if (n < 0 || (box_len != 5 && box_len != 6) || (sort_mode != 0 && sort_mode != 1) || n_labels < 1 ||
+      n_labels > 65535 || (n_labels > 1 && box_len != 6))
+    return JDET_E_BADARG;
   if (n == 0) return JDET_OK;
   if (!dets || !order || !keep || !workspace) return JDET_E_BADARG;
   if (workspace_bytes < jdet_nms_rotated_workspace(n)) return JDET_E_WORKSPACE;
@@ -458,11 +504,23 @@ JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32
   int* tile_jmax = (int*)((char*)workspace + nms_mask_bytes(n));
   int e = jdet_zero_async(workspace, jdet_nms_rotated_workspace(n), st);
   if (e) return e;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
-                     order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask, tile_jmax);
+  if (horizontal)
+    hipLaunchKernelGGL(nms_mask_kernel<true>, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
+                       order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask, tile_jmax);
+  else
+    hipLaunchKernelGGL(nms_mask_kernel<false>, dim3(col_blocks, col_blocks), dim3(64), 0, st, dets, n, box_len,
+                       order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask, tile_jmax);
   e = jdet_launch_status();
   if (e) return e;
   const size_t lds = (size_t)col_blocks * sizeof(unsigned long long);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(kScanBlock), lds, st, mask, n, order, tile_jmax, keep);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(n_labels), dim3(kScanBlock), lds, st, mask, n, order, tile_jmax, dets,
+                     n_labels, keep);
   return jdet_launch_status();
+}
+
+JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,
+                              float iou_threshold, int cmp_ge, int sort_mode, uint8_t* keep,
+                              void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
+  return jdet_nms_labeled(dets, n, box_len, order, iou_threshold, cmp_ge, sort_mode, 0, 1, keep, workspace,
+                          workspace_bytes, stream);
 }

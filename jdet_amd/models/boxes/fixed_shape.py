@@ -113,7 +113,8 @@ def proposal_table(boxes, scores, level_ids, level_sizes, alive, nms_thresh, nms
     from jdet_amd.ops.nms import nms_keep_mask
     low = torch.full_like(scores, -2.0)
     # dropped boxes get the lowest scores: visited last, they suppress nothing that is kept, and are removed below
-    keep, _ = nms_keep_mask(boxes, torch.where(alive, scores, low), nms_thresh, labels=level_ids)
+    keep, _ = nms_keep_mask(boxes, torch.where(alive, scores, low), nms_thresh, labels=level_ids,
+                            n_labels=len(level_sizes))
     ok = keep & alive
     if nms_post_per_level is not None:
         ranks, start = [], 0

@@ -3,19 +3,20 @@
 `jt.nms` is a Jittor builtin with no source in the reference tree: **parity unpinned** (SURVEY 8c).
 Documented assumption: standard greedy NMS, suppress when IoU > thresh, no "+1" pixel convention,
 kept indices returned in descending-score order.  It runs on the same device path as rotated NMS
-(axis-aligned boxes are rotated boxes with theta = 0): tile bitmask kernel + on-device scan.
+(tile bitmask kernel + on-device scan) with the rectangle overlap formula in the tile kernel.
 """
 import torch
 
 from .. import _lib as L
 
 
-def nms_keep_mask(boxes, scores, thresh, labels=None):
+def nms_keep_mask(boxes, scores, thresh, labels=None, n_labels=None):
     """greedy horizontal NMS -> bool keep mask over the input order; device-only, fixed shapes (no host sync).
     `labels` (optional, e.g. FPN level ids): boxes with different labels never suppress each other -- the effect of
     the reference's "add level_id * (max_coordinate + 1) to the boxes" trick (oriented_rpn_head.py:L214-219), obtained
-    by skipping the cross-label 64x64 tiles instead of computing their zero IoUs.  Returns (keep, order) with
-    `order` = indices by descending score (stable)."""
+    by skipping the cross-label 64x64 tiles instead of computing their zero IoUs.  `n_labels`: the labels are the
+    integers 0 .. n_labels-1 (every label gets its own scan workgroup); None: any labels, one scan.  Returns
+    (keep, order) with `order` = indices by descending score (stable)."""
     assert boxes.shape[-1] == 4 and len(scores) == len(boxes)
     if scores.dim() == 2:
         scores = scores[:, 0]
@@ -34,8 +35,9 @@ def nms_keep_mask(boxes, scores, thresh, labels=None):
     keep = torch.empty((n,), dtype=torch.uint8, device=b.device)
     wsb = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=b.device)
-    L.check(L.lib().jdet_nms_rotated(L.ptr(obb), n, obb.shape[1], L.ptr(o32), float(thresh), 0, 0, L.ptr(keep), L.ptr(ws), wsb,
-                                     L.stream_ptr(b)), "jdet_nms_rotated (horizontal)")
+    L.check(L.lib().jdet_nms_labeled(L.ptr(obb), n, obb.shape[1], L.ptr(o32), float(thresh), 0, 0, 1,
+                                     int(n_labels) if (labels is not None and n_labels) else 1, L.ptr(keep),
+                                     L.ptr(ws), wsb, L.stream_ptr(b)), "jdet_nms_labeled (horizontal)")
     return keep.bool(), order
 
 

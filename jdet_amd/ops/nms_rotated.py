@@ -16,10 +16,12 @@ __all__ = ["nms_rotated", "ml_nms_rotated", "multiclass_nms_rotated", "nms_rotat
 REFERENCE_RULE = "cpu"
 
 
-def nms_rotated_keep_mask(dets, order, iou_threshold, rule=None):
+def nms_rotated_keep_mask(dets, order, iou_threshold, rule=None, n_labels=1):
     """dets (n,5|6) fp32, order (n,) visiting order (descending score; for 6-column dets any order that is
     descending in score inside each label) -> bool keep mask over original indices.  Device-only, fixed shapes.
-    `rule`: "cpu" (suppress at iou >= thr) | "cuda" (iou > thr); None = the module-level REFERENCE_RULE."""
+    `rule`: "cpu" (suppress at iou >= thr) | "cuda" (iou > thr); None = the module-level REFERENCE_RULE.
+    `n_labels` > 1: column 5 holds integer labels 0 .. n_labels-1 and `order` is sorted by label -- one scan
+    workgroup per label."""
     L.need_device(dets, order)
     d = L.f32c(dets)
     n, bl = d.shape
@@ -27,9 +29,10 @@ def nms_rotated_keep_mask(dets, order, iou_threshold, rule=None):
     keep = torch.empty((n,), dtype=torch.uint8, device=d.device)
     ws_bytes = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=d.device)
-    L.check(L.lib().jdet_nms_rotated(L.ptr(d), n, bl, L.ptr(o), float(iou_threshold),
-                                     1 if (rule or REFERENCE_RULE) == "cpu" else 0, L.REFERENCE_SORT,
-                                     L.ptr(keep), L.ptr(ws), ws_bytes, L.stream_ptr(d)), "jdet_nms_rotated")
+    L.check(L.lib().jdet_nms_labeled(L.ptr(d), n, bl, L.ptr(o), float(iou_threshold),
+                                     1 if (rule or REFERENCE_RULE) == "cpu" else 0, L.REFERENCE_SORT, 0,
+                                     int(n_labels) if bl == 6 else 1, L.ptr(keep), L.ptr(ws), ws_bytes,
+                                     L.stream_ptr(d)), "jdet_nms_labeled")
     return keep.bool()
 
 
@@ -39,7 +42,7 @@ def _order(scores):
     return torch.argsort(scores, dim=0, descending=True, stable=True)
 
 
-def ml_nms_rotated(dets, scores, labels, iou_threshold):
+def ml_nms_rotated(dets, scores, labels, iou_threshold, num_classes=None):
     assert dets.numel() > 0 and dets.dim() == 2
     assert dets.dtype == scores.dtype
     dets6 = torch.cat([dets, labels.to(dets.dtype).unsqueeze(1)], dim=1)
@@ -48,7 +51,8 @@ def ml_nms_rotated(dets, scores, labels, iou_threshold):
     # and makes the 64x64 tiles label-homogeneous: the kernel skips every tile whose label ranges are disjoint
     order = _order(scores)
     order = order[torch.argsort(labels[order], stable=True)]
-    keep = nms_rotated_keep_mask(dets6, order, iou_threshold)
+    # num_classes given (labels are 0 .. num_classes-1): every class is scanned by its own workgroup
+    keep = nms_rotated_keep_mask(dets6, order, iou_threshold, n_labels=num_classes or 1)
     return torch.nonzero(keep)[:, 0]
 
 
@@ -81,7 +85,7 @@ def multiclass_nms_rotated(multi_bboxes, multi_scores, score_thr, nms_cfg, max_n
     nms_cfg_ = dict(nms_cfg)
     nms_cfg_.pop("type", "nms")
     iou_thr = nms_cfg_.pop("iou_thr", 0.1)
-    keep = ml_nms_rotated(bboxes, scores, labels, iou_thr)
+    keep = ml_nms_rotated(bboxes, scores, labels, iou_thr, num_classes=num_classes)
     bboxes, scores, labels = bboxes[keep], scores[keep], labels[keep]
     inds = _order(scores)
     if keep.size(0) > max_num:

@@ -218,3 +218,42 @@ def test_merge_nms_groups_on_the_device(dev):
             ref[idx] = O.nms_rotated_keep(poly_to_rotated_box_np(polys[idx]), order, thr, cmp_ge=0).astype(bool)
         np.testing.assert_array_equal(got, ref)
         assert 0 < got.sum() < n
+
+
+@pytest.mark.parametrize("horizontal", [0, 1])
+def test_nms_one_scan_workgroup_per_label(dev, horizontal):
+    """jdet_nms_labeled with n_labels > 1 (a scan workgroup per label) keeps exactly what the single scan keeps:
+    label segments of sizes that are not multiples of 64 (row blocks shared by two labels), an absent label, a
+    one-box label, heavy overlap inside the labels; for horizontal boxes additionally equal to the polygon-clipping
+    kernel on the same boxes (rectangle formula vs clipping: same decisions on these boxes)."""
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(8)
+    sizes = [700, 0, 1, 333, 64, 129]                # label 1 absent
+    n, n_labels = sum(sizes), len(sizes)
+    boxes = I.clustered_obbs(rng, n, n_clusters=20, extent=300.0, jitter=5.0, wh=(20.0, 70.0))
+    if horizontal:
+        boxes[:, 4] = 0.0
+    labels = np.concatenate([np.full(s, i) for i, s in enumerate(sizes)]).astype(np.float32)
+    perm = rng.permutation(n)
+    labels = labels[perm]
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    dets = torch.from_numpy(np.concatenate([boxes, labels[:, None]], 1).astype(np.float32)).to(dev)
+    order = np.argsort(-scores, kind="stable")
+    order = order[np.argsort(labels[order], kind="stable")].astype(np.int32)
+    o = torch.from_numpy(order).to(dev)
+    wsb = lib.jdet_nms_rotated_workspace(n)
+
+    def run(hz, nl):
+        keep = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+        L.check(lib.jdet_nms_labeled(L.ptr(dets), n, 6, L.ptr(o), 0.3, 0, 0, hz, nl, L.ptr(keep), L.ptr(ws), wsb,
+                                     L.stream_ptr(dets)), "nms_labeled")
+        return keep.cpu().numpy()
+
+    single = run(horizontal, 1)
+    per_label = run(horizontal, n_labels)
+    assert set(np.unique(single)) <= {0, 1} and np.array_equal(single, per_label)
+    assert 0 < single.sum() < n
+    if horizontal:
+        assert np.array_equal(single, run(0, 1))
