@@ -307,6 +307,13 @@ int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int
  *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
  *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
  * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+/* Axis-aligned overlaps out (K, A) row-major of K gt boxes (K,4) against A boxes (A, box_stride >= 4; the first four
+ * columns are x1,y1,x2,y2): the tensor program of `bbox_overlaps` (models/boxes/iou_calculator.py:L235-350, modes
+ * "iou" (iof = 0) and "iof" (iof = 1), not aligned) in the same operation order, one launch.  plus_one: the legacy
+ * +1 pixel convention (BboxOverlaps2D_v1).  alive (A) or NULL: columns of boxes with alive == 0 are -1. */
+int jdet_bbox_overlaps_hbb(const float* gts, int K, const float* boxes, int A, int box_stride, int iof, int plus_one,
+                           float eps, const uint8_t* alive, float* out, jdet_stream_t stream);
+
 size_t jdet_assign_max_iou_workspace(int K);
 int jdet_assign_max_iou(const float* overlaps, int K, int A, float pos_iou_thr, float neg_iou_lo,
                         float neg_iou_hi, float min_pos_iou, int match_low_quality,

@@ -77,6 +77,9 @@ def masked_overlaps(iou_calculator, gts, boxes, alive):
     """IoU matrix (K, A) with the columns of dead candidates (padding rows, anchors outside the image) at -1: the
     assigner ignores them and they can neither be sampled nor decide a low-quality match -- the same set the
     reference reaches by removing those candidates first."""
+    from jdet_amd.models.boxes.iou_calculator import _HbbOverlaps
+    if isinstance(iou_calculator, _HbbOverlaps):
+        return iou_calculator(gts, boxes, alive=alive)        # mask fused into the overlap launch
     overlaps = iou_calculator(gts, boxes)
     return torch.where(alive[None, :], overlaps, torch.full_like(overlaps, -1.0))
 
@@ -112,9 +115,13 @@ def proposal_table(boxes, scores, level_ids, level_sizes, alive, nms_thresh, nms
     the NMS sees; `payload` (default: the boxes): what the table rows carry."""
     from jdet_amd.ops.nms import nms_keep_mask
     low = torch.full_like(scores, -2.0)
-    # dropped boxes get the lowest scores: visited last, they suppress nothing that is kept, and are removed below
-    keep, _ = nms_keep_mask(boxes, torch.where(alive, scores, low), nms_thresh, labels=level_ids,
-                            n_labels=len(level_sizes))
+    # The candidates arrive level by level, descending score inside a level: that IS the visiting order (no device
+    # sort).  Dropped boxes (too small) are shrunk to a point far outside the image: they overlap nothing, so they
+    # suppress nothing that is kept (the reference removes them before the NMS), and are removed below.
+    nowhere = boxes.new_full((4,), -1.0e4)
+    keep, _ = nms_keep_mask(torch.where(alive[:, None], boxes, nowhere[None, :]), scores, nms_thresh,
+                            labels=level_ids, n_labels=len(level_sizes),
+                            visit_order=torch.arange(scores.shape[0], device=scores.device))
     ok = keep & alive
     if nms_post_per_level is not None:
         ranks, start = [], 0

@@ -81,17 +81,48 @@ def bbox_overlaps(bboxes1, bboxes2, mode="iou", is_aligned=False, eps=1e-6, vers
     return ious - (enclose_area - union) / enclose_area
 
 
+def bbox_overlaps_fused(bboxes1, bboxes2, mode="iou", version=0, eps=1e-6, alive=None):
+    """`bbox_overlaps` (not aligned, iou / iof) of (K,4) x (A,4+) device boxes as ONE launch (jdet_bbox_overlaps_hbb:
+    the same operation order, bit-identical to the ~12-pass tensor program).  `alive` (A,) bool: columns of dead
+    boxes come back as -1 (what the fixed-shape heads would otherwise write with a torch.where pass)."""
+    import torch
+    from jdet_amd import _lib as L
+    b1, b2 = L.f32c(bboxes1), L.f32c(bboxes2)
+    K, A = b1.shape[0], b2.shape[0]
+    out = torch.empty((K, A), dtype=torch.float32, device=b1.device)
+    al = alive.to(torch.uint8).contiguous() if alive is not None else None
+    L.check(L.lib().jdet_bbox_overlaps_hbb(L.ptr(b1), K, L.ptr(b2), A, b2.shape[1], 1 if mode == "iof" else 0,
+                                           int(version), float(eps), L.ptr(al), L.ptr(out), L.stream_ptr(b1)),
+            "jdet_bbox_overlaps_hbb")
+    return out
+
+
+def _fusable(b1, b2, mode, is_aligned):
+    import torch
+    return (not is_aligned and mode in ("iou", "iof") and b1.dim() == 2 and b2.dim() == 2 and b1.is_cuda
+            and b1.dtype == torch.float32 and b2.dtype == torch.float32 and b1.shape[0] > 0 and b2.shape[0] > 0
+            and b1.shape[1] == 4 and not (torch.is_grad_enabled() and (b1.requires_grad or b2.requires_grad)))
+
+
 class _HbbOverlaps:
     version = 0
 
-    def __call__(self, bboxes1, bboxes2, mode="iou", is_aligned=False, version=None):
+    def __call__(self, bboxes1, bboxes2, mode="iou", is_aligned=False, version=None, alive=None):
+        """`alive` (columns mask, fixed-shape heads only): dead columns are -1"""
         assert bboxes1.size(-1) in [0, 4, 5]
         assert bboxes2.size(-1) in [0, 4, 5]
-        if bboxes2.size(-1) == 5:
-            bboxes2 = bboxes2[..., :4]
+        version = self.version if version is None else version
         if bboxes1.size(-1) == 5:
             bboxes1 = bboxes1[..., :4]
-        return bbox_overlaps(bboxes1, bboxes2, mode, is_aligned, version=self.version if version is None else version)
+        if _fusable(bboxes1, bboxes2, mode, is_aligned):
+            return bbox_overlaps_fused(bboxes1, bboxes2, mode, version, alive=alive)
+        if bboxes2.size(-1) == 5:
+            bboxes2 = bboxes2[..., :4]
+        ious = bbox_overlaps(bboxes1, bboxes2, mode, is_aligned, version=version)
+        if alive is not None:
+            import torch
+            ious = torch.where(alive[None, :], ious, torch.full_like(ious, -1.0))
+        return ious
 
     def __repr__(self):
         return self.__class__.__name__ + "()"

@@ -116,9 +116,9 @@ class OrientedRPNHead(nn.Module):
         scores, deltas, anchors, ids = [], [], [], []
         for lvl, (s, d, a) in enumerate(zip(level_scores, level_deltas, level_anchors)):
             s = s.sigmoid()
-            if 0 < self.nms_pre < s.shape[0]:
-                s, top = torch.topk(s, self.nms_pre)          # descending; equal scores: lowest index first
-                d, a = d[top], a[top]
+            k = s.shape[0] if self.nms_pre <= 0 else min(self.nms_pre, s.shape[0])
+            s, top = torch.topk(s, k)         # always: proposal_table wants every level sorted by descending score
+            d, a = d[top], a[top]
             scores.append(s)
             deltas.append(d)
             anchors.append(a)

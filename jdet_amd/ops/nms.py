@@ -10,13 +10,15 @@ import torch
 from .. import _lib as L
 
 
-def nms_keep_mask(boxes, scores, thresh, labels=None, n_labels=None):
+def nms_keep_mask(boxes, scores, thresh, labels=None, n_labels=None, visit_order=None):
     """greedy horizontal NMS -> bool keep mask over the input order; device-only, fixed shapes (no host sync).
     `labels` (optional, e.g. FPN level ids): boxes with different labels never suppress each other -- the effect of
     the reference's "add level_id * (max_coordinate + 1) to the boxes" trick (oriented_rpn_head.py:L214-219), obtained
     by skipping the cross-label 64x64 tiles instead of computing their zero IoUs.  `n_labels`: the labels are the
-    integers 0 .. n_labels-1 (every label gets its own scan workgroup); None: any labels, one scan.  Returns
-    (keep, order) with `order` = indices by descending score (stable)."""
+    integers 0 .. n_labels-1 (every label gets its own scan workgroup); None: any labels, one scan.
+    `visit_order`: the caller's visiting order (label by label, descending score inside a label) when the boxes
+    already come that way -- saves the two device sorts; `order` is then returned as given.  Returns (keep, order)
+    with `order` = indices by descending score (stable)."""
     assert boxes.shape[-1] == 4 and len(scores) == len(boxes)
     if scores.dim() == 2:
         scores = scores[:, 0]
@@ -25,11 +27,15 @@ def nms_keep_mask(boxes, scores, thresh, labels=None, n_labels=None):
     b = boxes.float()
     cols = [(b[:, 0] + b[:, 2]) * 0.5, (b[:, 1] + b[:, 3]) * 0.5, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
             torch.zeros_like(b[:, 0])]
-    order = torch.argsort(scores.float(), descending=True, stable=True)
-    visit = order
     if labels is not None:
         cols.append(labels.to(b.dtype))
-        visit = order[torch.argsort(labels[order], stable=True)]   # class by class, descending score inside
+    if visit_order is not None:
+        order = visit = visit_order
+    else:
+        order = torch.argsort(scores.float(), descending=True, stable=True)
+        visit = order
+        if labels is not None:
+            visit = order[torch.argsort(labels[order], stable=True)]   # class by class, descending score inside
     obb = torch.stack(cols, dim=1).contiguous()
     o32 = visit.to(torch.int32).contiguous()
     keep = torch.empty((n,), dtype=torch.uint8, device=b.device)

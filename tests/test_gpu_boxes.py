@@ -303,3 +303,30 @@ def test_fused_oriented_codecs_vs_oracle(dev):
     np.testing.assert_allclose(back[:, :4], g[:, :4], rtol=2e-4, atol=2e-2)
     assert np.abs(np.sin(back[:, 4] - g[:, 4])).max() < 2e-4
     assert mc.decode(t(anchors[:0]), t(d6[:0])).shape == (0, 5)
+
+
+@pytest.mark.parametrize("version", [0, 1])
+@pytest.mark.parametrize("mode", ["iou", "iof"])
+def test_fused_hbb_overlaps_equal_the_tensor_program(dev, version, mode):
+    """jdet_bbox_overlaps_hbb = `bbox_overlaps` (iou_calculator.py:L235-350) bit for bit: same operation order, incl.
+    the +1 convention, the eps clamp (degenerate / identical boxes), 5-column candidates (score column ignored) and
+    the dead-column mask of the fixed-shape heads; the assigner on top (row maxima in chunks) is unchanged."""
+    from jdet_amd.models.boxes.iou_calculator import bbox_overlaps, bbox_overlaps_fused
+    g = torch.Generator().manual_seed(3 + version)
+    K, A = 37, 5003
+    c = torch.rand((K, 2), generator=g) * 500
+    wh = torch.rand((K, 2), generator=g) * 120
+    gts = torch.cat([c - wh / 2, c + wh / 2], 1)
+    gts[3, 2:] = gts[3, :2]                       # zero-area gt
+    c2 = torch.rand((A, 2), generator=g) * 500
+    wh2 = torch.rand((A, 2), generator=g) * 150
+    boxes = torch.cat([c2 - wh2 / 2, c2 + wh2 / 2, torch.rand((A, 1), generator=g)], 1)
+    boxes[:K, :4] = gts                           # exact duplicates
+    boxes[100, 2:4] = boxes[100, :2]              # zero-area box
+    gts, boxes = gts.to(dev), boxes.to(dev)
+    ref = bbox_overlaps(gts, boxes[:, :4], mode, version=version)
+    got = bbox_overlaps_fused(gts, boxes, mode, version)
+    assert torch.equal(got, ref)
+    alive = (torch.rand((A,), generator=g) > 0.3).to(dev)
+    got = bbox_overlaps_fused(gts, boxes, mode, version, alive=alive)
+    assert torch.equal(got, torch.where(alive[None, :], ref, torch.full_like(ref, -1.0)))
