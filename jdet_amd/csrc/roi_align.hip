@@ -909,9 +909,13 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
     if (!vec) return JDET_E_UNSUPPORTED;
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     // (the merged kernel keeps its per-wave tap lists in the first 2 KiB / wave of the dynamic LDS block)
-    if (sample_num == 2 && !g_fwd_reference_order && nbins <= 64)
-      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 0, true>), grid, dim3(256), 8 * 2048, st, feat, rois, out,
+    if (sample_num == 2 && !g_fwd_reference_order && nbins <= 64) {
+      // JDET_ROI_FWD_LDS_KB (profiling only): pads the LDS request to cap the workgroups per CU
+      static const int lds_kb = env_int("JDET_ROI_FWD_LDS_KB", 0);
+      const size_t lds_cl = lds_kb > 16 ? (size_t)lds_kb * 1024 : 8 * 2048;
+      hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 0, true>), grid, dim3(256), lds_cl, st, feat, rois, out,
                          C, H, W, PH, PW, scale, order, 0);
+    }
     else
       hipLaunchKernelGGL((roi_align_fwd_vec_kernel<V, 4, 4, 0, true>), grid, dim3(256), 16, st, feat, rois, out, C, H,
                          W, PH, PW, scale, sample_num, order);

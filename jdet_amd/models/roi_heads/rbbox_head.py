@@ -16,6 +16,8 @@ from jdet_amd.ops.bbox_transforms import (best_match_dbbox2delta, choose_best_ob
 from jdet_amd.ops.nms_rotated import multiclass_nms_rotated
 from jdet_amd.utils.registry import HEADS, LOSSES, build_from_cfg
 
+from .roi_feature_linear import RoIFeatureLinear
+
 
 def _get(cfg, key):
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
@@ -91,22 +93,28 @@ class BBoxHeadRbbox(nn.Module):
         self.reg_class_agnostic = reg_class_agnostic
         self.loss_cls = build_from_cfg(loss_cls, LOSSES)
         self.loss_bbox = build_from_cfg(loss_bbox, LOSSES)
-        in_channels = self.in_channels
         if self.with_avg_pool:
             self.avg_pool = nn.AvgPool2d(roi_feat_size)
-        else:
-            if isinstance(self.roi_feat_size, int):
-                in_channels *= self.roi_feat_size * self.roi_feat_size
-            else:
-                assert len(self.roi_feat_size) == 2
-                in_channels *= self.roi_feat_size[0] * self.roi_feat_size[1]
         if self.with_cls:
-            self.fc_cls = nn.Linear(in_channels, num_classes)
+            self.fc_cls = self._roi_linear(self.in_channels, num_classes)
         if self.with_reg:
-            self.fc_reg = nn.Linear(in_channels, 5 if reg_class_agnostic else 5 * num_classes)
+            self.fc_reg = self._roi_linear(self.in_channels, 5 if reg_class_agnostic else 5 * num_classes)
         self.debug_imgs = None
         self.with_module = with_module
         self.hbb_trans = hbb_trans
+
+    @property
+    def roi_feat_area(self):
+        size = self.roi_feat_size
+        return size * size if isinstance(size, int) else size[0] * size[1]
+
+    def _roi_linear(self, channels, out_features):
+        """a layer on the pooled (R, C, PH, PW) features: after average pooling a plain Linear on C values, otherwise
+        an FC over all C*PH*PW values that reads the channels-last memory in place (RoIFeatureLinear; state dicts
+        keep the reference's (c, ph, pw) column order)"""
+        if self.with_avg_pool:
+            return nn.Linear(channels, out_features)
+        return RoIFeatureLinear(channels, self.roi_feat_area, out_features)
 
     def init_weights(self):
         if self.with_cls:
@@ -118,8 +126,7 @@ class BBoxHeadRbbox(nn.Module):
 
     def forward(self, x):
         if self.with_avg_pool:
-            x = self.avg_pool(x)
-        x = x.reshape(x.shape[0], -1)
+            x = self.avg_pool(x).reshape(x.shape[0], -1)
         return (self.fc_cls(x) if self.with_cls else None), (self.fc_reg(x) if self.with_reg else None)
 
     execute = forward

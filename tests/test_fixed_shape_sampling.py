@@ -92,7 +92,7 @@ def test_scatter_rows_ignores_invalid_rows():
 def test_roi_feature_linear_keeps_reference_checkpoint_order():
     """the first FC layer of the RoI heads stores its weight for channels-last features; state dicts carry the
     reference's (c, ph, pw) column order in both directions"""
-    from jdet_amd.models.roi_heads.oriented_head import RoIFeatureLinear
+    from jdet_amd.models.roi_heads.roi_feature_linear import RoIFeatureLinear
     torch.manual_seed(0)
     C, O, R = 6, 5, 3
     ref = torch.nn.Linear(C * 4, O)
@@ -105,3 +105,29 @@ def test_roi_feature_linear_keeps_reference_checkpoint_order():
     sd = m.state_dict()
     assert torch.equal(sd["weight"], ref.weight) and torch.equal(sd["bias"], ref.bias)
     assert not torch.equal(m.weight, ref.weight)       # ... while the parameter itself is stored permuted
+
+
+def test_roi_transformer_head_keeps_the_reference_weight_order():
+    """SharedFCBBoxHeadRbbox consumes (R, C, 7, 7) features through RoIFeatureLinear: a state dict in the reference's
+    column order ((c, ph, pw), `x.reshape(R, -1)` of an NCHW tensor, convfc_rbbox_head.py:L136-144) gives the
+    reference's outputs for contiguous and channels-last inputs alike, and comes back unchanged from state_dict()"""
+    import torch.nn.functional as F
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.models.roi_heads import SharedFCBBoxHeadRbbox
+    torch.manual_seed(0)
+    C, R = 8, 6
+    head = SharedFCBBoxHeadRbbox(num_fcs=2, in_channels=C, fc_out_channels=32, roi_feat_size=7, num_classes=5,
+                                 reg_class_agnostic=True, with_module=False,
+                                 loss_cls=dict(type="CrossEntropyLossForRcnn", use_sigmoid=False, loss_weight=1.0))
+    ref = {k: torch.randn_like(v) for k, v in head.state_dict().items()}
+    head.load_state_dict(ref)
+    for k, v in head.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+    x = torch.randn(R, C, 7, 7)
+    h = F.relu(F.linear(x.reshape(R, -1), ref["shared_fcs.0.weight"], ref["shared_fcs.0.bias"]))
+    h = F.relu(F.linear(h, ref["shared_fcs.1.weight"], ref["shared_fcs.1.bias"]))
+    cls_ref = F.linear(h, ref["fc_cls.weight"], ref["fc_cls.bias"])
+    reg_ref = F.linear(h, ref["fc_reg.weight"], ref["fc_reg.bias"])
+    for inp in (x, x.contiguous(memory_format=torch.channels_last)):
+        cls, reg = head(inp)
+        assert torch.allclose(cls, cls_ref, atol=1e-5) and torch.allclose(reg, reg_ref, atol=1e-5)
