@@ -109,6 +109,16 @@ int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, in
  * (s_memtime stamps at the phase boundaries, hardware id in slot 31), or NULL to switch it off. */
 int jdet_debug_roi_tile_timeline(void* buf);
 
+/* Calibration probe (scripts/gather_probe.py; csrc/gather_probe.hip): n_blocks workgroups of 4 waves, every
+ * wave loads rows_per_wave pseudo-random 1 KiB rows of buf (total_rows x 256 floats), `unroll` (4 / 8 / 16) in flight,
+ * drawn from a window of window_rows rows -- one shared window, or one per workgroup (local_windows != 0). */
+int jdet_debug_gather_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave, int local_windows,
+                            int n_blocks, int unroll, float* sink, jdet_stream_t stream);
+/* ... the same gather with every row added `pairs` times into a 49 x 256 LDS accumulator block (ds_add_f32) that is
+ * streamed to out (n_blocks x 49 x 256 floats) at the end: the main loop of a pixel-stationary RoIAlign, emulated. */
+int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
+                                       int pairs, int n_blocks, float* out, jdet_stream_t stream);
+
 /* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
  *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);
  *                equals the reference up to fp32 re-association of the bilinear weights.
