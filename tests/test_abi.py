@@ -150,3 +150,30 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_deform_im2col_nhwc(N, N, 1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1, N, N) == -2        # C % 4
     assert lib.jdet_deform_col2im_nhwc_workspace(1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1) == 0
     assert lib.jdet_set_roi_forward_mode(7) in (0, 1)                                               # ignored value
+    # round-2 entry points
+    assert lib.jdet_roi_align_forward_cl_roi(2, N, 1, 16, 8, 8, N, 0, 7, 7, 1.0, 2, 3, N, N, N) == -1  # RiRoI: C % nO
+    assert lib.jdet_roi_align_forward_cl_roi(2, N, 1, 12, 8, 8, N, 0, 7, 7, 1.0, 2, 2, N, N, N) == -2  # RiRoI nO = 2
+    assert lib.jdet_roi_align_forward_cl_roi(0, N, 1, 6, 8, 8, N, 0, 7, 7, 1.0, 2, 1, N, N, N) == -2   # C % 4
+    assert lib.jdet_roi_align_forward_cl_roi(0, N, 1, 8, 8, 8, N, 0, 7, 7, 1.0, 2, 1, N, N, N) == 0    # R = 0
+    assert lib.jdet_roi_align_forward_cl_roi(0, N, 1, 8, 8, 8, N, 2, 7, 7, 1.0, 2, 1, N, N, N) == -1   # null pointers
+    assert lib.jdet_roi_align_backward_workspace(0, 10, 1, 8, 8, 8, 7, 7, 0) == 0                      # adaptive sampling
+    assert lib.jdet_roi_align_backward_workspace(0, 10, 1, 6, 8, 8, 7, 7, 2) == 0                      # C % 4
+    need = lib.jdet_roi_align_backward_workspace(0, 10, 1, 8, 8, 8, 7, 7, 2)
+    clean = lib.jdet_roi_align_backward_clean_bytes(0, 10, 1, 8, 8, 8, 7, 7, 2)
+    assert 0 < clean < need and clean == 4 * (16 + 1)                                                  # 4x4 patches + ticket
+    assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 0, 1, N, N, 0, 0, N) == -2   # adaptive
+    assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -3   # workspace
+    assert lib.jdet_roi_align_backward_cl(7, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -1   # variant
+    assert lib.jdet_roi_align_forward_cl_supported(2, 64, 64, 64, 7, 7, 2) == 0                        # tile path: no RiRoI
+    assert lib.jdet_nms_labeled(N, 10, 5, N, 0.1, 1, 0, 0, 4, N, N, 0, N) == -1                        # labels need 6 columns
+    assert lib.jdet_nms_labeled(N, 10, 6, N, 0.1, 1, 0, 1, 0, N, N, 0, N) == -1                        # n_labels < 1
+    assert lib.jdet_nms_labeled(N, 0, 6, N, 0.1, 1, 0, 1, 5, N, N, 0, N) == 0
+    assert lib.jdet_bbox_overlaps_hbb(N, 3, N, 5, 3, 0, 0, 1e-6, N, N, N) == -1                        # stride < 4
+    assert lib.jdet_bbox_overlaps_hbb(N, 0, N, 5, 4, 0, 0, 1e-6, N, N, N) == 0
+    assert lib.jdet_bbox_overlaps_hbb(N, 3, N, 5, 4, 0, 0, 1e-6, N, N, N) == -1                        # null pointers
+    six = built_lib.vecn([0.0] * 6, 6)
+    assert lib.jdet_midpoint_offset_decode(N, N, 0, N, N, 0.016, N, N) == -1                           # means / stds are host arrays
+    assert lib.jdet_midpoint_offset_decode(N, N, 0, six, six, 0.016, N, N) == 0
+    assert lib.jdet_midpoint_offset_decode(N, N, 4, six, six, 0.016, N, N) == -1
+    assert lib.jdet_oriented_delta_decode(N, N, 4, 0, six, six, 0.016, N, N) == -1                     # ncls < 1
+    assert lib.jdet_debug_gather_probe(N, 0, 1, 1, 0, 1, 16, N, N) == -1
