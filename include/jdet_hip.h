@@ -317,6 +317,18 @@ int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int
  *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
  *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
  * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+/* Polygon (4-point) IoU matrix ious (n1, n2) and polygon NMS.  Replaces nms_poly.py: `devPolyIoU` L113-133 /
+ * `poly_nms` L187-232 / `multiclass_poly_nms` L234-245 and the per-pair CPU `iou_poly` L247-252 of the DOTA
+ * evaluation and tile merging.  polys rows: x1 y1 .. x4 y4 (stride >= 8 floats), any orientation, convex or not.
+ * mode 0: the kernel's degenerate rule (union == 0 -> 1), mode 1: iou_poly's (inter / max(union, 0.01)).
+ * jdet_nms_poly: rows of row_len 8, or 9 with a label in column 8 (different labels never suppress each other;
+ * n_labels > 1: labels are 0 .. n_labels-1 and `order` visits them label by label -- one scan workgroup each);
+ * suppression at IoU > thr; keep (n) uint8 over original indices; workspace = jdet_nms_rotated_workspace(n). */
+int jdet_poly_iou(const float* polys1, int n1, int stride1, const float* polys2, int n2, int stride2, int mode,
+                  float* ious, jdet_stream_t stream);
+int jdet_nms_poly(const float* polys, int n, int row_len, const int32_t* order, float iou_threshold, int n_labels,
+                  uint8_t* keep, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
 /* Axis-aligned overlaps out (K, A) row-major of K gt boxes (K,4) against A boxes (A, box_stride >= 4; the first four
  * columns are x1,y1,x2,y2): the tensor program of `bbox_overlaps` (models/boxes/iou_calculator.py:L235-350, modes
  * "iou" (iof = 0) and "iof" (iof = 1), not aligned) in the same operation order, one launch.  plus_one: the legacy

@@ -37,6 +37,8 @@ SIGNATURES = {
     "jdet_box_iou_rotated": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "jdet_nms_rotated_workspace": (_sz, [_i]),
     "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),
+    "jdet_poly_iou": (_i, [_p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "jdet_nms_poly": (_i, [_p, _i, _i, _p, _f, _i, _p, _p, _sz, _p]),
     "jdet_bbox_overlaps_hbb": (_i, [_p, _i, _p, _i, _i, _i, _i, _f, _p, _p, _p]),
     "jdet_nms_labeled": (_i, [_p, _i, _i, _p, _f, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "jdet_deform_im2col": (_i, [_p, _p] + [_i] * 13 + [_p, _p]),

@@ -25,6 +25,7 @@
 //     workgroup: diagonal tile resolved by v_readlane chain, remaining words OR-ed in parallel
 //     into LDS) -- no cudaDeviceSynchronize + host loop as in the reference.
 #include "common.h"
+#include "nms_scan.h"
 
 namespace {
 
@@ -363,100 +364,6 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   }
 }
 
-constexpr int kScanBlock = 1024;
-constexpr int kScanMaxWords = 8192;  // n <= 524288
-
-// Greedy scan.  Boxes of different labels never interact and are visited label by label, so every label is its own
-// greedy problem: workgroup g scans the positions [seg_begin, seg_end) whose label is g (n_labels == 1: everything).
-// Per 64-row block: wave 0 resolves the diagonal tile (readlane chain), then all 16 waves OR the rows of the kept
-// boxes into the running `removed` words of the column blocks that can be affected (<= tile_jmax): the (kept row,
-// column) pairs are flattened over the 1024 threads, 8 independent loads in flight per thread.  Row blocks that
-// straddle two labels are visited by both workgroups, each touching only its own rows.
-__global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                              int n, const int32_t* __restrict__ order,
-                                                              const int* __restrict__ tile_jmax,
-                                                              const float* __restrict__ dets, int n_labels,
-                                                              uint8_t* __restrict__ keep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_remv[];  // col_blocks words
-  __shared__ int s_rows[64];
-  __shared__ int s_nkept;
-  __shared__ int s_seg[2];
-  const int col_blocks = (n + 63) >> 6;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (threadIdx.x == 0) {
-    s_seg[0] = n_labels > 1 ? n : 0;
-    s_seg[1] = n;
-  }
-  __syncthreads();
-  if (n_labels > 1) {
-    // positions are sorted by label: the segment of label g starts at the first position whose label is >= g and
-    // ends where the first label >= g + 1 sits; every boundary is found by exactly one thread
-    const float g = (float)blockIdx.x;
-    for (int pos = threadIdx.x; pos < n; pos += kScanBlock) {
-      const float l = dets[(size_t)order[pos] * 6 + 5];
-      const float lp = pos > 0 ? dets[(size_t)order[pos - 1] * 6 + 5] : -INFINITY;
-      if (lp < g && l >= g) s_seg[0] = pos;
-      if (lp < g + 1.f && l >= g + 1.f) s_seg[1] = pos;
-    }
-    __syncthreads();
-  }
-  const int seg_lo = s_seg[0], seg_hi = min(s_seg[1], n);
-  if (seg_lo >= seg_hi) return;
-  const int c_lo = seg_lo >> 6, c_hi = (seg_hi + 63) >> 6;
-  for (int j = c_lo + threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
-  __syncthreads();
-  for (int c = c_lo; c < c_hi; c++) {
-    const int rows = min(64, n - c * 64);
-    if (wave == 0) {
-      // diagonal tile: lane = row; resolve the within-tile greedy dependency with readlanes
-      const int row = c * 64 + lane;
-      const bool own = row >= seg_lo && row < seg_hi;
-      unsigned long long d = 0ull;
-      if (own) d = mask[(size_t)row * col_blocks + c];
-      unsigned long long removed = s_remv[c];
-      unsigned long long keepbits = 0ull;
-      const unsigned long long ownbits = __ballot(own);
-      const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
-      for (int i = 0; i < rows; i++) {
-        if (((ownbits >> i) & 1ull) && !((removed >> i) & 1ull)) {
-          keepbits |= 1ull << i;
-          const unsigned long long di =
-              ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
-              (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dlo, i);
-          removed |= di;
-        }
-      }
-      const bool mine = (keepbits >> lane) & 1ull;
-      if (own) keep[order[row]] = (uint8_t)mine;
-      if (mine) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;   // k-th kept row of the block
-      if (lane == 0) s_nkept = __popcll(keepbits);
-    }
-    __syncthreads();
-    const int jmax = min(tile_jmax[c], c_hi - 1);   // later labels' columns hold no bit of these rows
-    const int ncols = max(jmax - c, 0);             // column blocks c+1 .. jmax
-    const int items = s_nkept * ncols;
-    for (int it0 = threadIdx.x; it0 < items; it0 += kScanBlock * 8) {
-      unsigned long long w[8];
-      int jj[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int it = it0 + u * kScanBlock;
-        w[u] = 0ull;
-        jj[u] = 0;
-        if (it < items) {
-          const int ri = it / ncols;
-          jj[u] = c + 1 + (it - ri * ncols);
-          w[u] = mask[(size_t)(c * 64 + s_rows[ri]) * col_blocks + jj[u]];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (w[u]) atomicOr(&s_remv[jj[u]], w[u]);
-    }
-    __syncthreads();
-  }
-}
-
 }  // namespace
 
 JDET_API int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxes2, int n2, int stride,
@@ -474,16 +381,7 @@ JDET_API int jdet_box_iou_rotated(const float* boxes1, int n1, const float* boxe
   return jdet_launch_status();
 }
 
-static size_t nms_mask_bytes(int n) {
-  const size_t col_blocks = ((size_t)n + 63) >> 6;
-  return (((size_t)n * col_blocks * sizeof(unsigned long long)) + 255) & ~(size_t)255;
-}
-
-JDET_API size_t jdet_nms_rotated_workspace(int n) {
-  if (n <= 0) return 0;
-  const size_t col_blocks = ((size_t)n + 63) >> 6;
-  return nms_mask_bytes(n) + ((col_blocks * sizeof(int) + 255) & ~(size_t)255);
-}
+JDET_API size_t jdet_nms_rotated_workspace(int n) { return jdet_nms::workspace_bytes(n); }
 
 // horizontal != 0: every angle is 0 (the caller's promise): rectangle overlap instead of polygon clipping.
 // n_labels > 1 (box_len 6 only): the labels are the integers 0 .. n_labels-1 and `order` visits the boxes label by
@@ -498,10 +396,10 @@ JDET_API int jdet_nms_labeled(const float* dets, int n, int box_len, const int32
   if (!dets || !order || !keep || !workspace) return JDET_E_BADARG;
   if (workspace_bytes < jdet_nms_rotated_workspace(n)) return JDET_E_WORKSPACE;
   const int col_blocks = (n + 63) >> 6;
-  if (col_blocks > kScanMaxWords) return JDET_E_UNSUPPORTED;
+  if (col_blocks > jdet_nms::kScanMaxWords) return JDET_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* mask = (unsigned long long*)workspace;
-  int* tile_jmax = (int*)((char*)workspace + nms_mask_bytes(n));
+  int* tile_jmax = (int*)((char*)workspace + jdet_nms::mask_bytes(n));
   int e = jdet_zero_async(workspace, jdet_nms_rotated_workspace(n), st);
   if (e) return e;
   if (horizontal)
@@ -512,10 +410,7 @@ JDET_API int jdet_nms_labeled(const float* dets, int n, int box_len, const int32
                        order, iou_threshold, cmp_ge ? 1 : 0, sort_mode, mask, tile_jmax);
   e = jdet_launch_status();
   if (e) return e;
-  const size_t lds = (size_t)col_blocks * sizeof(unsigned long long);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(n_labels), dim3(kScanBlock), lds, st, mask, n, order, tile_jmax, dets,
-                     n_labels, keep);
-  return jdet_launch_status();
+  return jdet_nms::launch_scan(mask, n, order, tile_jmax, dets + 5, 6, n_labels, keep, st);
 }
 
 JDET_API int jdet_nms_rotated(const float* dets, int n, int box_len, const int32_t* order,

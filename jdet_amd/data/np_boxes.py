@@ -55,6 +55,19 @@ def poly_to_rotated_box_np(polys):
                     1).astype(np.float32)
 
 
+def polys_are_rectangles(polys, rel_tol=1e-3):
+    """(n,8): every polygon is a rectangle given corner by corner (diagonals bisect each other and have equal
+    length) up to `rel_tol` of its size -- the test that routes evaluation / merging to the rotated-box kernels"""
+    p = np.asarray(polys, dtype=np.float64).reshape(-1, 4, 2)
+    if p.shape[0] == 0:
+        return True
+    mid = np.abs((p[:, 0] + p[:, 2]) - (p[:, 1] + p[:, 3])).max(-1) / 2
+    d1 = np.sqrt(((p[:, 0] - p[:, 2]) ** 2).sum(-1))
+    d2 = np.sqrt(((p[:, 1] - p[:, 3]) ** 2).sum(-1))
+    size = np.maximum(np.maximum(d1, d2), 1e-9)
+    return bool(np.all(mid <= rel_tol * size) and np.all(np.abs(d1 - d2) <= rel_tol * size))
+
+
 def rotated_box_to_bbox_np(rboxes):
     """-> (enclosing (n,4) boxes, (n,8) polys)"""
     rboxes = np.asarray(rboxes)

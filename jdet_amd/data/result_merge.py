@@ -17,7 +17,7 @@ import re
 
 import numpy as np
 
-from .np_boxes import poly_to_rotated_box_np
+from .np_boxes import poly_to_rotated_box_np, polys_are_rectangles
 
 NMS_THRESHOLD = 0.1
 NMS_THRESHOLD_BY_CLASS = {"roundabout": 0.1, "tennis-court": 0.3, "swimming-pool": 0.1, "storage-tank": 0.2,
@@ -65,7 +65,12 @@ def device_group_nms(polys, scores, groups, thresh, device=None, max_boxes=MAX_B
     import torch
     from jdet_amd.ops.nms_rotated import nms_rotated_keep_mask
     dev = torch.device("cuda") if device is None else torch.device(device)
-    rb = np.concatenate([poly_to_rotated_box_np(polys), np.asarray(groups, np.float32)[:, None]], 1)
+    rect = polys_are_rectangles(polys)     # general quadrilaterals (foreign result files): polygon kernel
+    if rect:
+        rb = np.concatenate([poly_to_rotated_box_np(polys), np.asarray(groups, np.float32)[:, None]], 1)
+    else:
+        from jdet_amd.ops.nms_poly import poly_nms_keep_mask
+        rb = np.concatenate([np.asarray(polys, np.float32).reshape(-1, 8), np.asarray(groups, np.float32)[:, None]], 1)
     sc = np.asarray(scores, np.float32)
     keep = np.zeros(len(sc), bool)
     for idx in group_chunks(groups, max_boxes):
@@ -75,8 +80,10 @@ def device_group_nms(polys, scores, groups, thresh, device=None, max_boxes=MAX_B
         boxes = torch.from_numpy(rb[idx]).to(dev)
         s = torch.from_numpy(sc[idx]).to(dev)
         order = torch.argsort(s, descending=True, stable=True)
-        order = order[torch.argsort(boxes[order, 5], stable=True)]
-        keep[idx] = nms_rotated_keep_mask(boxes, order, thresh, rule="cuda").cpu().numpy().astype(bool)
+        order = order[torch.argsort(boxes[order, -1], stable=True)]
+        mask = nms_rotated_keep_mask(boxes, order, thresh, rule="cuda") if rect else \
+            poly_nms_keep_mask(boxes, order, thresh)
+        keep[idx] = mask.cpu().numpy().astype(bool)
     return keep
 
 

@@ -10,7 +10,7 @@ boxes -> `box_iou_rotated`), and only the take-once bookkeeping remains a host l
 """
 import numpy as np
 
-from .np_boxes import poly_to_rotated_box_np
+from .np_boxes import poly_to_rotated_box_np, polys_are_rectangles
 
 
 def voc_ap(rec, prec, use_07_metric=False):
@@ -27,13 +27,20 @@ def voc_ap(rec, prec, use_07_metric=False):
 
 
 def device_iou_matrix(det_polys, gt_polys, device=None):
-    """(m,8) x (k,8) rectangles given by their corners -> (m,k) IoU on the HIP device"""
+    """(m,8) x (k,8) polygons given by their corners -> (m,k) IoU on the HIP device.  Rectangles (what the detectors
+    emit and most DOTA labels are) go through the rotated-box kernel; anything else -- foreign submissions, skewed
+    ground-truth quadrilaterals -- through the polygon kernel with `iou_poly`'s rule (nms_poly.py:L247-252)."""
     import torch
-    from jdet_amd.ops import box_iou_rotated
     dev = torch.device("cuda") if device is None else torch.device(device)
-    a = torch.from_numpy(poly_to_rotated_box_np(det_polys)).to(dev)
-    b = torch.from_numpy(poly_to_rotated_box_np(gt_polys)).to(dev)
-    return box_iou_rotated(a, b).cpu().numpy()
+    if polys_are_rectangles(det_polys) and polys_are_rectangles(gt_polys):
+        from jdet_amd.ops import box_iou_rotated
+        a = torch.from_numpy(poly_to_rotated_box_np(det_polys)).to(dev)
+        b = torch.from_numpy(poly_to_rotated_box_np(gt_polys)).to(dev)
+        return box_iou_rotated(a, b).cpu().numpy()
+    from jdet_amd.ops.nms_poly import poly_iou_matrix
+    a = torch.from_numpy(np.asarray(det_polys, np.float32).reshape(-1, 8)).to(dev)
+    b = torch.from_numpy(np.asarray(gt_polys, np.float32).reshape(-1, 8)).to(dev)
+    return poly_iou_matrix(a, b, 1).cpu().numpy()
 
 
 def voc_eval_dota(dets, gts, iou_matrix_fn=device_iou_matrix, ovthresh=0.5, use_07_metric=False):
