@@ -222,14 +222,16 @@ def make_retinanet_infer(a, rank, dev):
     head = model.bbox_head
     g = torch.Generator(device="cpu").manual_seed(7)
     noise = {}
-    orig = head.forward_single
+    orig = head.get_bboxes
 
-    def forward_single(x, stride):
-        cls, reg = orig(x, stride)
-        if stride not in noise:
-            noise[stride] = (torch.randn(cls.shape, generator=g) * 1.5 - 1.4).to(dev)   # bias init is -4.6
-        return cls + noise[stride], reg
-    head.forward_single = forward_single
+    def get_bboxes(cls_scores, bbox_preds, img_metas, rescale=True):
+        shifted = []
+        for lvl, cls in enumerate(cls_scores):
+            if lvl not in noise:
+                noise[lvl] = (torch.randn(cls.shape, generator=g) * 1.5 - 1.4).to(dev)   # bias init is -4.6
+            shifted.append(cls + noise[lvl])
+        return orig(shifted, bbox_preds, img_metas, rescale)
+    head.get_bboxes = get_bboxes
     amp = {"none": None, "bf16": torch.bfloat16, "fp16": torch.float16}[a.amp]
 
     def step():

@@ -19,6 +19,7 @@ from torch import nn
 
 from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
 from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
+from jdet_amd.models.utils.level_pack import run_levels
 from jdet_amd.ops.bbox_transforms import bbox2delta, delta2bbox
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
 
@@ -61,11 +62,11 @@ class AnchorHead(nn.Module):
             nn.init.normal_(m.weight, 0, 0.01)
             nn.init.constant_(m.bias, 0.0)
 
-    def forward_single(self, x):
+    def forward_single(self, x, mask=None):
         return self.conv_cls(x), self.conv_reg(x)
 
     def forward(self, feats):
-        outs = [self.forward_single(f) for f in feats]
+        outs = run_levels(list(feats), self.forward_single)     # small levels as one packed tensor
         return [o[0] for o in outs], [o[1] for o in outs]
 
     execute = forward
@@ -166,8 +167,8 @@ class FasterrcnnHead(AnchorHead):
     def _heads(self):
         return [self.rpn_conv, self.rpn_cls, self.rpn_reg]
 
-    def forward_single(self, x):
-        x = F.relu(self.rpn_conv(x))
+    def forward_single(self, x, mask=None):
+        x = F.relu(self.rpn_conv(x))      # the 1x1 layers below read no neighbours: a packed input needs no mask
         return self.rpn_cls(x), self.rpn_reg(x)
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, gt_bboxes_ignore=None):

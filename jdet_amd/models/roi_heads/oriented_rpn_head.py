@@ -23,6 +23,7 @@ from torch import nn
 
 from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
 from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
+from jdet_amd.models.utils.level_pack import run_levels
 from jdet_amd.ops.bbox_transforms import obb2hbb
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
 
@@ -64,8 +65,8 @@ class OrientedRPNHead(nn.Module):
         self.rpn_reg = nn.Conv2d(feat_channels, self.num_anchors * 6, 1)
 
     # ------------------------------------------------------------------ network
-    def forward_single(self, x):
-        x = F.relu(self.rpn_conv(x))
+    def forward_single(self, x, mask=None):
+        x = F.relu(self.rpn_conv(x))      # the 1x1 layers below read no neighbours: a packed input needs no mask
         return self.rpn_cls(x), self.rpn_reg(x)
 
     @staticmethod
@@ -140,7 +141,7 @@ class OrientedRPNHead(nn.Module):
                                       target["img_size"]) for i, target in enumerate(targets)]
 
     def forward(self, features, targets):
-        outs = [self.forward_single(f) for f in features]
+        outs = run_levels(list(features), self.forward_single)
         cls_scores, bbox_preds = [o[0] for o in outs], [o[1] for o in outs]
         losses = self.loss(cls_scores, bbox_preds, targets) if self.training else dict()
         return self.get_bboxes(cls_scores, bbox_preds, targets), losses

@@ -6,6 +6,7 @@ from torch import nn
 
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedRetinaNet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
+from jdet_amd.models.utils.level_pack import run_levels
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.utils.general import multi_apply
@@ -73,15 +74,18 @@ class RotatedRetinaHead(RotatedAnchorHeadMixin, nn.Module):
         normal_init(self.retina_reg, std=0.01)
         normal_init(self.retina_cls, std=0.01, bias=bias_cls)
 
-    def forward_single(self, x, stride):
-        reg_feat = x
+    def forward_single(self, x, stride=None, mask=None):
+        """mask: set when x is a LevelPack of several small levels (models/utils/level_pack.py)"""
+        reg_feat = cls_feat = x
         for conv in self.reg_convs:
             reg_feat = conv(reg_feat)
-        bbox_pred = self.retina_reg(reg_feat)
-        cls_feat = x
+            if mask is not None:
+                reg_feat = reg_feat * mask
         for conv in self.cls_convs:
             cls_feat = conv(cls_feat)
-        return self.retina_cls(cls_feat), bbox_pred
+            if mask is not None:
+                cls_feat = cls_feat * mask
+        return self.retina_cls(cls_feat), self.retina_reg(reg_feat)
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         cfg = self.train_cfg.copy()
@@ -126,7 +130,8 @@ class RotatedRetinaHead(RotatedAnchorHeadMixin, nn.Module):
         return result_list
 
     def forward(self, feats, targets):
-        outs = multi_apply(self.forward_single, feats, self.anchor_strides)
+        per_level = run_levels(list(feats), lambda x, mask: self.forward_single(x, mask=mask))
+        outs = tuple(map(list, zip(*per_level)))
         if self.training:
             return self.loss(*outs, *self.parse_targets(targets))
         return self.get_bboxes(*outs, self.parse_targets(targets, is_train=False))

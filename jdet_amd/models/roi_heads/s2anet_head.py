@@ -12,6 +12,7 @@ from torch import nn
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
 from jdet_amd.models.boxes.box_ops import delta2bbox_rotated
+from jdet_amd.models.utils.level_pack import LevelPack
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.ops.dcn_v1 import DeformConv
@@ -84,6 +85,8 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         self.anchor_generators = [AnchorGeneratorRotatedS2ANet(b, anchor_scales, anchor_ratios)
                                   for b in self.anchor_base_sizes]
         self.base_anchors = dict()   # anchor cache, keyed by (level, featmap size, device)
+        # levels of at most this many positions run their conv towers as ONE packed tensor (see LevelPack)
+        self.pack_max_positions = 1024
         self._init_layers()
 
     def _init_layers(self):
@@ -131,33 +134,57 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         normal_init(self.odm_reg, std=0.01)
 
     # ------------------------------------------------------------------ forward
-    def forward_single(self, x, stride):
-        fam_reg_feat = x
-        for conv in self.fam_reg_convs:
-            fam_reg_feat = conv(fam_reg_feat)
-        fam_bbox_pred = self.fam_reg(fam_reg_feat)
-        if self.training:   # the FAM classification tower only runs in training (L213-220)
-            fam_cls_feat = x
-            for conv in self.fam_cls_convs:
-                fam_cls_feat = conv(fam_cls_feat)
-            fam_cls_score = self.fam_cls(fam_cls_feat)
-        else:
-            fam_cls_score = None
+    def _towers(self, x, convs, mask=None):
+        for conv in convs:
+            x = conv(x)
+            if mask is not None:
+                x = x * mask       # the gaps of a packed tensor stay zero: they are the zero padding of each level
+        return x
+
+    def _fam(self, x, mask=None):
+        fam_bbox_pred = self.fam_reg(self._towers(x, self.fam_reg_convs, mask))
+        # the FAM classification tower only runs in training (L213-220)
+        fam_cls_score = self.fam_cls(self._towers(x, self.fam_cls_convs, mask)) if self.training else None
+        return fam_cls_score, fam_bbox_pred
+
+    def _refine(self, x, fam_bbox_pred, stride):
         num_level = self.anchor_strides.index(stride)
-        featmap_size = tuple(fam_bbox_pred.shape[-2:])
-        init_anchors = self._init_anchors(num_level, featmap_size, x.device)
+        init_anchors = self._init_anchors(num_level, tuple(fam_bbox_pred.shape[-2:]), x.device)
         refine_anchor = bbox_decode(fam_bbox_pred.detach(), init_anchors, self.target_means, self.target_stds)
-        align_feat = self.align_conv(x, refine_anchor.clone(), stride)
+        return refine_anchor, self.align_conv(x, refine_anchor.clone(), stride)
+
+    def _odm(self, align_feat, mask=None):
         or_feat = self.or_conv(align_feat)
-        odm_reg_feat = or_feat
+        if mask is not None:
+            or_feat = or_feat * mask
         odm_cls_feat = self.or_pool(or_feat) if self.with_orconv else or_feat
-        for conv in self.odm_reg_convs:
-            odm_reg_feat = conv(odm_reg_feat)
-        for conv in self.odm_cls_convs:
-            odm_cls_feat = conv(odm_cls_feat)
-        odm_cls_score = self.odm_cls(odm_cls_feat)
-        odm_bbox_pred = self.odm_reg(odm_reg_feat)
+        odm_cls_score = self.odm_cls(self._towers(odm_cls_feat, self.odm_cls_convs, mask))
+        odm_bbox_pred = self.odm_reg(self._towers(or_feat, self.odm_reg_convs, mask))
+        return odm_cls_score, odm_bbox_pred
+
+    def forward_single(self, x, stride):
+        fam_cls_score, fam_bbox_pred = self._fam(x)
+        refine_anchor, align_feat = self._refine(x, fam_bbox_pred, stride)
+        odm_cls_score, odm_bbox_pred = self._odm(align_feat)
         return fam_cls_score, fam_bbox_pred, refine_anchor, odm_cls_score, odm_bbox_pred
+
+    def forward_packed(self, xs, strides):
+        """The same five outputs per level for a group of SMALL levels (P5-P7 of a 1024 tile: 32x32, 16x16, 8x8),
+        with every convolution of the FAM / ODM towers run once on a packed tensor instead of once per level.  The
+        towers share their weights across levels, and on these maps a 3x3 conv over 256 channels is latency bound
+        (a 2304-deep reduction for a handful of output tiles: ~48 us each whatever the size); one launch for the
+        three levels costs about what one of them did, and the weight gradients need no per-level accumulation.
+        AlignConv (per-level anchors / offsets) stays per level.  Equal to the per-level path up to the library's
+        accumulation order (tests/test_gpu_s2anet.py)."""
+        pack = LevelPack.cached([tuple(x.shape[-2:]) for x in xs], xs[0].device)
+        mask = pack.mask.to(xs[0].dtype)
+        fam_cls_p, fam_box_p = self._fam(pack.pack(xs), mask)
+        fam_box = pack.unpack(fam_box_p)
+        fam_cls = pack.unpack(fam_cls_p) if fam_cls_p is not None else [None] * len(xs)
+        refined = [self._refine(x, b, stride) for x, b, stride in zip(xs, fam_box, strides)]
+        odm_cls_p, odm_box_p = self._odm(pack.pack([r[1] for r in refined]), mask)
+        odm_cls, odm_box = pack.unpack(odm_cls_p), pack.unpack(odm_box_p)
+        return [(fam_cls[i], fam_box[i], refined[i][0], odm_cls[i], odm_box[i]) for i in range(len(xs))]
 
     def get_refine_anchors(self, featmap_sizes, refine_anchors, img_metas, is_train=True, device=None):
         num_levels = len(featmap_sizes)
@@ -247,8 +274,23 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
                                                       img_shape, scale_factor, cfg, rescale))
         return result_list
 
+    def _level_outputs(self, feats):
+        """per level (fam_cls_score, fam_bbox_pred, refine_anchor, odm_cls_score, odm_bbox_pred); the small levels
+        go through forward_packed together"""
+        small = [i for i, f in enumerate(feats)
+                 if f.is_cuda and f.shape[-2] * f.shape[-1] <= self.pack_max_positions]
+        outs = [None] * len(feats)
+        if len(small) >= 2:
+            packed = self.forward_packed([feats[i] for i in small], [self.anchor_strides[i] for i in small])
+            for i, o in zip(small, packed):
+                outs[i] = o
+        for i, f in enumerate(feats):
+            if outs[i] is None:
+                outs[i] = self.forward_single(f, self.anchor_strides[i])
+        return tuple(map(list, zip(*outs)))
+
     def forward(self, feats, targets):
-        outs = multi_apply(self.forward_single, feats, self.anchor_strides)
+        outs = self._level_outputs(feats)
         if self.training:
             return self.loss(*outs, *self.parse_targets(targets))
         return self.get_bboxes(*outs, self.parse_targets(targets, is_train=False))

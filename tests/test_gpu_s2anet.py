@@ -134,3 +134,43 @@ def test_retinanet_obb_train_and_infer(dev):
     polys, scores, labels = res[0]
     assert polys.shape[0] > 0 and polys.shape[1] == 8 and scores.min() > 0.05 and labels.max() < 15
     assert torch.all(scores[1:] <= scores[:-1])
+
+
+def test_packed_small_levels_equal_the_per_level_path(dev):
+    """S2ANetHead runs the conv towers of the small pyramid levels on one packed tensor (LevelPack: levels stacked
+    along H, zero gaps kept zero); outputs and gradients equal the per-level execution up to the conv library's
+    accumulation order"""
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.models.roi_heads.s2anet_head import S2ANetHead
+    from jdet_amd.models.utils.level_pack import LevelPack
+    torch.manual_seed(0)
+    head = S2ANetHead(num_classes=16, in_channels=32, feat_channels=32, stacked_convs=2, with_orconv=True,
+                      anchor_strides=[8, 16, 32, 64, 128]).to(dev)
+    head.train()
+    sizes = [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)]          # 1600 positions: stays per level; 4 packed
+    feats = [torch.randn(2, 32, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for h, w in sizes]
+    pack = LevelPack(sizes[1:], dev)
+    assert pack.height == 20 + 1 + 10 + 1 + 5 + 1 + 3 and pack.width == 20
+    again = pack.unpack(pack.pack([f.detach() for f in feats[1:]]))
+    assert all(torch.equal(a, f.detach()) for a, f in zip(again, feats[1:]))
+
+    def run(limit):
+        head.pack_max_positions = limit
+        for f in feats:
+            f.grad = None
+        head.zero_grad()
+        outs = head._level_outputs(feats)
+        total = sum((o.float() ** 2).sum() * (0.5 + k) for k, group in enumerate(outs) for o in group
+                    if o is not None and o.requires_grad)
+        total.backward()
+        flat = [o.detach().clone() for group in outs for o in group if o is not None]
+        grads = [f.grad.clone() for f in feats] + [p.grad.clone() for p in head.parameters() if p.grad is not None]
+        return flat, grads
+
+    ref_out, ref_grad = run(0)
+    got_out, got_grad = run(1024)
+    assert len(ref_out) == len(got_out) and len(ref_grad) == len(got_grad)
+    for a, b in zip(got_out + got_grad, ref_out + ref_grad):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(b.abs().max())))
