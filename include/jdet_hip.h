@@ -116,6 +116,9 @@ int jdet_debug_gather_probe(const float* buf, long total_rows, int window_rows, 
                             int n_blocks, int unroll, float* sink, jdet_stream_t stream);
 /* ... the same gather with every row added `pairs` times into a 49 x 256 LDS accumulator block (ds_add_f32) that is
  * streamed to out (n_blocks x 49 x 256 floats) at the end: the main loop of a pixel-stationary RoIAlign, emulated. */
+/* ... the same rows fetched as dword / dwordx2 / dwordx4 loads (dwords_per_lane 1 / 2 / 4; 4 rows in flight) */
+int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
+                                  int dwords_per_lane, int n_blocks, float* sink, jdet_stream_t stream);
 int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
                                        int pairs, int n_blocks, float* out, jdet_stream_t stream);
 

@@ -30,6 +30,7 @@ SIGNATURES = {
     "jdet_roi_align_backward_clean_bytes": (_sz, [_i] * 9),
     "jdet_debug_roi_tile_timeline": (_i, [_p]),
     "jdet_debug_gather_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _i, _p, _p]),
+    "jdet_debug_gather_width_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_gather_accumulate_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "jdet_roi_align_backward_workspace": (_sz, [_i] * 9),
     "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _sz, _p]),

@@ -39,6 +39,34 @@ __global__ __launch_bounds__(256) void gather_probe_kernel(const float* __restri
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[wave * 64 + lane] = acc.x;   // keeps the loads alive
 }
 
+// The same 1 KiB row fetched as 4 / 2 / 1 load instructions of 4 / 8 / 16 bytes per lane (dword / dwordx2 / dwordx4):
+// does the texture path deliver more bytes per clock with narrower loads?
+template <int W>
+__global__ __launch_bounds__(256) void gather_width_probe_kernel(const float* __restrict__ buf, long total_rows,
+                                                                 int window_rows, int rows_per_wave,
+                                                                 float* __restrict__ sink) {
+  typedef float vw __attribute__((ext_vector_type(W)));
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float acc = 0.f;
+  for (int i = 0; i < rows_per_wave; i += 4) {
+    vw v[4][4 / W];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const long row = (long)(mix(wave * 7919u + (unsigned)(i + u)) % (unsigned)window_rows);
+#pragma unroll
+      for (int j = 0; j < 4 / W; j++)
+        v[u][j] = *reinterpret_cast<const vw*>(buf + row * 256 + j * 64 * W + lane * W);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int j = 0; j < 4 / W; j++)
+        acc += v[u][j][0];
+  }
+  if (acc == 12345.678f) sink[wave * 64 + lane] = acc;
+}
+
 // The main loop of a pixel-stationary RoIAlign, emulated: every loaded row is added `pairs` times into an LDS
 // accumulator block [49 bins][256 channels] with ds_add_f32 (channel 4*lane+k of a bin lives at k*64+lane: conflict
 // free), and at the end the block (50 KB) is streamed to `out` with non-temporal stores -- loads through the TA, LDS
@@ -91,6 +119,24 @@ JDET_API int jdet_debug_gather_accumulate_probe(const float* buf, long total_row
     return JDET_E_BADARG;
   hipLaunchKernelGGL(gather_accumulate_probe_kernel, dim3(n_blocks), dim3(256), 49 * 256 * sizeof(float),
                      (hipStream_t)stream, buf, total_rows, window_rows, rows_per_wave, pairs, out);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
+                                           int dwords_per_lane, int n_blocks, float* sink, jdet_stream_t stream) {
+  if (!buf || !sink || total_rows <= 0 || window_rows <= 0 || window_rows > total_rows || rows_per_wave <= 0 ||
+      n_blocks <= 0)
+    return JDET_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dwords_per_lane == 1)
+    hipLaunchKernelGGL(gather_width_probe_kernel<1>, dim3(n_blocks), dim3(256), 0, st, buf, total_rows, window_rows,
+                       rows_per_wave, sink);
+  else if (dwords_per_lane == 2)
+    hipLaunchKernelGGL(gather_width_probe_kernel<2>, dim3(n_blocks), dim3(256), 0, st, buf, total_rows, window_rows,
+                       rows_per_wave, sink);
+  else
+    hipLaunchKernelGGL(gather_width_probe_kernel<4>, dim3(n_blocks), dim3(256), 0, st, buf, total_rows, window_rows,
+                       rows_per_wave, sink);
   return jdet_launch_status();
 }
 

@@ -81,3 +81,22 @@ print("%-58s %9s" % ("rows per wave x pairs per row", "us"))
 for per_wave, pairs in ((59, 0), (59, 1), (59, 2), (59, 3), (122, 0), (122, 1), (30, 2), (30, 4)):
     print("%-58s %9.1f" % ("%d x %d  (%.2f M rows, %.2f M pairs)" % (per_wave, pairs, per_wave * 8e-3, per_wave * 8e-3 * pairs),
                            run_acc(512, per_wave, pairs)))
+
+
+print("# the same 1 KiB rows as dword / dwordx2 / dwordx4 loads (4 rows in flight per wave), shared window")
+print("%-58s %9s %9s" % ("window, load width", "us", "TB/s"))
+for window in (16, 1024, 65536):
+    for w in (1, 2, 4):
+        def go():
+            L.check(lib.jdet_debug_gather_width_probe(L.ptr(buf), ROWS, window, 128, w, 2000, L.ptr(sink),
+                                                      L.stream_ptr(buf)), "probe")
+        for _ in range(5):
+            go()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(40):
+            go()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 40 * 1e3
+        print("%-58s %9.1f %9.2f" % ("%d KiB window, %d B per lane" % (window, 4 * w), us, 2000 * 4 * 128 * 1024 / 1e9 / (us * 1e-6) / 1e3))
