@@ -320,6 +320,18 @@ int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int
  *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
  *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
  * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+/* Feature refinement of R3Det, replaces fr.py:L113-159 (forward) and L161-242 (backward, 1 + 4 * points float
+ * atomics per scalar there; a sorted gather here).  feat / out / grads: (N, H, W, C) channels-last, C % 4 == 0;
+ * boxes (N, H, W, 5) [x_ctr, y_ctr, w, h, angle]: out = feat + sum over the `points` (1: centre; 5: centre + the four
+ * corners) of the bilinear sample of feat at that point, with the reference's coordinate convention (box column 0
+ * is used as the row coordinate, fr.py:L134-135). */
+int jdet_feature_refine_forward(const float* feat_nhwc, const float* boxes, int N, int C, int H, int W,
+                                float spatial_scale, int points, float* out_nhwc, jdet_stream_t stream);
+size_t jdet_feature_refine_backward_workspace(int N, int C, int H, int W, int points);
+int jdet_feature_refine_backward(const float* grad_out_nhwc, const float* boxes, int N, int C, int H, int W,
+                                 float spatial_scale, int points, float* grad_in_nhwc, void* workspace,
+                                 size_t workspace_bytes, jdet_stream_t stream);
+
 /* Polygon (4-point) IoU matrix ious (n1, n2) and polygon NMS.  Replaces nms_poly.py: `devPolyIoU` L113-133 /
  * `poly_nms` L187-232 / `multiclass_poly_nms` L234-245 and the per-pair CPU `iou_poly` L247-252 of the DOTA
  * evaluation and tile merging.  polys rows: x1 y1 .. x4 y4 (stride >= 8 floats), any orientation, convex or not.

@@ -177,3 +177,10 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_midpoint_offset_decode(N, N, 4, six, six, 0.016, N, N) == -1
     assert lib.jdet_oriented_delta_decode(N, N, 4, 0, six, six, 0.016, N, N) == -1                     # ncls < 1
     assert lib.jdet_debug_gather_probe(N, 0, 1, 1, 0, 1, 16, N, N) == -1
+    assert lib.jdet_feature_refine_forward(N, N, 1, 8, 4, 4, 0.125, 3, N, N) == -1                     # points in {1, 5}
+    assert lib.jdet_feature_refine_forward(N, N, 1, 6, 4, 4, 0.125, 5, N, N) == -2                     # C % 4
+    assert lib.jdet_feature_refine_forward(N, N, 0, 8, 4, 4, 0.125, 5, N, N) == 0
+    assert lib.jdet_feature_refine_backward_workspace(1, 6, 4, 4, 5) == 0
+    assert lib.jdet_feature_refine_backward(N, N, 1, 8, 4, 4, 0.125, 5, N, N, 0, N) == -1
+    assert lib.jdet_poly_iou(N, 2, 7, N, 2, 8, 0, N, N) == -1                                          # stride < 8
+    assert lib.jdet_nms_poly(N, 4, 9, N, 0.1, 0, N, N, 0, N) == -1                                     # n_labels < 1
