@@ -38,7 +38,9 @@ def nms_keep_mask(boxes, scores, thresh, labels=None, n_labels=None, visit_order
             visit = order[torch.argsort(labels[order], stable=True)]   # class by class, descending score inside
     obb = torch.stack(cols, dim=1).contiguous()
     o32 = visit.to(torch.int32).contiguous()
-    keep = torch.empty((n,), dtype=torch.uint8, device=b.device)
+    # one scan workgroup per label writes the flags of ITS boxes: a label outside 0 .. n_labels-1 is never visited and
+    # stays "suppressed" (zeros) instead of uninitialised
+    keep = torch.zeros((n,), dtype=torch.uint8, device=b.device)
     wsb = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=b.device)
     L.check(L.lib().jdet_nms_labeled(L.ptr(obb), n, obb.shape[1], L.ptr(o32), float(thresh), 0, 0, 1,

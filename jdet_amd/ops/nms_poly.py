@@ -40,7 +40,7 @@ def poly_nms_keep_mask(polys, order, thresh, n_labels=1):
     n, rl = p.shape
     assert rl in (8, 9)
     o = order.to(torch.int32).contiguous()
-    keep = torch.empty((n,), dtype=torch.uint8, device=p.device)
+    keep = (torch.zeros if n_labels > 1 else torch.empty)((n,), dtype=torch.uint8, device=p.device)
     wsb = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(wsb, 8),), dtype=torch.uint8, device=p.device)
     L.check(L.lib().jdet_nms_poly(L.ptr(p), n, rl, L.ptr(o), float(thresh), int(n_labels) if rl == 9 else 1,

@@ -26,7 +26,7 @@ def nms_rotated_keep_mask(dets, order, iou_threshold, rule=None, n_labels=1):
     d = L.f32c(dets)
     n, bl = d.shape
     o = order.to(torch.int32).contiguous()
-    keep = torch.empty((n,), dtype=torch.uint8, device=d.device)
+    keep = (torch.zeros if n_labels > 1 else torch.empty)((n,), dtype=torch.uint8, device=d.device)
     ws_bytes = L.lib().jdet_nms_rotated_workspace(n)
     ws = torch.empty((max(ws_bytes, 8),), dtype=torch.uint8, device=d.device)
     L.check(L.lib().jdet_nms_labeled(L.ptr(d), n, bl, L.ptr(o), float(iou_threshold),
