@@ -320,6 +320,14 @@ int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int
  *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
  *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
  * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+/* Input pipeline on the device: uint8 batch (N, Hs, Ws, 3) -> float32 (N, Hs, Ws, 3) = channels-last memory of a
+ * (N, 3, Hs, Ws) tensor, (v - mean[c]) / std[c] with the optional channel reversal first (`Normalize`,
+ * data/transforms.py:L467-487), zeros outside each image's valid_hw[n] = (height, width) (`collate_batch`,
+ * data/custom.py:L90-106).  mean3 / std3 are HOST pointers indexed by output channel.  Bit-identical to the host
+ * arithmetic; a quarter of the PCIe bytes. */
+int jdet_normalize_u8_nhwc(const uint8_t* src_nhwc, const int32_t* valid_hw, int N, int Hs, int Ws,
+                           const float* mean3, const float* std3, int swap_rb, float* dst_nhwc, jdet_stream_t stream);
+
 /* Feature refinement of R3Det, replaces fr.py:L113-159 (forward) and L161-242 (backward, 1 + 4 * points float
  * atomics per scalar there; a sorted gather here).  feat / out / grads: (N, H, W, C) channels-last, C % 4 == 0;
  * boxes (N, H, W, 5) [x_ctr, y_ctr, w, h, angle]: out = feat + sum over the `points` (1: centre; 5: centre + the four

@@ -38,6 +38,7 @@ SIGNATURES = {
     "jdet_box_iou_rotated": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "jdet_nms_rotated_workspace": (_sz, [_i]),
     "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),
+    "jdet_normalize_u8_nhwc": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "jdet_feature_refine_forward": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     "jdet_feature_refine_backward_workspace": (_sz, [_i] * 5),
     "jdet_feature_refine_backward": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _p, _p, _sz, _p]),

@@ -40,8 +40,19 @@ def _load_pickle(path):
 
 
 def collate_batch(batch):
-    """[(image (3,h,w) float32, target)] -> ((N,3,Hmax,Wmax) float32 zero-padded at right / bottom, [targets])"""
+    """[(image (3,h,w) float32, target)] -> ((N,3,Hmax,Wmax) float32 zero-padded at right / bottom, [targets]).
+    Samples left un-normalised for the device (`Normalize(on_device=True)`: uint8 (h,w,3)) are collated as
+    (N,Hmax,Wmax,3) uint8; each target then carries its image's extent in the canvas (`canvas_hw`)."""
     images, targets = zip(*batch)
+    if images[0].dtype == np.uint8 and images[0].ndim == 3 and images[0].shape[-1] == 3:
+        hmax = max(im.shape[0] for im in images)
+        wmax = max(im.shape[1] for im in images)
+        out = np.zeros((len(images), hmax, wmax, 3), dtype=np.uint8)
+        targets = [dict(t) for t in targets]
+        for i, im in enumerate(images):
+            out[i, :im.shape[0], :im.shape[1]] = im
+            targets[i]["canvas_hw"] = (int(im.shape[0]), int(im.shape[1]))
+        return out, targets
     hmax = max(im.shape[-2] for im in images)
     wmax = max(im.shape[-1] for im in images)
     out = np.zeros((len(images), 3, hmax, wmax), dtype=np.float32)
@@ -256,8 +267,28 @@ class DeviceFeeder:
         self.loader, self.device = loader, torch.device(device)
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
 
+    def _normalize(self, images_u8, targets):
+        """uint8 (N,H,W,3) batch on the device -> normalised (N,3,H,W) float32, channels-last (one launch)"""
+        from jdet_amd import _lib as L
+        n, h, w, _ = images_u8.shape
+        t0 = targets[0]
+        valid = torch.tensor([t["canvas_hw"] for t in targets], dtype=torch.int32).to(images_u8.device,
+                                                                                     non_blocking=True)
+        out = torch.empty((n, h, w, 3), dtype=torch.float32, device=images_u8.device)
+        L.check(L.lib().jdet_normalize_u8_nhwc(L.ptr(images_u8), L.ptr(valid), n, h, w,
+                                               L.vecn(np.asarray(t0["mean"]).reshape(-1), 3),
+                                               L.vecn(np.asarray(t0["std"]).reshape(-1), 3), int(bool(t0["to_bgr"])),
+                                               L.ptr(out), L.stream_ptr(out)), "jdet_normalize_u8_nhwc")
+        return out.permute(0, 3, 1, 2)
+
     def _stage(self, batch):
         images, targets = batch
+        if images.dtype == torch.uint8:            # Normalize(on_device=True): a quarter of the bytes cross PCIe
+            assert self.device.type == "cuda", "device-side normalisation needs a HIP device"
+            with torch.cuda.stream(self.stream):
+                images = self._normalize(images.to(self.device, non_blocking=True), targets)
+                targets = targets_to_device(targets, self.device)
+            return images, targets
         if self.stream is None:
             return images.to(self.device).contiguous(memory_format=torch.channels_last), \
                 targets_to_device(targets, self.device, False)

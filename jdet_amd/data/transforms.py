@@ -203,18 +203,28 @@ class Pad:
 
 @TRANSFORMS.register_module()
 class Normalize:
-    def __init__(self, mean, std, to_bgr=True):
+    """`on_device=True` (not in the reference): the arithmetic is left to the device -- the sample stays the uint8
+    (H, W, 3) array the decoder produced, `collate_batch` pads uint8, and `DeviceFeeder` uploads a quarter of the
+    bytes and runs jdet_normalize_u8_nhwc (the same two float32 operations per element: bit-identical images)."""
+
+    def __init__(self, mean, std, to_bgr=True, on_device=False):
         self.mean = np.float32(mean).reshape(-1, 1, 1)
         self.std = np.float32(std).reshape(-1, 1, 1)
         self.to_bgr = to_bgr
+        self.on_device = on_device
 
     def __call__(self, image, target=None):
+        target["mean"] = self.mean
+        target["std"] = self.std
+        target["to_bgr"] = self.to_bgr
+        if self.on_device:
+            image = np.ascontiguousarray(np.array(image) if isinstance(image, Image.Image)
+                                         else np.asarray(image).transpose((1, 2, 0)), dtype=np.uint8)
+            target["normalize_on_device"] = True
+            return image, target
         if isinstance(image, Image.Image):
             image = np.array(image).transpose((2, 0, 1))
         if self.to_bgr:
             image = image[::-1]
         image = (image - self.mean) / self.std
-        target["mean"] = self.mean
-        target["std"] = self.std
-        target["to_bgr"] = self.to_bgr
         return image, target

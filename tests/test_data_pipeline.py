@@ -436,3 +436,24 @@ def test_group_chunks_split_on_group_boundaries():
     assert len(runs) > 1
     one = group_chunks(np.zeros(1000, int), max_boxes=100)     # a single oversized image stays whole
     assert len(one) == 1 and len(one[0]) == 1000
+
+
+def test_uint8_samples_for_device_side_normalisation(tmp_path):
+    """Normalize(on_device=True) leaves the sample as the decoder's uint8 (h,w,3) array; collate_batch pads uint8 and
+    records each image's extent -- the host half of the PCIe-saving path (the device half: tests/test_gpu_data.py)"""
+    from jdet_amd.data import DOTADataset, collate_batch
+    rng = np.random.default_rng(6)
+    root = str(tmp_path / "trainval")
+    _make_dataset(root, [(96, 64), (64, 64), (80, 120)], rng)
+    norm = dict(S2ANET_TRAIN_TRANSFORMS[3])
+    tfm = [dict(type="RotatedResize", min_size=64, max_size=128), dict(type="Pad", size_divisor=32)]
+    host = DOTADataset(dataset_dir=root, transforms=tfm + [norm])
+    dev = DOTADataset(dataset_dir=root, transforms=tfm + [dict(norm, on_device=True)])
+    (xh, th), (xd, td) = host[0], dev[0]
+    assert xd.dtype == np.uint8 and xd.shape == (xh.shape[1], xh.shape[2], 3) and td["normalize_on_device"] is True
+    mean, std = np.float32(norm["mean"]).reshape(3, 1, 1), np.float32(norm["std"]).reshape(3, 1, 1)
+    assert np.array_equal(xh, (xd.transpose(2, 0, 1) - mean) / std)          # same float32 arithmetic, same bits
+    imgs, ts = collate_batch([dev[0], dev[2]])
+    assert imgs.dtype == np.uint8 and imgs.shape[0] == 2 and imgs.shape[3] == 3
+    assert ts[0]["canvas_hw"] == dev[0][0].shape[:2] and ts[1]["canvas_hw"] == dev[2][0].shape[:2]
+    assert imgs[0, ts[0]["canvas_hw"][0]:].max(initial=0) == 0 and imgs[1, :, ts[1]["canvas_hw"][1]:].max(initial=0) == 0
