@@ -90,22 +90,23 @@ def make_step(workload, d):
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         fp, rp = feat.data_ptr(), rois.data_ptr()
         path = os.environ.get("JDET_ROI_FWD_PATH", "roi_cl")
-        if path in ("tile", "tile_exact"):
-            # default product path: tile-stationary kernel, channels-last result (logical shape (R,256,7,7))
+        if path == "pool":
+            # EXPERIMENTAL (libjdet_experimental.so, not a product path): schedule + plan + register-cached pool kernel
+            from jdet_amd import _experimental as X
+            xl = X.lib()
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
-            exact = 1 if path == "tile_exact" else 0
-            wsb = lib.jdet_roi_align_forward_cl_workspace(1, 256, 256, R, 7, 7)
-            ws = torch.zeros((wsb,), dtype=torch.uint8, device=feat.device)   # cursor (first 256 B) zero on entry
+            wsb = xl.jdet_roi_align_forward_pool_workspace(R)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
             wp = ws.data_ptr()
 
             def step():
-                L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, exact, op, wp, wsb,
-                                                      L.stream_ptr(feat)), "fwd_cl")
+                L.check(xl.jdet_roi_align_forward_pool(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, op, wp, wsb,
+                                                       L.stream_ptr(feat)), "fwd_pool")
             d["out"] = out
             return (step, nbytes / 1e9, "GB", nbytes,
-                    "roi_tile_plan_kernel + roi_align_tile_pool_kernel<ROTATED,%s> (channels-last output)"
-                    % ("reference order" if exact else "fma"), "f32")
+                    "EXPERIMENTAL roi_order_kernel + roi_plan_kernel<ROTATED> + roi_pool_kernel (channels-last output)",
+                    "f32")
         cl = path == "roi_cl"   # default product path: RoI-stationary kernels, channels-last result
         out = torch.empty((R, 256, 7, 7), device=feat.device,
                           memory_format=torch.channels_last if cl else torch.contiguous_format)

@@ -1,0 +1,53 @@
+/* libjdet_experimental.so -- NOT part of the product ABI (include/jdet_hip.h, libjdet_hip.so).
+ *
+ * Measured alternatives and calibration probes that scripts/, bench.py (JDET_ROI_FWD_PATH=pool) and
+ * tests/test_gpu_experimental_pool.py load explicitly through jdet_amd/_experimental.py.  Nothing in jdet_amd.ops /
+ * jdet_amd.models loads this library.  Sources: jdet_amd/csrc/experimental/.
+ */
+#ifndef JDET_EXPERIMENTAL_H
+#define JDET_EXPERIMENTAL_H
+#include "jdet_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Register-cached RoIAlign forward, channels-last in and out (csrc/experimental/roi_align_pool.hip).  Same jt.code
+ * sites and values as jdet_roi_align_forward in its default (merged-tap) mode: roi_align_rotated.py:L265-283,
+ * roi_align_rotated_v1.py:L308-326, roi_align.py:L217-237.
+ *   out_cl    : (R, PH, PW, C) -- the reference's (R, C, PH, PW) tensor stored channels-last.
+ *   workspace : jdet_roi_align_forward_pool_workspace(R) bytes of scratch, no contract on its contents (per RoI: a
+ *               stream of merged (pixel slot, weight) taps in blocks of four, per group of bins the byte offsets of
+ *               the group's distinct pixels, the group count; plus the XCD schedule of jdet_roi_spatial_order).
+ * Three launches: the schedule (R >= 64), a plan kernel (one workgroup per RoI, no map traffic) and a persistent pool
+ * kernel in which a wave owns (group of bins, 128 channels), keeps the group's pixel rows in 96 VGPRs (each distinct
+ * pixel of the group is loaded once) and accumulates every bin from that register cache through M0-relative operands.
+ * Supported (jdet_roi_align_forward_pool_supported() == 1): rotated v0 / v1 and horizontal v0 / v1, C = 128 / 256 /
+ * 512, sample_num 1 or 2, PH*PW <= 64, H*W*C*4 < 2 GiB per image; otherwise JDET_E_UNSUPPORTED.  RoIs with a
+ * negative batch index are skipped (their rows stay untouched).
+ * Measured at the north-star point (profiles/r03_roi_pool_notes.md): plan 56 us + pool 64 us against 60 us for the
+ * product kernel -- the register cache halves the rows through the vector L1, but the forward is bound by the traffic
+ * beyond the L2, which it does not reduce.  Kept as the measured answer to "dedup the taps of a whole RoI". */
+int jdet_roi_align_forward_pool_supported(int variant, int C, int H, int W, int PH, int PW, int sample_num);
+size_t jdet_roi_align_forward_pool_workspace(int R);
+int jdet_roi_align_forward_pool(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                                const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                                float* out_cl, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+
+/* Calibration probe (scripts/gather_probe.py; csrc/experimental/gather_probe.hip): n_blocks workgroups of 4 waves, every
+ * wave loads rows_per_wave pseudo-random 1 KiB rows of buf (total_rows x 256 floats), `unroll` (4 / 8 / 16) in flight,
+ * drawn from a window of window_rows rows -- one shared window, or one per workgroup (local_windows != 0). */
+int jdet_debug_gather_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave, int local_windows,
+                            int n_blocks, int unroll, float* sink, jdet_stream_t stream);
+/* ... the same gather with every row added `pairs` times into a 49 x 256 LDS accumulator block (ds_add_f32) that is
+ * streamed to out (n_blocks x 49 x 256 floats) at the end: the main loop of a pixel-stationary RoIAlign, emulated. */
+/* ... the same rows fetched as dword / dwordx2 / dwordx4 loads (dwords_per_lane 1 / 2 / 4; 4 rows in flight) */
+int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
+                                  int dwords_per_lane, int n_blocks, float* sink, jdet_stream_t stream);
+int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
+                                       int pairs, int n_blocks, float* out, jdet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

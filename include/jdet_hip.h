@@ -73,29 +73,6 @@ int jdet_roi_align_forward(int variant, const float* feat_nhwc, int N, int C, in
                            int sample_num, int n_orient, const int32_t* order, float* out,
                            jdet_stream_t stream);
 
-/* Tile-stationary RoIAlign forward, channels-last in and out (csrc/roi_align_tile.hip).  Same jt.code sites
- * as jdet_roi_align_forward (roi_align_rotated.py:L265-283, roi_align_rotated_v1.py:L308-326,
- * roi_align.py:L217-237); same values.
- *   out_cl : (R, PH, PW, C) -- the reference's (R, C, PH, PW) tensor stored channels-last: the 32-channel
- *            chunk of a bin is one 128-byte store and a consumer reads it through channels-last strides.
- *   exact_order 1: the reference's operation order (bit-identical to the CPU oracle); 0: same weights, fma.
- *   workspace : jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW) bytes of scratch (the plan: per map
- *            tile the list of bins whose centre lies in it, with their sample tables).  Its FIRST 256 BYTES
- *            MUST BE ZERO ON ENTRY (the plan's allocation cursor) and are zero again when the call's work has
- *            run: zero-fill a buffer once, then keep re-using it on one stream.
- * Two launches: a plan kernel (no map traffic) and a pool kernel that stages a map tile
- * (+ halo) of one 32-channel chunk in LDS and serves every tap of the tile's bins from LDS; each map byte leaves
- * HBM once and no RoI ordering pass is needed.
- * Supported (jdet_roi_align_forward_cl_supported() == 1): rotated v0 / v1 and horizontal v0 / v1, C % 4 == 0,
- * sample_num 1 or 2, PH*PW <= 64, H*W*C*4 < 2 GiB per image; otherwise JDET_E_UNSUPPORTED (use
- * jdet_roi_align_forward).  RoIs with a negative batch index are skipped (their rows stay untouched). */
-int jdet_roi_align_forward_cl_supported(int variant, int C, int H, int W, int PH, int PW, int sample_num);
-size_t jdet_roi_align_forward_cl_workspace(int N, int H, int W, int R, int PH, int PW);
-int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W,
-                              const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
-                              int exact_order, float* out_cl, void* workspace, size_t workspace_bytes,
-                              jdet_stream_t stream);
-
 /* RoI-stationary forward (the kernels of jdet_roi_align_forward) with the channels-last result layout
  * out_cl (R, PH, PW, C): each wave stores a bin's channel chunk straight from registers (1 KiB contiguous,
  * non-temporal) instead of transposing the RoI's block through LDS.  Rotated v0 / v1, horizontal v0 / v1 and
@@ -104,23 +81,6 @@ int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C,
 int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, int C, int H, int W,
                                   const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
                                   int n_orient, const int32_t* order, float* out_cl, jdet_stream_t stream);
-
-/* Profiling hook of the tile kernel (scripts/tile_timeline.py): buf = device array of 32 uint64 per workgroup
- * (s_memtime stamps at the phase boundaries, hardware id in slot 31), or NULL to switch it off. */
-int jdet_debug_roi_tile_timeline(void* buf);
-
-/* Calibration probe (scripts/gather_probe.py; csrc/gather_probe.hip): n_blocks workgroups of 4 waves, every
- * wave loads rows_per_wave pseudo-random 1 KiB rows of buf (total_rows x 256 floats), `unroll` (4 / 8 / 16) in flight,
- * drawn from a window of window_rows rows -- one shared window, or one per workgroup (local_windows != 0). */
-int jdet_debug_gather_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave, int local_windows,
-                            int n_blocks, int unroll, float* sink, jdet_stream_t stream);
-/* ... the same gather with every row added `pairs` times into a 49 x 256 LDS accumulator block (ds_add_f32) that is
- * streamed to out (n_blocks x 49 x 256 floats) at the end: the main loop of a pixel-stationary RoIAlign, emulated. */
-/* ... the same rows fetched as dword / dwordx2 / dwordx4 loads (dwords_per_lane 1 / 2 / 4; 4 rows in flight) */
-int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
-                                  int dwords_per_lane, int n_blocks, float* sink, jdet_stream_t stream);
-int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
-                                       int pairs, int n_blocks, float* out, jdet_stream_t stream);
 
 /* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
  *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);

@@ -22,16 +22,9 @@ SIGNATURES = {
     "jdet_nchw_to_nhwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "jdet_nhwc_to_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
-    "jdet_roi_align_forward_cl_supported": (_i, [_i] * 7),
     "jdet_roi_align_forward_cl_roi": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
-    "jdet_roi_align_forward_cl_workspace": (_sz, [_i] * 6),
-    "jdet_roi_align_forward_cl": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_cl": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _i, _p]),
     "jdet_roi_align_backward_clean_bytes": (_sz, [_i] * 9),
-    "jdet_debug_roi_tile_timeline": (_i, [_p]),
-    "jdet_debug_gather_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _i, _p, _p]),
-    "jdet_debug_gather_width_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
-    "jdet_debug_gather_accumulate_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "jdet_roi_align_backward_workspace": (_sz, [_i] * 9),
     "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _sz, _p]),
     "jdet_roi_spatial_order": (_i, [_p, _i, _i, _f, _i, _i, _i, _p, _p, _p]),

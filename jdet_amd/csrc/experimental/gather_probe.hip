@@ -5,6 +5,7 @@
 // kernels are compared with these rates in DESIGN.md 3.1 -- the HBM stream roofline (8 TB/s) is not the one a
 // row gather can reach.  Not on any product path (scripts/gather_probe.py).
 #include "common.h"
+#include "jdet_experimental.h"
 
 namespace {
 

@@ -910,8 +910,11 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     // (the merged kernel keeps its per-wave tap lists in the first 2 KiB / wave of the dynamic LDS block)
     if (sample_num == 2 && !g_fwd_reference_order && nbins <= 64) {
-      // JDET_ROI_FWD_LDS_KB (profiling only): pads the LDS request to cap the workgroups per CU
-      static const int lds_kb = env_int("JDET_ROI_FWD_LDS_KB", 0);
+      // The LDS request caps the workgroups per CU at 4 (36 KiB each; the tap lists need 16): one workgroup fewer
+      // in flight per CU leaves the time where it is (59.4 vs 60.9 us at the north-star point) and cuts the reads
+      // beyond the L2 by 14 % (1.34 M vs 1.55 M 128-byte requests, profiles/r03_roi_pool_notes.md) -- fewer RoIs
+      // in flight, smaller working set.  JDET_ROI_FWD_LDS_KB overrides (profiling).
+      static const int lds_kb = env_int("JDET_ROI_FWD_LDS_KB", 36);
       const size_t lds_cl = lds_kb > 16 ? (size_t)lds_kb * 1024 : 8 * 2048;
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 0, true>), grid, dim3(256), lds_cl, st, feat, rois, out,
                          C, H, W, PH, PW, scale, order, 0);

@@ -34,61 +34,27 @@ SPATIAL_ORDER_MIN_ROIS = 64
 
 # Forward path (process-wide; tests and bench switch it):
 #   "roi_cl"     RoI-stationary kernels (csrc/roi_align.hip), channels-last result stored straight from registers
-#                [default: 65 us at the north-star point vs 78 us for the tile path, see DESIGN.md 3.1]
+#                [default]
 #   "roi"        the same kernels with the reference's (R,C,PH,PW)-contiguous result (transposed through LDS)
-#   "tile"       tile-stationary plan + pool kernels (csrc/roi_align_tile.hip), fma arithmetic, channels-last result
-#   "tile_exact" the tile kernels in the reference's operation order (bit-identical to the CPU oracle)
-# The arithmetic of the RoI-stationary kernels is jdet_set_roi_forward_mode (0 merged taps, 1 reference order).
-# Dialects / shapes a path does not take (RiRoIAlign, C % 4 != 0; for the tile path also adaptive sampling and
-# > 64 bins) fall back to "roi".  Either way the result is the same logical (R, C, PH, PW) tensor; only its strides
-# differ.
+# The arithmetic of the kernels is jdet_set_roi_forward_mode (0 merged taps, 1 reference order).  Shapes the
+# channels-last store does not take (C % 4 != 0, RiRoIAlign with other than 4 / 8 orientations) fall back to "roi".
+# Either way the result is the same logical (R, C, PH, PW) tensor; only its strides differ.
+# (Two measured alternatives are not product paths: the tile-stationary kernels of round 2 -- removed, DESIGN.md 3.1 --
+# and the register-cached plan + pool kernels, csrc/experimental/.)
 _FORWARD_PATH = ["roi_cl"]
 
 
 def set_forward_path(name):
-    assert name in ("tile", "tile_exact", "roi", "roi_cl")
+    assert name in ("roi", "roi_cl")
     prev = _FORWARD_PATH[0]
     _FORWARD_PATH[0] = name
     return prev
-
-
-def _tile_ok(variant, C, H, W, PH, PW, sample_num):
-    return _FORWARD_PATH[0] in ("tile", "tile_exact") and bool(
-        L.lib().jdet_roi_align_forward_cl_supported(int(variant), C, H, W, PH, PW, int(sample_num)))
 
 
 def _roi_cl_ok(variant, C, H, W, n_orient=1):
     if variant == V_RI and n_orient not in (4, 8):
         return False
     return _FORWARD_PATH[0] == "roi_cl" and C % 4 == 0 and H * W * C * 4 < (1 << 31)
-
-
-_PLAN_WS = {}
-
-
-def _plan_workspace(dev, nbytes):
-    """Scratch of the tile path.  Contract of jdet_roi_align_forward_cl: the first 256 bytes (the plan's cursor) are
-    zero on entry and are handed back zeroed, so the buffer is zero-filled once and then re-used -- one buffer per
-    (device, stream): launches on one stream are ordered, two streams must not share a plan."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _PLAN_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros((max(nbytes, 1 << 20),), dtype=torch.uint8, device=dev)
-        _PLAN_WS[key] = ws
-    return ws
-
-
-def _forward_cl(variant, feat, rois_c, out, PH, PW, scale, sample_num, exact):
-    """tile-stationary forward into the channels-last `out` (plan + pool launches, csrc/roi_align_tile.hip)"""
-    N, C, H, W = feat.shape
-    R = rois_c.shape[0]
-    if R == 0 or N == 0:
-        return
-    wsb = L.lib().jdet_roi_align_forward_cl_workspace(N, H, W, R, PH, PW)
-    ws = _plan_workspace(feat.device, wsb)
-    L.check(L.lib().jdet_roi_align_forward_cl(int(variant), L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                              float(scale), int(sample_num), int(exact), L.ptr(out), L.ptr(ws),
-                                              ws.numel(), L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
 
 
 _BWD_WS = {}
@@ -159,13 +125,7 @@ class RoIAlignFunction(torch.autograd.Function):
         rois_c = L.f32c(rois)
         N, C, H, W = feat.shape
         R = rois_c.shape[0]
-        if _tile_ok(variant, C, H, W, PH, PW, sample_num):
-            out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
-                              memory_format=torch.channels_last)
-            order = None
-            _forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num,
-                        1 if _FORWARD_PATH[0] == "tile_exact" else 0)
-        elif _roi_cl_ok(variant, C, H, W, n_orient):
+        if _roi_cl_ok(variant, C, H, W, n_orient):
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
                               memory_format=torch.channels_last)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
@@ -210,11 +170,9 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
         rois_c = L.f32c(rois)
         R = rois_c.shape[0]
         C = feats[0].shape[1]
-        tile = all(_tile_ok(variant, C, f.shape[2], f.shape[3], PH, PW, sample_num) for f in feats)
-        roi_cl = (not tile) and all(_roi_cl_ok(variant, C, f.shape[2], f.shape[3], n_orient) for f in feats)
+        roi_cl = all(_roi_cl_ok(variant, C, f.shape[2], f.shape[3], n_orient) for f in feats)
         out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device,
-                          memory_format=torch.channels_last if (tile or roi_cl) else torch.contiguous_format)
-        exact = 1 if _FORWARD_PATH[0] == "tile_exact" else 0
+                          memory_format=torch.channels_last if roi_cl else torch.contiguous_format)
         lvl = target_lvls.to(rois_c.device)
         masked, shapes = [], []
         for i, f in enumerate(feats):
@@ -223,9 +181,7 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             assert Ci == C
             r_i = rois_c.clone()
             r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
-            if R and tile:
-                _forward_cl(variant, fm, r_i, out, PH, PW, scales[i], sample_num, exact)
-            elif R and roi_cl:
+            if R and roi_cl:
                 L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                               float(scales[i]), int(sample_num), int(n_orient), None,
                                                               L.ptr(out), L.stream_ptr(fm)),

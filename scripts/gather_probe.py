@@ -9,13 +9,14 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from jdet_amd import _experimental as X  # noqa: E402
 from jdet_amd import _lib as L  # noqa: E402
 
 dev = torch.device("cuda:0")
 ROWS = 65536                                      # 64 MiB: the bench map
 buf = torch.randn((ROWS, 256), device=dev)
 sink = torch.zeros((1 << 20,), device=dev)
-lib = L.lib()
+lib = X.lib()   # the probes live in libjdet_experimental.so (include/jdet_experimental.h)
 
 
 def run(window, local, blocks=2000, per_wave=128, unroll=16, reps=40):

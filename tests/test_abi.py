@@ -56,6 +56,24 @@ def test_ctypes_signatures_match_header(built_lib):
     assert lib.jdet_nms_rotated_workspace(65) >= 65 * 2 * 8 + 2 * 4
 
 
+def test_experimental_library_is_separate(built_lib):
+    """include/jdet_experimental.h: every declared symbol is exported by libjdet_experimental.so, none of them by the
+    product library, and the product python never loads it"""
+    from jdet_amd import _experimental as X
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "jdet_experimental.h")).read(), flags=re.S)
+    names = re.findall(r"\b(?:int|size_t)\s+(jdet_\w+)\s*\(", src)
+    assert set(names) == set(X.SIGNATURES)
+    if not os.path.exists(X.LIB_PATH):
+        pytest.skip("libjdet_experimental.so not built")
+    raw, prod = ctypes.CDLL(X.LIB_PATH), ctypes.CDLL(built_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n) and not hasattr(prod, n), n
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "jdet_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "_experimental.py":
+                assert "_experimental" not in open(os.path.join(dirpath, f)).read(), f
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from jdet_amd._lib import JDetHipError
@@ -164,7 +182,6 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 0, 1, N, N, 0, 0, N) == -2   # adaptive
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -3   # workspace
     assert lib.jdet_roi_align_backward_cl(7, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -1   # variant
-    assert lib.jdet_roi_align_forward_cl_supported(2, 64, 64, 64, 7, 7, 2) == 0                        # tile path: no RiRoI
     assert lib.jdet_nms_labeled(N, 10, 5, N, 0.1, 1, 0, 0, 4, N, N, 0, N) == -1                        # labels need 6 columns
     assert lib.jdet_nms_labeled(N, 10, 6, N, 0.1, 1, 0, 1, 0, N, N, 0, N) == -1                        # n_labels < 1
     assert lib.jdet_nms_labeled(N, 0, 6, N, 0.1, 1, 0, 1, 5, N, N, 0, N) == 0
@@ -176,7 +193,6 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_midpoint_offset_decode(N, N, 0, six, six, 0.016, N, N) == 0
     assert lib.jdet_midpoint_offset_decode(N, N, 4, six, six, 0.016, N, N) == -1
     assert lib.jdet_oriented_delta_decode(N, N, 4, 0, six, six, 0.016, N, N) == -1                     # ncls < 1
-    assert lib.jdet_debug_gather_probe(N, 0, 1, 1, 0, 1, 16, N, N) == -1
     assert lib.jdet_feature_refine_forward(N, N, 1, 8, 4, 4, 0.125, 3, N, N) == -1                     # points in {1, 5}
     assert lib.jdet_feature_refine_forward(N, N, 1, 6, 4, 4, 0.125, 5, N, N) == -2                     # C % 4
     assert lib.jdet_feature_refine_forward(N, N, 0, 8, 4, 4, 0.125, 5, N, N) == 0

@@ -1,6 +1,6 @@
 """GPU parity: HIP RoIAlign family (through the C ABI / jdet_amd.ops) vs golden fixtures and the
-CPU oracle.  Forward tolerances (inputs ~N(0,1)): reference-order arithmetic (RoI-stationary mode 1, tile kernel
-"tile_exact") = 0 ulp (same operation order, contraction off); fma / merged-tap arithmetic = 2e-6 abs.
+CPU oracle.  Forward tolerances (inputs ~N(0,1)): reference-order arithmetic (mode 1) = 0 ulp (same operation order,
+contraction off); merged-tap arithmetic (default) = 2e-6 abs.
 Backward: 2e-5 abs (summation order of the gather / atomics)."""
 import numpy as np
 import pytest
@@ -16,15 +16,14 @@ FWD_MERGED_ATOL = 2e-6   # default mode
 BWD_ATOL = 2e-5
 
 
-PATHS = [("roi", 1, FWD_ATOL), ("roi", 0, FWD_MERGED_ATOL), ("roi_cl", 1, FWD_ATOL), ("roi_cl", 0, FWD_MERGED_ATOL),
-         ("tile_exact", 0, FWD_ATOL), ("tile", 0, FWD_MERGED_ATOL)]
+PATHS = [("roi", 1, FWD_ATOL), ("roi", 0, FWD_MERGED_ATOL), ("roi_cl", 1, FWD_ATOL), ("roi_cl", 0, FWD_MERGED_ATOL)]
 
 
-@pytest.fixture(params=PATHS, ids=["roi-reforder", "roi-merged", "roicl-reforder", "roicl-merged", "tile-exact", "tile"],
+@pytest.fixture(params=PATHS, ids=["roi-reforder", "roi-merged", "roicl-reforder", "roicl-merged"],
                 autouse=True)
 def fwd_mode(request):
-    """every forward path: RoI-stationary kernels (reference-order / merged-tap arithmetic) and the tile-stationary
-    kernel (reference-order / fma arithmetic).  Yields the forward tolerance of the path."""
+    """every forward path: (R,C,PH,PW)-contiguous / channels-last result x reference-order / merged-tap arithmetic.
+    Yields the forward tolerance of the path."""
     from jdet_amd import _lib as L
     from jdet_amd.ops import _roi_common as RC
     path, mode, atol = request.param
@@ -113,7 +112,7 @@ def test_cfg0_micro_vs_oracle(dev, fwd_mode):
 
 @pytest.mark.parametrize("variant", [O.V_ROT, O.V_ROT_V1, O.V_HBB0])
 def test_channels_last_result_and_gradient(dev, variant, fwd_mode):
-    """the tile path returns the (R,C,PH,PW) tensor with channels-last strides; a channels-last gradient goes to
+    """the channels-last paths return the (R,C,PH,PW) tensor with channels-last strides; a channels-last gradient goes to
     jdet_roi_align_backward_cl (no transpose pass) and must equal the oracle's scatter"""
     from jdet_amd.ops import _roi_common as RC
     rng = np.random.default_rng(21 + variant)
@@ -200,43 +199,6 @@ def test_backward_cl_kept_workspace_contract(dev):
             got = gin.permute(0, 3, 1, 2).cpu().numpy()
             np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
             assert int(ws_call[:clean].max()) == 0
-
-
-def test_tile_path_many_rois_and_big_rois(dev):
-    """the batching paths of the tile kernel: > 128 candidate RoIs per tile (several candidate batches), > 224 owned
-    bins per tile (several bin passes), RoIs far larger than the halo (per-bin global fallback), a masked RoI
-    (negative batch index: rows untouched).  Bit-exact against the oracle in reference-order arithmetic."""
-    from jdet_amd.ops import _roi_common as RC
-    rng = np.random.default_rng(99)
-    N, C, H, W, scale = 1, 36, 32, 32, 0.5     # C % 32 != 0: partial channel chunk
-    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
-    small = I.random_obbs(rng, 700, extent=24.0, wh=(2.0, 8.0))        # 700 tiny RoIs piled on one corner
-    small[:, :2] += 4.0
-    big = I.random_obbs(rng, 30, extent=W / scale, wh=(40.0, 200.0))    # up to 100 map pixels: bins of 14 px
-    rois = I.rois_from_obbs(np.concatenate([small, big], 0), np.zeros(730))
-    prev = RC.set_forward_path("tile_exact")
-    try:
-        x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
-        r = torch.from_numpy(rois).to(dev)
-        y = _layer(O.V_ROT, (7, 7), scale, 2)(x, r).cpu().numpy()
-        np.testing.assert_array_equal(y, O.roi_align_forward(O.V_ROT, feat, rois, (7, 7), scale, 2))
-        y1 = _layer(O.V_ROT, (7, 7), scale, 1)(x, r).cpu().numpy()      # 1x1 sampling grid
-        np.testing.assert_array_equal(y1, O.roi_align_forward(O.V_ROT, feat, rois, (7, 7), scale, 1))
-        # masked RoI: the kernel must not touch its rows
-        from jdet_amd import _lib as L
-        out = torch.full((730, C, 7, 7), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
-        r2 = r.clone()
-        r2[5, 0] = -1.0
-        wsb = L.lib().jdet_roi_align_forward_cl_workspace(N, H, W, 730, 7, 7)
-        ws = torch.zeros((wsb,), dtype=torch.uint8, device=dev)   # plan cursor: zero on entry, zero on return
-        L.check(L.lib().jdet_roi_align_forward_cl(0, x.data_ptr(), N, C, H, W, r2.data_ptr(), 730, 7, 7, scale, 2, 1,
-                                                  out.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(x)), "fwd_cl")
-        o = out.cpu().numpy()
-        assert int(ws[:256].to(torch.int32).abs().sum().item()) == 0    # the cursor came back zeroed
-        assert (o[5] == 7.0).all()
-        np.testing.assert_array_equal(np.delete(o, 5, 0), np.delete(y, 5, 0))
-    finally:
-        RC.set_forward_path(prev)
 
 
 def test_full_size_properties(dev):
