@@ -272,6 +272,10 @@ class DeviceFeeder:
         from jdet_amd import _lib as L
         n, h, w, _ = images_u8.shape
         t0 = targets[0]
+        for t in targets[1:]:   # one launch, one (mean, std, channel order): the batch must agree on them
+            assert (np.array_equal(np.asarray(t["mean"]), np.asarray(t0["mean"]))
+                    and np.array_equal(np.asarray(t["std"]), np.asarray(t0["std"]))
+                    and bool(t["to_bgr"]) == bool(t0["to_bgr"])), "samples of one batch disagree on mean / std / to_bgr"
         valid = torch.tensor([t["canvas_hw"] for t in targets], dtype=torch.int32).to(images_u8.device,
                                                                                      non_blocking=True)
         out = torch.empty((n, h, w, 3), dtype=torch.float32, device=images_u8.device)

@@ -218,10 +218,13 @@ class Normalize:
         target["std"] = self.std
         target["to_bgr"] = self.to_bgr
         if self.on_device:
-            image = np.ascontiguousarray(np.array(image) if isinstance(image, Image.Image)
-                                         else np.asarray(image).transpose((1, 2, 0)), dtype=np.uint8)
-            target["normalize_on_device"] = True
-            return image, target
+            arr = np.array(image) if isinstance(image, Image.Image) else np.asarray(image).transpose((1, 2, 0))
+            if arr.dtype == np.uint8:
+                target["normalize_on_device"] = True
+                return np.ascontiguousarray(arr), target
+            # an earlier transform left floats (or anything that is not the decoder's uint8): casting would wrap or
+            # truncate silently -- normalise this sample on the host instead
+            image = arr.transpose((2, 0, 1))
         if isinstance(image, Image.Image):
             image = np.array(image).transpose((2, 0, 1))
         if self.to_bgr:

@@ -57,7 +57,10 @@ def _roi_cl_ok(variant, C, H, W, n_orient=1):
     return _FORWARD_PATH[0] == "roi_cl" and C % 4 == 0 and H * W * C * 4 < (1 << 31)
 
 
-_BWD_WS = {}
+import collections
+
+_BWD_WS = collections.OrderedDict()
+_BWD_WS_MAX = 16   # (device, stream, map size) triples kept: an FPN has 4-5 maps per stream; captures add streams
 
 
 def _kept_backward_workspace(dev, map_shape, nbytes):
@@ -69,6 +72,9 @@ def _kept_backward_workspace(dev, map_shape, nbytes):
     if ws is None or ws.numel() < nbytes:
         ws = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
         _BWD_WS[key] = ws
+        while len(_BWD_WS) > _BWD_WS_MAX:       # least recently used out: a dropped buffer is simply re-created zeroed
+            _BWD_WS.popitem(last=False)
+    _BWD_WS.move_to_end(key)
     return ws, key
 
 

@@ -58,6 +58,8 @@ class Runner:
             torch.backends.cudnn.benchmark = True
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if self.device.type == "cuda":
+            if self.device.index is None:   # "cuda" / torch.device("cuda"): the current device
+                self.device = torch.device("cuda", torch.cuda.current_device())
             # the C-ABI kernels launch on the CURRENT HIP device: make the runner's device current (one process per GPU)
             torch.cuda.set_device(self.device)
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -194,6 +196,8 @@ class Runner:
             # bounded (least recently used capture dropped).
             self._graph_misses += 1
             if self._graph_misses > max(2, self._graph_cap):
+                # (ranks decide on their own: batch signatures differ per rank.  That is safe because an eager step's
+                # all-reduce -- _allreduce_grads -- uses the flat layout of the graph step, element for element)
                 if self.rank == 0:
                     print("jdet_amd.Runner: %d consecutive steps with a new batch signature -- HIP-graph mode is for "
                           "fixed-shape batches; continuing with eager steps" % self._graph_misses)
@@ -253,18 +257,34 @@ class Runner:
         self.iter += 1
         return all_loss.detach(), {k: v.detach() for k, v in losses.items()}
 
+    @staticmethod
+    def _flat_order(p, t):
+        """`t` (shaped like parameter p) in the element order `_flat_grads` gives p's segment of the flat buffer:
+        channels-last 4-D parameters are laid out (o, kh, kw, i), everything else in logical order"""
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+            return t.permute(0, 2, 3, 1)
+        return t
+
     def _allreduce_grads(self):
-        grads = [p.grad for p in self.model.parameters() if p.requires_grad and p.grad is not None]
-        if not grads:
+        """Gradient all-reduce of an eager step without DDP.  Same buffer as a graph step's, element for element:
+        every trainable parameter in model order (zeros where a rank has no gradient), so a rank that has left
+        HIP-graph mode and one that still replays its capture take part in the same collective."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        if not params:
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = torch.cat([(self._flat_order(p, p.grad).reshape(-1) if p.grad is not None
+                           else torch.zeros(p.numel(), dtype=torch.float32, device=p.device)) for p in params])
         dist.all_reduce(flat)
         flat.div_(self.world_size)
         off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view(g.shape))   # reshape(-1) flattened in logical order, whatever g's strides
+        for p in params:
+            n = p.numel()
+            seg = flat[off:off + n]
             off += n
+            if p.grad is None:       # the other ranks' contribution
+                p.grad = torch.zeros_like(p)
+            view = self._flat_order(p, p.grad)
+            view.copy_(seg.view(view.shape))
 
     def _leave_graph_mode(self):
         """drop the captures and continue eagerly (p.grad no longer aliases a flat capture buffer)"""
@@ -383,6 +403,10 @@ class Runner:
         if "lr" in st:
             for g in self.optimizer.param_groups:
                 g["lr"] = float(st["lr"])
+            if self.scheduler is not None:
+                # one saved rate cannot restore per-group rates (base_lr_pg multipliers): recompute every group's
+                # rate from the schedule at the restored position, as the next step would
+                self.scheduler.step(max(self.iter - 1, 0), self.epoch, by_epoch=True)
         params = dict(self.model.named_parameters())
         with torch.no_grad():
             for n, arr in (st.get("momentum_buffer") or {}).items():
