@@ -131,3 +131,143 @@ def integer_offsets(dy, dx, B, Ho, Wo):
             off[:, 2 * (ky * kw + kx)] = dy[ky, kx]
             off[:, 2 * (ky * kw + kx) + 1] = dx[ky, kx]
     return off
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Pins the affine map cannot give.  On f = a x + b y + d the pooled value does not depend on where the samples of a
+# bin sit, on their number or on the divisor; on a QUADRATIC map it does: bilinear interpolation of (x - x0)^2 between
+# integer abscissae i, i + 1 at fraction t returns (x - x0)^2 + t (1 - t), so the expected pooled value is
+#     mean over the bin's samples of  F(x, y) + p tx (1 - tx) + q ty (1 - ty),      F = p (x-x0)^2 + q (y-y0)^2 + affine
+# with the sample positions (x, y), the sampling grid and the divisor written here from the dialect definitions:
+# grid = sample_num > 0 ? sample_num : ceil(roi_size / pooled_size)  (roi_align_rotated.py:L92-97, _v1.py:L104-109,
+# roi_align.py:L119-124), sample (iy, ix) of bin (ph, pw) at start + ph*bin + (iy + .5)*bin/grid (L108-116), divisor
+# grid_h*grid_w (L104).
+# ---------------------------------------------------------------------------------------------------------------
+def quadratic_map(rng, N, C, H, W):
+    """(N,C,H,W) map p (x-x0)^2 + q (y-y0)^2 + a x + b y + d, dyadic coefficients, exact in fp32."""
+    x0, y0 = W // 2, H // 2
+    p = rng.choice([-1.0, -0.5, -0.25, 0.25, 0.5, 1.0], size=(N, C))
+    q = rng.choice([-1.0, -0.5, -0.25, 0.25, 0.5, 1.0], size=(N, C))
+    a = rng.integers(-8, 9, size=(N, C)).astype(np.float64) / 8.0
+    b = rng.integers(-8, 9, size=(N, C)).astype(np.float64) / 8.0
+    d = rng.integers(-16, 17, size=(N, C)).astype(np.float64) / 4.0
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    e = lambda v: v[:, :, None, None]
+    f = e(p) * (xs - x0) ** 2 + e(q) * (ys - y0) ** 2 + e(a) * xs + e(b) * ys + e(d)
+    assert np.array_equal(f.astype(np.float32).astype(np.float64), f)
+    return f.astype(np.float32), (p, q, a, b, d, x0, y0)
+
+
+def roi_frame(variant, roi, scale):
+    """(origin_x, origin_y, roi_w, roi_h, cos, sin, start_x, start_y) of one RoI row, from the dialect definitions"""
+    roi = [float(v) for v in roi]
+    if variant in (V_HBB0, V_HBB1):
+        x1, y1, x2, y2 = roi[1:5]
+        sw, sh = x1 * scale, y1 * scale
+        if variant == V_HBB1:
+            rw, rh = max((x2 + 1) * scale - sw, 0.0), max((y2 + 1) * scale - sh, 0.0)
+        else:
+            rw, rh = max(x2 * scale - sw, 1.0), max(y2 * scale - sh, 1.0)
+        return 0.0, 0.0, rw, rh, 1.0, 0.0, sw, sh
+    xc, yc, w, h, th = roi[1:6]
+    cx, cy = xc * scale, yc * scale
+    if variant == V_ROT_V1:
+        cx, cy = cx - 0.5, cy - 0.5
+    rw, rh = max(w * scale, 1.0), max(h * scale, 1.0)
+    return cx, cy, rw, rh, math.cos(th), math.sin(th), -rw / 2, -rh / 2
+
+
+def sample_positions(variant, roi, scale, PH, PW, sample_num):
+    """X, Y of shape (PH, PW, gh, gw): map coordinates of every sample of every bin; and the divisor."""
+    cx, cy, rw, rh, c, s, sx, sy = roi_frame(variant, roi, scale)
+    gh = sample_num if sample_num > 0 else int(math.ceil(rh / PH))
+    gw = sample_num if sample_num > 0 else int(math.ceil(rw / PW))
+    bh, bw = rh / PH, rw / PW
+    ph = np.arange(PH)[:, None, None, None]
+    pw = np.arange(PW)[None, :, None, None]
+    iy = np.arange(gh)[None, None, :, None]
+    ix = np.arange(gw)[None, None, None, :]
+    yy = sy + ph * bh + (iy + 0.5) * bh / gh + 0 * (pw + ix)
+    xx = sx + pw * bw + (ix + 0.5) * bw / gw + 0 * (ph + iy)
+    if variant in (V_HBB0, V_HBB1):
+        return xx, yy, gh * gw
+    if variant == V_ROT_V1:
+        return xx * c + yy * s + cx, yy * c - xx * s + cy, gh * gw
+    return xx * c - yy * s + cx, xx * s + yy * c + cy, gh * gw
+
+
+def roi_align_expected_quadratic(variant, coefs, rois, scale, PH, PW, sample_num, n_orient=1):
+    """(R, C, PH, PW) float64 expectation on quadratic_map() for RoIs whose samples all stay in [1, W-2] x [1, H-2]."""
+    p, q, a, b, d, x0, y0 = coefs
+    R, C = rois.shape[0], p.shape[1]
+    out = np.zeros((R, C, PH, PW))
+    e = lambda v, n: v[n][:, None, None, None, None]
+    for r in range(R):
+        n = int(rois[r, 0])
+        X, Y, count = sample_positions(variant if variant != V_RI else V_ROT, rois[r], scale, PH, PW, sample_num)
+        tx, ty = X - np.floor(X), Y - np.floor(Y)
+        F = (e(p, n) * ((X - x0) ** 2 + tx * (1 - tx)) + e(q, n) * ((Y - y0) ** 2 + ty * (1 - ty))
+             + e(a, n) * X + e(b, n) * Y + e(d, n))
+        F = F.sum(axis=(3, 4)) / count                        # (C, PH, PW)
+        if variant != V_RI:
+            out[r] = F
+            continue
+        nO = n_orient
+        th = float(np.float32(rois[r, 5]))
+        ind_f = float(np.float32(np.float64(np.float32(th * nO)) / (2 * RI_PI)))
+        ind = math.floor(ind_f)
+        l = ind_f - ind
+        rr = 1.0 - l
+        ind = (ind + nO) % nO
+        Fc = F.reshape(C // nO, nO, PH, PW)
+        o = np.arange(nO)
+        i0 = (o - ind + nO) % nO
+        i1 = (i0 + 1 + nO) % nO
+        out[r] = (rr * Fc[:, i0] + l * Fc[:, i1]).reshape(C, PH, PW)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Boundary literals: a 3x3 one-channel map v[y][x] = 1 + 3 y + x, scale 1, ONE bin, ONE sample at (sx, sy) unless
+# stated.  Expected values derived by hand from the bilinear routine of the reference (roi_align_rotated.py:L21-59,
+# identical in the other dialects): a coordinate below -1 or above the extent contributes 0 (L26) -- but the divisor
+# stays --, a coordinate in [-1, 0] is moved to 0 (L29-32), floor >= extent-1 pins both corners to the last pixel
+# (L35-46).
+# ---------------------------------------------------------------------------------------------------------------
+BOUNDARY_MAP = (1.0 + 3.0 * np.arange(3)[:, None] + np.arange(3)[None, :]).astype(np.float32).reshape(1, 1, 3, 3)
+
+# (sample x, sample y, expected value)
+BOUNDARY_POINTS = [
+    (1.0, 1.0, 5.0),                 # a pixel centre
+    (0.5, 0.5, 3.0),                 # (1 + 2 + 4 + 5) / 4
+    (1.25, 0.0, 2.25),               # top row, 2 + 0.25
+    (-0.5, 1.0, 4.0),                # x in [-1, 0] -> x = 0: v[1][0]
+    (-1.0, 1.0, 4.0),                # x = -1 is not below -1: still valid, moved to 0
+    (-1.5, 1.0, 0.0),                # x < -1: the sample is dropped
+    (2.5, 1.0, 6.0),                 # floor(x) = 2 >= W - 1: both corners = last column: v[1][2]
+    (3.0, 1.0, 6.0),                 # x = W is not above W: valid, pinned to the last column
+    (3.5, 1.0, 0.0),                 # x > W: dropped
+    (1.0, -0.75, 2.0),               # y in [-1, 0] -> y = 0: v[0][1]
+    (1.0, 2.75, 8.0),                # last row: v[2][1]
+    (1.0, 3.25, 0.0),                # y > H: dropped
+    (2.0, 2.0, 9.0),                 # the last pixel itself
+    (-0.25, -0.25, 1.0),             # both moved to 0: v[0][0]
+]
+
+
+def boundary_roi(variant, sx, sy, w=1.0, h=1.0):
+    """the RoI row (scale 1) whose single sample (one 1x1 bin, sampling 1) sits at map position (sx, sy)"""
+    if variant in (V_HBB0, V_HBB1):
+        # v0: extent max(x2 - x1, 1); v1: (x2 + 1) - x1.  Sample at x1 + extent / 2.
+        ext_w, ext_h = w, h
+        x1, y1 = sx - ext_w / 2, sy - ext_h / 2
+        if variant == V_HBB1:
+            return [0.0, x1, y1, x1 + ext_w - 1.0, y1 + ext_h - 1.0]
+        return [0.0, x1, y1, x1 + ext_w, y1 + ext_h]
+    shift = 0.5 if variant == V_ROT_V1 else 0.0
+    return [0.0, sx + shift, sy + shift, w, h, 0.0]
+
+
+# a 2x2-sample bin straddling the left border: RoI 2x2 centred at (-1, 1): samples x in {-1.5, -0.5}, y in {0.5, 1.5};
+# x = -1.5 is dropped, x = -0.5 moves to column 0: (1 + 4)/2 + (4 + 7)/2 = 8, divisor 4 -> 2.0
+BOUNDARY_STRADDLE = (-1.0, 1.0, 2.0, 2.0, 2.0)   # (centre x, centre y, w, h, expected)

@@ -77,3 +77,94 @@ def test_deform_conv_integer_offsets(dev, k, pad, stride, dil, cl):
     y = conv(xt, torch.from_numpy(off).to(dev))
     ref = CF.deform_conv_integer_expected(x, conv.weight.detach().cpu().numpy(), dy, dx, pad, stride, dil)
     np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+# ---- pins the affine map cannot give: sample positions, sampling grid, divisor, boundary rules ----
+@pytest.mark.parametrize("variant", [V_ROT, V_ROT_V1, V_HBB0, V_HBB1, V_RI])
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 1), ((4, 4), 0), ((2, 3), 3)])
+def test_roi_align_on_quadratic_map(dev, path, variant, hw, s):
+    """the pooled value of a quadratic map depends on every sample position, the sampling grid (fixed and adaptive) and
+    the divisor; expectation written from the dialect definitions (tests/closed_form.py), no oracle involved"""
+    rng = np.random.default_rng(5 + variant)
+    N, C, H, W, scale, nO = 2, 16, 48, 56, 0.25, 8
+    feat, co = CF.quadratic_map(rng, N, C, H, W)
+    rois = CF.interior_rois(rng, 40, N, H, W, scale, variant, max_wh=18.0)
+    x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
+    y = _layer(variant, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
+    ref = CF.roi_align_expected_quadratic(variant, co, rois, scale, hw[0], hw[1], s, nO)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=1e-3)    # |f| up to ~900: 1e-6 relative
+
+
+@pytest.mark.parametrize("variant", [V_ROT, V_ROT_V1, V_HBB0, V_HBB1])
+def test_roi_align_boundary_literals(dev, path, variant):
+    """hand-derived values on a 3x3 map (roi_align_rotated.py:L21-59): samples below -1 / above the extent are dropped
+    but still counted in the divisor, coordinates in [-1, 0] move to 0, the last pixel pins both corners"""
+    x = torch.from_numpy(CF.BOUNDARY_MAP).to(dev)
+    rois = np.asarray([CF.boundary_roi(variant, sx, sy) for sx, sy, _ in CF.BOUNDARY_POINTS], np.float32)
+    y = _layer(variant, (1, 1), 1.0, 1)(x, torch.from_numpy(rois).to(dev)).cpu().numpy().ravel()
+    np.testing.assert_allclose(y, [e for _, _, e in CF.BOUNDARY_POINTS], rtol=0, atol=1e-6)
+    cx, cy, w, h, exp = CF.BOUNDARY_STRADDLE
+    roi = torch.from_numpy(np.asarray([CF.boundary_roi(variant, cx, cy, w, h)], np.float32)).to(dev)
+    assert float(_layer(variant, (1, 1), 1.0, 2)(x, roi).cpu().ravel()[0]) == pytest.approx(exp, abs=1e-6)
+
+
+@pytest.mark.parametrize("variant", [V_ROT, V_ROT_V1, V_HBB0, V_HBB1, V_RI])
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 0)])
+@pytest.mark.parametrize("grad_cl", [False, True])
+def test_roi_align_backward_is_the_adjoint(dev, path, variant, hw, s, grad_cl):
+    """<forward(x), g> == <x, backward(g)> on the device: every backward route (sorted gather for the channels-last
+    gradient, transposing entry point, atomics for adaptive sampling, RiRoI's mixed rows) against the forward kernels
+    the closed forms pin; RoIs include the boundary cases"""
+    from tests import inputs as I
+    rng = np.random.default_rng(40 + variant)
+    N, C, H, W, scale, nO = 2, 8, 20, 24, 0.5, 4
+    xn = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    obbs = I.random_obbs(rng, 30, extent=W / scale, wh=(2.0, 40.0))
+    rois = np.concatenate([I.rois_from_obbs(obbs, rng.integers(0, N, 30)), I.edge_rois(H, W, scale)], 0)
+    if variant in (V_HBB0, V_HBB1):
+        rois = I.obb_to_hbb_rois(rois)
+    x = torch.from_numpy(xn).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = _layer(variant, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
+    g = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+    if grad_cl:
+        g = g.contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    lhs = float((y.detach().double() * g.double()).sum())
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=2e-5, abs=1e-3)
+
+
+@pytest.mark.parametrize("k,pad,stride,dil,dg", [(3, 1, 1, 1, 1), (3, 2, 2, 2, 2), (1, 0, 1, 1, 1)])
+@pytest.mark.parametrize("cl", [False, True])
+def test_deform_conv_gradients_are_adjoint_and_derivative(dev, k, pad, stride, dil, dg, cl):
+    """dcn_v1.py:L185-306 on the device: the input gradient is the adjoint of the (integer-offset-pinned) forward; the
+    offset gradient equals central differences of the forward (offsets drawn away from integer sample positions:
+    bilinear sampling is linear inside a cell, the difference quotient is exact up to fp32 rounding)"""
+    from jdet_amd.ops.dcn_v1 import DeformConv
+    rng = np.random.default_rng(7 * k + pad)
+    B, C, Cout, H, W = 2, 4 * dg, 6, 9, 11
+    conv = DeformConv(C, Cout, k, stride=stride, padding=pad, dilation=dil, deformable_groups=dg).to(dev)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    offn = (rng.integers(-2, 3, size=(B, dg * 2 * k * k, Ho, Wo)) + rng.uniform(0.2, 0.8, size=(B, dg * 2 * k * k, Ho, Wo))
+            ).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32)).to(dev)
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    off = torch.from_numpy(offn).to(dev).requires_grad_(True)
+    y = conv(x, off)
+    g = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dev)
+    y.backward(g)
+    # linear in x with the bias-free module: <y, g> == <x, grad_x>
+    lhs, rhs = float((y.detach().double() * g.double()).sum()), float((x.detach().double() * x.grad.double()).sum())
+    assert lhs == pytest.approx(rhs, rel=5e-5, abs=1e-3)
+    eps = 1.0 / 64
+    with torch.no_grad():
+        for _ in range(24):
+            i = tuple(int(rng.integers(0, n)) for n in offn.shape)
+            op, om = off.detach().clone(), off.detach().clone()
+            op[i] += eps
+            om[i] -= eps
+            fd = float(((conv(x.detach(), op).double() - conv(x.detach(), om).double()) * g.double()).sum()) / (2 * eps)
+            assert float(off.grad[i]) == pytest.approx(fd, rel=5e-3, abs=5e-3), i

@@ -79,10 +79,10 @@ def test_cfg3_oriented_rcnn_train_1024(dev):
 
 
 def test_cfg4_roi_transformer_r101_train_1024(dev):
-    """configs[4]: RoI-Transformer with Resnet101 (3-4-23-3), 1024 x 1024 tiles; 2 tiles here (the 8-GPU config has
-    4 per GPU: same shapes, twice the batch)"""
+    """configs[4]: RoI-Transformer with Resnet101 (3-4-23-3), 1024 x 1024 tiles, batch 32 over 8 GPUs = 4 tiles per
+    GPU -- the per-GPU batch of the config"""
     from jdet_amd.config.named import roitrans_train_cfg
-    r = _train_two_steps(roitrans_train_cfg("Resnet101"), dev, 2,
+    r = _train_two_steps(roitrans_train_cfg("Resnet101"), dev, 4,
                          {"loss_rpn_cls", "loss_rpn_bbox", "s0.rbbox_loss_cls", "s0.rbbox_loss_bbox",
                           "s1.rbbox_loss_cls", "s1.rbbox_loss_bbox"})
     assert len(r.model.backbone.layer3) == 23
