@@ -135,3 +135,50 @@ def s2anet_get_bboxes_single(odm_cls, odm_box, refine_anchors, score_thr=0.05, i
     mb[:, :4] /= scale_factor
     ms = np.concatenate([np.zeros((ms.shape[0], 1), np.float32), ms], 1)
     return multiclass_nms_rotated(mb.astype(np.float32), ms, score_thr, iou_thr, max_per_img, cmp_ge)
+
+
+def hbb_nms(boxes, scores, thr):
+    """`jt.nms(dets (n,5), thr)` as SURVEY 8c restates it (Jittor-internal, unpinned): greedy in descending score order
+    (stable), suppress at IoU > thr, areas without the +1 px convention; returns the kept indices in score order."""
+    order = np.argsort(-scores, kind="stable")
+    b = boxes.astype(np.float64)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    dead = np.zeros(len(b), bool)
+    keep = []
+    for i in order:
+        if dead[i]:
+            continue
+        keep.append(i)
+        iw = np.clip(np.minimum(b[i, 2], b[:, 2]) - np.maximum(b[i, 0], b[:, 0]), 0, None)
+        ih = np.clip(np.minimum(b[i, 3], b[:, 3]) - np.maximum(b[i, 1], b[:, 1]), 0, None)
+        inter = iw * ih
+        iou = inter / np.maximum(area[i] + area - inter, 1e-300)
+        dead |= iou > thr
+    return np.asarray(keep, np.int64)
+
+
+def oriented_rpn_proposals_single(cls_scores, bbox_preds, mlvl_anchors, nms_pre=2000, nms_post=2000, nms_thresh=0.8,
+                                  min_bbox_size=0, means=(0.,) * 6, stds=(1., 1., 1., 1., 0.5, 0.5)):
+    """models/roi_heads/oriented_rpn_head.py:L128-226 for one image.  cls_scores: list over levels of (A, H, W);
+    bbox_preds: (A*6, H, W); mlvl_anchors: (H*W*A, 4) in grid order.  Returns (k, 6) [obb, score], best first."""
+    sc, dl, an, ids = [], [], [], []
+    for idx, (cls, reg, anchors) in enumerate(zip(cls_scores, bbox_preds, mlvl_anchors)):
+        s = 1.0 / (1.0 + np.exp(-np.transpose(cls, (1, 2, 0)).reshape(-1).astype(np.float64)))      # L167-169
+        d = np.transpose(reg, (1, 2, 0)).reshape(-1, 6)                                                 # L177
+        if 0 < nms_pre < s.shape[0]:                                                                    # L180-187
+            top = np.argsort(-s, kind="stable")[:nms_pre]
+            s, d, anchors = s[top], d[top], anchors[top]
+        sc.append(s.astype(np.float32))
+        dl.append(d)
+        an.append(anchors)
+        ids.append(np.full(s.shape[0], idx, np.int64))
+    sc, dl, an, ids = np.concatenate(sc), np.concatenate(dl), np.concatenate(an), np.concatenate(ids)
+    prop = B.midpoint_offset_decode(an, dl, means, stds)                                               # L198
+    if min_bbox_size >= 0:                                                                              # L201-207
+        ok = (prop[:, 2] > min_bbox_size) & (prop[:, 3] > min_bbox_size)
+        prop, sc, ids = prop[ok], sc[ok], ids[ok]
+    h = B.obb2hbb(prop).astype(np.float64)                                                              # L209-212
+    h = h + (ids.astype(np.float64) * (h.max() - h.min() + 1))[:, None]
+    keep = hbb_nms(h, sc, nms_thresh)                                                                   # L214-215
+    dets = np.concatenate([prop, sc[:, None]], 1)[keep]
+    return dets[:nms_post]

@@ -97,3 +97,35 @@ def test_s2anet_head_get_bboxes_vs_restatement(dev):
         np.testing.assert_allclose(scores, es, rtol=1e-5, atol=1e-6)
         assert np.array_equal(labels.astype(np.int64), el.astype(np.int64))
         np.testing.assert_allclose(_corner_sets(polys), _corner_sets(_rect_corners(eb)), rtol=0, atol=2e-3)
+
+
+def test_oriented_rpn_proposals_vs_restatement(dev):
+    """OrientedRPNHead.get_bboxes on fixed head outputs: per-level top-k, midpoint-offset decode, per-level horizontal
+    NMS, best nms_post overall (oriented_rpn_head.py:L128-226) -- the fixed-shape proposal table's valid rows must be
+    the restatement's proposals, in order"""
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.models.roi_heads.oriented_rpn_head import INVALID_SCORE, OrientedRPNHead
+    rng = np.random.default_rng(33)
+    N, size = 2, 256
+    head = OrientedRPNHead(in_channels=256, nms_pre=300, nms_post=200, nms_thresh=0.8).to(dev).eval()
+    strides = [4, 8, 16, 32, 64]
+    sizes = [(size // s, size // s) for s in strides]
+    A = head.num_anchors
+    cls = [rng.normal(-1.0, 2.0, size=(N, A) + sz).astype(np.float32) for sz in sizes]
+    reg = [rng.normal(0, 0.25, size=(N, A * 6) + sz).astype(np.float32) for sz in sizes]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    targets = [dict(img_size=(size, size), pad_shape=(size, size)) for _ in range(N)]
+    with torch.no_grad():
+        tables = head.get_bboxes([t(a) for a in cls], [t(a) for a in reg], targets)
+        anchors = [a.cpu().numpy() for a in head.anchor_generator.grid_anchors(sizes, device=dev)]
+    for i in range(N):
+        tab = tables[i].cpu().numpy()
+        assert tab.shape == (200, 6)
+        valid = tab[:, 5] > INVALID_SCORE
+        ref = HO.oriented_rpn_proposals_single([c[i] for c in cls], [r[i] for r in reg], anchors, nms_pre=300,
+                                               nms_post=200, nms_thresh=0.8)
+        assert valid.sum() == len(ref) > 50
+        assert np.all(valid[:len(ref)])                      # valid rows first, padding after
+        np.testing.assert_allclose(tab[:len(ref), 5], ref[:, 5], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(tab[:len(ref), :4], ref[:, :4], rtol=1e-5, atol=2e-3)
+        np.testing.assert_allclose(np.cos(2 * tab[:len(ref), 4]), np.cos(2 * ref[:, 4]), rtol=0, atol=1e-4)
