@@ -218,8 +218,7 @@ class Runner:
         st["lr"].fill_(float(self.optimizer.param_groups[0]["lr"]))
         st["g1"].replay()
         if self.world_size > 1:
-            dist.all_reduce(st["flat"])
-            st["flat"].div_(self.world_size)
+            self._allreduce_flat(st["flat"])
             st["g2"].replay()
         if self.scheduler is not None:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
@@ -257,6 +256,19 @@ class Runner:
         self.iter += 1
         return all_loss.detach(), {k: v.detach() for k, v in losses.items()}
 
+    def _allreduce_flat(self, flat):
+        """mean over ranks, in place.  RCCL orders the collective on the current stream.  The gloo backend (CPU tests, the
+        two-ranks-on-one-GPU test) would stage a device tensor through pinned host memory on streams of its own; that
+        path gave intermittently different results on the two ranks here (tests/test_gpu_ddp_detectors.py, graph mode,
+        ~1 run in 4), so for gloo the staging is done here, synchronously"""
+        if flat.is_cuda and dist.get_backend() == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat)
+        flat.div_(self.world_size)
+
     @staticmethod
     def _flat_order(p, t):
         """`t` (shaped like parameter p) in the element order `_flat_grads` gives p's segment of the flat buffer:
@@ -274,8 +286,7 @@ class Runner:
             return
         flat = torch.cat([(self._flat_order(p, p.grad).reshape(-1) if p.grad is not None
                            else torch.zeros(p.numel(), dtype=torch.float32, device=p.device)) for p in params])
-        dist.all_reduce(flat)
-        flat.div_(self.world_size)
+        self._allreduce_flat(flat)
         off = 0
         for p in params:
             n = p.numel()
