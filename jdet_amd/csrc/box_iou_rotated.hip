@@ -320,6 +320,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   if (lane == 0) atomicMax(&tile_jmax[row_blk], col_blk);
   __shared__ float s_x[24 * 64];
   __shared__ float s_y[24 * 64];
+  __shared__ float s_row[64 * 6];                  // the tile's row boxes (lane i staged row i)
+  __shared__ float s_col[64 * 6];
+  __shared__ unsigned short s_pair[64 * 64];       // candidate pairs (row << 6 | column), rotated boxes only
+  __shared__ unsigned long long s_word[64];
   LanePts<64> q;
   q.x = s_x + lane;
   q.y = s_y + lane;
@@ -334,33 +338,88 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     if (box_len == 6) cb[5] = p[5];
   }
   const int rows = min(64, n - row_blk * 64);
+  {
+    float rb[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < rows) {
+      const float* p = dets + (size_t)order[row_blk * 64 + lane] * box_len;
+#pragma unroll
+      for (int k = 0; k < 5; k++) rb[k] = p[k];
+      if (box_len == 6) rb[5] = p[5];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      s_row[lane * 6 + k] = rb[k];
+      s_col[lane * 6 + k] = cb[k];
+    }
+    s_word[lane] = 0ull;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (HBB) {
+    for (int i = 0; i < rows; i++) {
+      const int row = row_blk * 64 + i;
+      float rb[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) rb[k] = s_row[i * 6 + k];   // same address in every lane: broadcast
+      bool hit = false;
+      if (col_ok && col > row && !(box_len == 6 && rb[5] != cb[5])) {
+        const float iw = fminf(rb[0] + 0.5f * rb[2], cb[0] + 0.5f * cb[2]) - fmaxf(rb[0] - 0.5f * rb[2], cb[0] - 0.5f * cb[2]);
+        const float ih = fminf(rb[1] + 0.5f * rb[3], cb[1] + 0.5f * cb[3]) - fmaxf(rb[1] - 0.5f * rb[3], cb[1] - 0.5f * cb[3]);
+        const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+        const float uni = rb[2] * rb[3] + cb[2] * cb[3] - inter;
+        const float ovr = uni > 0.f ? inter / uni : 0.f;
+        hit = cmp_ge ? (ovr >= thr) : (ovr > thr);
+      }
+      const unsigned long long word = __ballot(hit);
+      if (lane == 0 && word) mask[(size_t)row * col_blocks + col_blk] = word;
+    }
+    return;
+  }
+  // Rotated boxes, two phases.  The polygon clipping costs thousands of instructions and only pairs whose
+  // circumscribed circles meet need it: running it inside the row loop left most lanes of most iterations idle while
+  // one pair was being clipped (355 us for 2000 boxes, 4x the per-pair time of box_iou_kernel).
+  //   1. every (row, column) pair of the tile that is in order, of one label (ml_nms: different labels -> IoU 0,
+  //      nms_rotated.py:L283-286) and not surely disjoint is appended to a list (one cheap pass, lane = column);
+  //   2. the list is clipped 64 pairs at a time, one pair per lane, and the hits OR-ed into the rows' words.
+  // Same pairs, same function, same bits as before.  A threshold that an IoU of exactly 0 passes makes EVERY pair a
+  // hit: then the disjoint ones have to stay in the list.
+  const bool zero_hits = cmp_ge ? !(thr > 0.f) : (thr < 0.f);
+  int total = 0;
   for (int i = 0; i < rows; i++) {
     const int row = row_blk * 64 + i;
-    const float* p = dets + (size_t)order[row] * box_len;  // wave-uniform -> scalar loads
     float rb[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) rb[k] = p[k];
-    rb[5] = box_len == 6 ? p[5] : 0.f;
-    bool hit = false;
-    if (col_ok && col > row) {
-      // ml_nms: different labels -> IoU 0 (nms_rotated.py:L283-286); argument order is
-      // (earlier, later) as in the CPU loop L443
-      float ovr = 0.f;
-      if (!(box_len == 6 && rb[5] != cb[5])) {
-        if (HBB) {
-          const float iw = fminf(rb[0] + 0.5f * rb[2], cb[0] + 0.5f * cb[2]) - fmaxf(rb[0] - 0.5f * rb[2], cb[0] - 0.5f * cb[2]);
-          const float ih = fminf(rb[1] + 0.5f * rb[3], cb[1] + 0.5f * cb[3]) - fmaxf(rb[1] - 0.5f * rb[3], cb[1] - 0.5f * cb[3]);
-          const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
-          const float uni = rb[2] * rb[3] + cb[2] * cb[3] - inter;
-          ovr = uni > 0.f ? inter / uni : 0.f;
-        } else {
-          ovr = iou_dispatch<64>(rb, cb, 0, sort_mode, q);
-        }
+    for (int k = 0; k < 6; k++) rb[k] = s_row[i * 6 + k];
+    const bool cand = col_ok && col > row && !(box_len == 6 && rb[5] != cb[5]) &&
+                      (zero_hits || !surely_disjoint(rb, cb));
+    const unsigned long long word = __ballot(cand);
+    if (cand) s_pair[total + __builtin_amdgcn_mbcnt_hi((unsigned)(word >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)word, 0))] =
+        (unsigned short)((i << 6) | lane);
+    total += __popcll(word);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < total) {
+      const int pr = s_pair[t];
+      const int i = pr >> 6, j = pr & 63;
+      float rb[5], b2[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        rb[k] = s_row[i * 6 + k];
+        b2[k] = s_col[j * 6 + k];
       }
-      hit = cmp_ge ? (ovr >= thr) : (ovr > thr);
+      // argument order (earlier, later) as in the CPU loop L443
+      const float ovr = iou_dispatch<64>(rb, b2, 0, sort_mode, q);
+      if (cmp_ge ? (ovr >= thr) : (ovr > thr)) atomicOr(&s_word[i], 1ull << j);
     }
-    const unsigned long long word = __ballot(hit);
-    if (lane == 0 && word) mask[(size_t)row * col_blocks + col_blk] = word;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < rows) {
+    const unsigned long long word = s_word[lane];
+    if (word) mask[(size_t)(row_blk * 64 + lane) * col_blocks + col_blk] = word;
   }
 }
 

@@ -48,20 +48,49 @@ static __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsig
   const int c_lo = seg_lo >> 6, c_hi = (seg_hi + 63) >> 6;
   for (int j = c_lo + threadIdx.x; j < col_blocks; j += kScanBlock) s_remv[j] = 0ull;
   __syncthreads();
+  // The rows a block contributes depend on which of its boxes survive, but WHICH words can be needed does not: all
+  // 64 rows x (columns c+1 .. jmax) of block c+1 are fetched into registers while block c is being resolved, so the
+  // scan's critical path holds no global-memory round trip (it had two per block: 142 us for 2000 boxes).  Blocks too
+  // wide for 8 words per thread keep the fetch-after-resolve path.
+  __shared__ unsigned long long s_keepbits;
+  constexpr int kPre = 8;
+  auto block_cols = [&](int c) { return max(min(tile_jmax[c], c_hi - 1) - c, 0); };
+  auto fetch = [&](int c, unsigned long long (&w)[kPre], unsigned long long& diag) {
+    const int ncols = block_cols(c), items = 64 * ncols, rows = min(64, n - c * 64);
+    diag = 0ull;
+    if (wave == 0) {
+      const int row = c * 64 + lane;
+      if (row >= seg_lo && row < seg_hi) diag = mask[(size_t)row * col_blocks + c];
+    }
+#pragma unroll
+    for (int u = 0; u < kPre; u++) {
+      const int it = threadIdx.x + u * kScanBlock;
+      w[u] = 0ull;
+      if (items <= kPre * kScanBlock && it < items) {
+        const int ri = it / ncols;
+        if (ri < rows) w[u] = mask[(size_t)(c * 64 + ri) * col_blocks + c + 1 + (it - ri * ncols)];
+      }
+    }
+  };
+  unsigned long long cur[kPre], nxt[kPre], dcur, dnxt = 0ull;
+  fetch(c_lo, cur, dcur);
   for (int c = c_lo; c < c_hi; c++) {
-    const int rows = min(64, n - c * 64);
+    if (c + 1 < c_hi) fetch(c + 1, nxt, dnxt);
     if (wave == 0) {
       // diagonal tile: lane = row; resolve the within-tile greedy dependency with readlanes
       const int row = c * 64 + lane;
       const bool own = row >= seg_lo && row < seg_hi;
-      unsigned long long d = 0ull;
-      if (own) d = mask[(size_t)row * col_blocks + c];
+      const unsigned long long d = dcur;
       unsigned long long removed = s_remv[c];
       unsigned long long keepbits = 0ull;
       const unsigned long long ownbits = __ballot(own);
       const unsigned int dlo = (unsigned int)d, dhi = (unsigned int)(d >> 32);
-      for (int i = 0; i < rows; i++) {
-        if (((ownbits >> i) & 1ull) && !((removed >> i) & 1ull)) {
+      // fully unrolled: row index and readlane lane are immediates, a suppressed row costs a bit test and a branch
+      // (the rolled loop spent ~20 scalar instructions per row on 64-bit shifts: 3 us of a lone wave per block);
+      // rows past the end / of other labels have their `own` bit clear
+#pragma unroll
+      for (int i = 0; i < 64; i++) {
+        if (((ownbits & ~removed) >> i) & 1ull) {
           keepbits |= 1ull << i;
           const unsigned long long di =
               ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
@@ -72,31 +101,48 @@ static __global__ __launch_bounds__(kScanBlock) void nms_scan_kernel(const unsig
       const bool mine = (keepbits >> lane) & 1ull;
       if (own) keep[order[row]] = (uint8_t)mine;
       if (mine) s_rows[__popcll(keepbits & ((1ull << lane) - 1ull))] = lane;   // k-th kept row of the block
-      if (lane == 0) s_nkept = __popcll(keepbits);
+      if (lane == 0) {
+        s_nkept = __popcll(keepbits);
+        s_keepbits = keepbits;
+      }
     }
     __syncthreads();
-    const int jmax = min(tile_jmax[c], c_hi - 1);   // later labels' columns hold no bit of these rows
-    const int ncols = max(jmax - c, 0);             // column blocks c+1 .. jmax
-    const int items = s_nkept * ncols;
-    for (int it0 = threadIdx.x; it0 < items; it0 += kScanBlock * 8) {
-      unsigned long long w[8];
-      int jj[8];
+    const int ncols = block_cols(c);                // column blocks c+1 .. jmax (later labels' columns hold no bit)
+    if (64 * ncols <= kPre * kScanBlock) {
+      const unsigned long long kb = s_keepbits;
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int it = it0 + u * kScanBlock;
-        w[u] = 0ull;
-        jj[u] = 0;
-        if (it < items) {
+      for (int u = 0; u < kPre; u++) {
+        const int it = threadIdx.x + u * kScanBlock;
+        if (cur[u]) {   // (non-zero only for it < 64 * ncols)
           const int ri = it / ncols;
-          jj[u] = c + 1 + (it - ri * ncols);
-          w[u] = mask[(size_t)(c * 64 + s_rows[ri]) * col_blocks + jj[u]];
+          if ((kb >> ri) & 1ull) atomicOr(&s_remv[c + 1 + (it - ri * ncols)], cur[u]);
         }
       }
+    } else {
+      const int items = s_nkept * ncols;
+      for (int it0 = threadIdx.x; it0 < items; it0 += kScanBlock * 8) {
+        unsigned long long w[8];
+        int jj[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (w[u]) atomicOr(&s_remv[jj[u]], w[u]);
+        for (int u = 0; u < 8; u++) {
+          const int it = it0 + u * kScanBlock;
+          w[u] = 0ull;
+          jj[u] = 0;
+          if (it < items) {
+            const int ri = it / ncols;
+            jj[u] = c + 1 + (it - ri * ncols);
+            w[u] = mask[(size_t)(c * 64 + s_rows[ri]) * col_blocks + jj[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (w[u]) atomicOr(&s_remv[jj[u]], w[u]);
+      }
     }
     __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPre; u++) cur[u] = nxt[u];
+    dcur = dnxt;
   }
 }
 
