@@ -1,21 +1,12 @@
-#!/bin/bash
-# usage: gpu_pmc.sh "<pmc counters>" "ENV=.." ["ENV=.." ...] -- per-kernel counter averages of the roi_align_rotated bench
-set -u
-OUT=$PWD/gpurun_out/r3_pmc; mkdir -p $OUT
-export TMPDIR=/tmp
-pmc=$1; shift
-i=0
-cd /tmp
-for e in "$@"; do
-  i=$((i+1))
-  env $e timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $OUT/p$i -o t -- python $OLDPWD/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p$i.log 2>&1
-  python - <<PY
-import csv,glob,collections
-for f in sorted(glob.glob("$OUT/p$i/**/*counter_collection.csv",recursive=True)):
-    d=collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        d[r["Kernel_Name"].split("::")[-1][:24]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in d.items():
-        if "roi_" in k: print("[$e]", k, {c: round(sum(x)/len(x)) for c,x in v.items()})
-PY
+# usage: bash scripts/gpu_counters.sh <tag> [bench args...]   -- rocprofv3 kernel trace + separate PMC passes
+tag=$1; shift
+R=$PWD
+mkdir -p $R/gpurun_out/$tag
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/$tag/trace -o t -- python $R/bench.py --no-cpu-baseline --steps 50 --warmup 5 "$@" > $R/gpurun_out/$tag/trace.log 2>&1
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $c -f csv -d $R/gpurun_out/$tag/pmc_$n -o p -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > $R/gpurun_out/$tag/pmc_$n.log 2>&1 || echo "pmc $c failed"
 done
+cd $R
+python scripts/summarize_prof.py gpurun_out/$tag
