@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpu_pmc.sh "<pmc counters>" "ENV=.." ["ENV=.." ...] -- per-kernel counter averages of the roi_align_rotated bench
+# usage: gpu_counters.sh "<pmc counters>" "ENV=.." ["ENV=.." ...] -- per-kernel counter averages of the roi_align_rotated bench
 set -u
 OUT=$PWD/gpurun_out/r3_pmc; mkdir -p $OUT
 export TMPDIR=/tmp

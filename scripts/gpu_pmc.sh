@@ -1,4 +1,4 @@
-# usage: bash scripts/gpu_counters.sh <tag> [bench args...]   -- rocprofv3 kernel trace + separate PMC passes
+# usage: bash scripts/gpu_pmc.sh <tag> [bench args...]   -- rocprofv3 kernel trace + separate PMC passes
 tag=$1; shift
 R=$PWD
 mkdir -p $R/gpurun_out/$tag
