@@ -185,6 +185,20 @@ int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, 
                             int dil_h, int dil_w, float* grad_x_nhwc, void* workspace,
                             size_t workspace_bytes, jdet_stream_t stream);
 
+/* 3x3 / stride 1 / pad 1 convolution as an fp32-MFMA implicit GEMM, channels-last, with the epilogue of the dense
+ * stack fused: replaces nn.Conv(3x3) [+ bias] [+ ReLU] of ConvModule (models/utils/modules.py:L91-175) as the head
+ * towers / FPN output convs / the RPN conv use it, and -- with `offset` non-NULL -- the whole DeformConv forward of
+ * ops/dcn_v1.py:L412-454 (deformable im2col L130-184 + matmul) without a column matrix.
+ * x (N,H,W,Cin); w (Cout,3,3,Cin) [= torch channels_last memory of a (Cout,Cin,3,3) weight]; bias (Cout) or NULL;
+ * rowmask (N*H*W) or NULL multiplies the finished output rows (gap rows of a level pack); offset (N,18,H,W) with
+ * (dy,dx) per tap or NULL; y (N,H,W,Cout); tile = 0 (chosen from the problem size), 64 or 128 (edge of the
+ * workgroup's output tile).  Cin % 16 == 0 and 16-byte aligned x / w, else JDET_E_UNSUPPORTED / JDET_E_BADARG
+ * (query: jdet_conv3x3_igemm_supported).  Products are fp32 in, fp32 accumulate (v_mfma_f32_32x32x2). */
+int jdet_conv3x3_igemm_supported(int Cin, int Cout);
+int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,
+                               const float* bias, int relu, const float* rowmask, const float* offset,
+                               int tile, float* y_nhwc, jdet_stream_t stream);
+
 /* Sigmoid focal loss, replaces the tensor-op chain of models/losses/focal_loss.py:L5-96 (sigmoid_focal_loss with
  * binary_cross_entropy_with_logits): logits (M, C) row-major, labels (M) int32 (0 = background, k = class k),
  * weight (M) or NULL; alpha < 0 disables the alpha term.  *loss_sum = sum over all M*C elements (the caller divides

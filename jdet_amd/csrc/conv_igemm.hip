@@ -1,0 +1,281 @@
+// fp32 MFMA implicit GEMM for the 3x3 / stride 1 / pad 1 convolutions of the dense stack (FPN output convs, the head
+// towers, the RPN conv) and -- with a gathered A operand -- the deformable convolution of AlignConv, channels-last.
+//
+// Reference modules: nn.Conv (+ ReLU) inside ConvModule (python/jdet/models/utils/modules.py:L91-175), the towers of
+// models/roi_heads/s2anet_head.py:L127-205 / rotated_retina_head.py, necks/fpn.py:L150-201; DeformConv =
+// im2col -> matmul, ops/dcn_v1.py:L412-454.
+//
+//   Y[m, n] = sum_{tap, c} A[m, (tap, c)] * Wt[n, (tap, c)]            m = (image, y, x), n = output channel
+//   plain conv : A[m, (tap, c)] = X[pixel(m) + tap, c]   (0 outside the image)
+//   deformable : A[m, (tap, c)] = bilinear sample of X[., c] at pixel(m) + tap + offset[m, tap]  (dcn_v1.py:L132-166)
+//
+// Tiling (one workgroup = 256 threads = 4 waves as 2 x 2, BT x BT outputs with BT = 128 or 64, K step = 16 channels of
+// one tap):
+//   * v_mfma_f32_32x32x2_f32: a wave owns (BT/2)^2 outputs = T x T tiles of 32 x 32 (T = 2: 64 accumulator registers).
+//     The instruction takes ONE f32 of A and of B per lane (lane l: row / column l & 31, k = l >> 5); which two k of
+//     the tile a given instruction consumes is free as long as A and B agree, so lanes 0-31 take k = 8q .. 8q+3 and
+//     lanes 32-63 take k = 8q+4 .. 8q+7 of an 8-wide group: ONE ds_read_b128 per operand tile feeds four MFMAs.
+//   * both operand tiles sit in LDS as [row][16 k] = rows of four 16-byte chunks, chunk c of row r stored at position
+//     c ^ ((r >> 2) & 3): the loader's stores (4 lanes = one row's 64 bytes, 16 rows per instruction) and the fragment
+//     reads (16 consecutive rows, one chunk) both touch every bank once -- no padding, 8 KB per 128-row tile.  The
+//     weight tile [n][k] is the weight tensor's own (Cout, 3, 3, Cin) memory order: no transposition anywhere.
+//   * double-buffered LDS, register-staged: the global loads of K step t+1 are issued before the MFMAs of step t and
+//     stored to the other buffer after them: one barrier per K step.
+//   * workgroup -> tile mapping is XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its
+//     own L2), so XCD x takes the x-th contiguous band of M tiles with the N tiles of one M tile adjacent: the input
+//     rows (incl. the halo shared by neighbouring tiles) of a band stay in one L2.
+//   * epilogue in registers: + bias, ReLU, x per-position mask (the gap rows of a LevelPack), 128-byte row segments.
+// The matrix pipe is the bound: 2 * M * N * K flop at 157 TFLOP/s (fp32-input MFMA = the fp32 vector rate).
+#include "common.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+
+struct ConvArgs {
+  const float* x;        // (N, H, W, Cin)
+  const float* w;        // (Cout, 3, 3, Cin)
+  const float* bias;     // (Cout) or null
+  const float* rowmask;  // (N*H*W) or null: multiplies the finished row (after bias / ReLU)
+  const float* offset;   // deformable: (N, 18, H, W) [per tap (dy, dx), dcn_v1.py:L132-140]; null = plain conv
+  float* y;              // (N, H, W, Cout)
+  int N, H, W, Cin, Cout, relu;
+};
+
+// chunk (4 floats) `chunk` of LDS row `row`: BK = 16 -> 4 chunks, position c ^ ((r >> 2) & 3); BK = 32 -> 8 chunks,
+// position c ^ ((r >> 1) & 7): 16 consecutive rows of one chunk, and the 16 lanes of a store, cover the 64 banks once
+template <int BK>
+__device__ __forceinline__ int swz(int row, int chunk) {
+  return row * BK + ((chunk ^ (BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7)) << 2);
+}
+
+// what a (row, tap) pair reads: plain conv = one pixel (or nothing); deformable = four weighted corners
+struct Tap {
+  int off[4];     // element offset of the corner pixel's channel 0, or -1
+  float wt[4];
+};
+
+template <int BT, int BK, bool DEFORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ? (BK == 32 ? 2 : (DEFORM ? 3 : 4)) : 4))) void conv3x3_igemm_kernel(ConvArgs a) {
+  constexpr int T = BT / 64;             // 32 x 32 tiles per wave and direction
+  constexpr int CH = BK / 4;             // 16-byte chunks per LDS row
+  constexpr int RPP = 256 / CH;          // loader: RPP rows x CH chunks per pass
+  constexpr int PASSES = BT / RPP;
+  constexpr int NC = DEFORM ? 4 : 1;
+  __shared__ __attribute__((aligned(16))) float s_a[2][BT * BK];
+  __shared__ __attribute__((aligned(16))) float s_b[2][BT * BK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long M = (long)a.N * a.H * a.W;
+  // ---- XCD-aware tile id ----
+  const int NT = (a.Cout + BT - 1) / BT;
+  const int total = gridDim.x;
+  int logical = blockIdx.x;
+  if ((total & 7) == 0) logical = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const long m0 = (long)(logical / NT) * BT;
+  const int n0 = (logical % NT) * BT;
+  // ---- loader role: pass p covers rows p*64 + tid/4, chunk tid%4 (4 channels of the 16 of a K step) ----
+  const int lchunk = tid % CH, lrow = tid / CH;
+  int img[PASSES], py[PASSES], px[PASSES];
+  bool m_ok[PASSES], n_ok[PASSES];
+  const float* wrow[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; p++) {
+    const int row = p * RPP + lrow;
+    const long lm = m0 + row;
+    m_ok[p] = lm < M;
+    img[p] = py[p] = px[p] = 0;
+    if (m_ok[p]) {
+      img[p] = (int)(lm / ((long)a.H * a.W));
+      const int rem = (int)(lm - (long)img[p] * a.H * a.W);
+      py[p] = rem / a.W;
+      px[p] = rem - py[p] * a.W;
+    }
+    n_ok[p] = n0 + row < a.Cout;
+    wrow[p] = a.w + (size_t)(n_ok[p] ? n0 + row : 0) * 9 * a.Cin + lchunk * 4;
+  }
+  const int ksteps_per_tap = a.Cin / BK;   // (host: BK = 32 only when Cin % 32 == 0)
+  const int nsteps = 9 * ksteps_per_tap;
+
+  Tap tp[PASSES];
+  auto set_tap = [&](int tap) {
+    const int r = tap / 3, s = tap - r * 3;
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        tp[p].off[k] = -1;
+        tp[p].wt[k] = 0.f;
+      }
+      if (!m_ok[p]) continue;
+      if (!DEFORM) {
+        const int yy = py[p] + r - 1, xx = px[p] + s - 1;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) tp[p].off[0] = ((img[p] * a.H + yy) * a.W + xx) * a.Cin;
+      } else {
+        // dcn_v1.py:L132-166 (deformable_im2col): h_im = h_in + i*dil + offset_h, zero outside (-1, H) x (-1, W),
+        // corners outside the image contribute 0 (dmcn_im2col_bilinear L25-56)
+        const size_t ob = (((size_t)img[p] * 18 + 2 * tap) * a.H + py[p]) * a.W + px[p];
+        const float oh = a.offset[ob], ow = a.offset[ob + (size_t)a.H * a.W];
+        const float h_im = (float)(py[p] + r - 1) + oh, w_im = (float)(px[p] + s - 1) + ow;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+          const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
+          const float lh = h_im - hl, lw = w_im - wl, hh = 1.f - lh, hw = 1.f - lw;
+          const float wt[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+          const int cy[4] = {hl, hl, hl + 1, hl + 1}, cx[4] = {wl, wl + 1, wl, wl + 1};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            tp[p].wt[k] = wt[k];
+            if (cy[k] >= 0 && cy[k] < a.H && cx[k] >= 0 && cx[k] < a.W)
+              tp[p].off[k] = ((img[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin;
+          }
+        }
+      }
+    }
+  };
+
+  v4f ra[PASSES], rb[PASSES];
+  auto load_step = [&](int tap, int c) {     // c: first channel of the K step
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+      if (!DEFORM) {
+        const v4f v = *reinterpret_cast<const v4f*>(a.x + (size_t)max(tp[p].off[0], 0) + c + lchunk * 4);
+        ra[p] = tp[p].off[0] >= 0 ? v : z;     // unconditional load of a valid address + select: no branches
+      } else {
+        v4f v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          const v4f t = *reinterpret_cast<const v4f*>(a.x + (size_t)max(tp[p].off[k], 0) + c + lchunk * 4);
+          v[k] = tp[p].off[k] >= 0 ? t : z;
+        }
+        ra[p] = tp[p].wt[0] * v[0] + tp[p].wt[1] * v[1] + tp[p].wt[2] * v[2] + tp[p].wt[3] * v[3];
+      }
+      const v4f wv = *reinterpret_cast<const v4f*>(wrow[p] + (size_t)tap * a.Cin + c);
+      rb[p] = n_ok[p] ? wv : z;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PASSES; p++) {
+      const int row = p * RPP + lrow;
+      *reinterpret_cast<v4f*>(&s_a[buf][swz<BK>(row, lchunk)]) = ra[p];
+      *reinterpret_cast<v4f*>(&s_b[buf][swz<BK>(row, lchunk)]) = rb[p];
+    }
+  };
+
+  // ---- compute role: wave (wm, wn) owns outputs [wm*BT/2, +BT/2) x [wn*BT/2, +BT/2) of the block tile ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  v16f acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; i++)
+#pragma unroll
+    for (int j = 0; j < T; j++)
+#pragma unroll
+      for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+  int tap = 0, c = 0;
+  set_tap(0);
+  load_step(0, 0);
+  store_step(0);
+  __syncthreads();
+  for (int step = 0; step < nsteps; step++) {
+    const int buf = step & 1;
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      c += BK;
+      if (c == a.Cin) {
+        c = 0;
+        tap++;
+        set_tap(tap);
+      }
+      load_step(tap, c);            // in flight during the MFMAs below
+    }
+#pragma unroll
+    for (int q = 0; q < BK / 8; q++) {
+      v4f fa[T], fb[T];
+#pragma unroll
+      for (int i = 0; i < T; i++) {
+        fa[i] = *reinterpret_cast<const v4f*>(&s_a[buf][swz<BK>(wm * (BT / 2) + i * 32 + frow, q * 2 + fhalf)]);
+        fb[i] = *reinterpret_cast<const v4f*>(&s_b[buf][swz<BK>(wn * (BT / 2) + i * 32 + frow, q * 2 + fhalf)]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+        for (int i = 0; i < T; i++)
+#pragma unroll
+          for (int j = 0; j < T; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_step(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous step
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < T; i++) {
+    float mk[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const long m = m0 + wm * (BT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      mk[e] = (a.rowmask && m < M) ? a.rowmask[m] : 1.f;       // all 16 loads in flight together
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      const int n = n0 + wn * (BT / 2) + j * 32 + (lane & 31);
+      const float b = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const long m = m0 + wm * (BT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < M && n < a.Cout) {
+          float v = acc[i][j][e] + b;
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.rowmask) v *= mk[e];
+          a.y[(size_t)m * a.Cout + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BT, int BK>
+int launch(const ConvArgs& a, hipStream_t st) {
+  const long M = (long)a.N * a.H * a.W;
+  const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
+  if (a.offset)
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+  return jdet_launch_status();
+}
+
+}  // namespace
+
+// Supported: Cin % 16 == 0, 16-byte aligned tensors, N*H*W*max(Cin, Cout) < 2^31; any Cout, any N, H, W.
+JDET_API int jdet_conv3x3_igemm_supported(int Cin, int Cout) { return Cin > 0 && Cin % 16 == 0 && Cout > 0; }
+
+JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,
+                                        const float* bias, int relu, const float* rowmask, const float* offset,
+                                        int tile, float* y_nhwc, jdet_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return JDET_E_BADARG;
+  if (!jdet_conv3x3_igemm_supported(Cin, Cout)) return JDET_E_UNSUPPORTED;
+  if (N == 0) return JDET_OK;
+  if (!x_nhwc || !w_krsc || !y_nhwc) return JDET_E_BADARG;
+  if ((((uintptr_t)x_nhwc) | ((uintptr_t)w_krsc)) & 15) return JDET_E_BADARG;
+  const long M = (long)N * H * W;
+  if (M * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return JDET_E_UNSUPPORTED;
+  ConvArgs a{x_nhwc, w_krsc, bias, rowmask, offset, y_nhwc, N, H, W, Cin, Cout, relu ? 1 : 0};
+  // 128 x 128 tiles once they fill the chip (2 workgroups per CU), 64 x 64 below: four times the workgroups, a
+  // quarter of the per-tile latency chain
+  // tile: 0 = automatic; 64 / 128 = edge of the output tile; + 1 selects the 16-deep K step (65, 129: measurement aid)
+  const int edge = tile & ~1;
+  if (tile != 0 && edge != 64 && edge != 128) return JDET_E_BADARG;
+  const long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
+  const bool big = tile ? edge == 128 : tiles128 >= 512;
+  const bool k32 = Cin % 32 == 0 && !(tile & 1);
+  hipStream_t st = (hipStream_t)stream;
+  if (big) return k32 ? launch<128, 32>(a, st) : launch<128, 16>(a, st);
+  return k32 ? launch<64, 32>(a, st) : launch<64, 16>(a, st);
+}

@@ -1,0 +1,109 @@
+"""3x3 convolution / deformable convolution forward as one fp32-MFMA implicit GEMM (csrc/conv_igemm.hip).
+
+Replaces, for inference, the `nn.Conv(3x3) [+ ReLU]` of ConvModule (python/jdet/models/utils/modules.py:L91-175) in
+the head towers and the FPN, and the im2col + matmul pair of DeformConv.execute (python/jdet/ops/dcn_v1.py:L412-454):
+no column matrix, bias / ReLU / gap-row mask applied to the accumulators.  The kernel is a forward kernel:
+`conv3x3_bias_act` gives it a backward through the library's data / weight gradient kernels (the ReLU mask comes from
+the saved output), the deformable form is used where no gradient is needed (the training path keeps the column-matrix
+deformable conv, whose weight-gradient GEMM reads the columns).
+
+Measured on MI355X, 256 -> 256 channels, batch 2 (scripts/conv_igemm_timing.py, profiles/r03_conv_igemm.md):
+128^2 map 336 us vs 390 us for library conv + bias + ReLU; 64^2 map 111 vs 127 us; below that the 2304-deep reduction
+per tile makes the tile's own latency the floor (74 us) and the library (split-K) wins, so `preferred()` says no.
+"""
+import os
+
+import torch
+
+from jdet_amd import _lib as L
+
+
+def supported(cin, cout):
+    return bool(L.lib().jdet_conv3x3_igemm_supported(int(cin), int(cout)))
+
+
+def weight_krsc(weight):
+    """(Cout, Cin, 3, 3) logical -> (Cout, 3, 3, Cin) contiguous fp32; free when the weight is channels_last"""
+    return L.f32c(weight.permute(0, 2, 3, 1))
+
+
+def conv3x3_nhwc(x_nhwc, w_krsc, bias=None, relu=False, rowmask=None, offset=None, tile=0):
+    """x_nhwc (N,H,W,Cin) contiguous fp32, w_krsc (Cout,3,3,Cin), offset (N,18,H,W) or None -> (N,H,W,Cout)"""
+    L.need_device(x_nhwc, w_krsc, bias, rowmask, offset)
+    N, H, W, Cin = x_nhwc.shape
+    Cout = w_krsc.shape[0]
+    if w_krsc.shape[1:] != (3, 3, Cin):
+        raise ValueError("weight %r does not match input channels %d" % (tuple(w_krsc.shape), Cin))
+    if offset is not None and tuple(offset.shape) != (N, 18, H, W):
+        raise ValueError("offset must be (N, 18, H, W), got %r" % (tuple(offset.shape),))
+    x_nhwc, w_krsc = L.f32c(x_nhwc), L.f32c(w_krsc)
+    y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x_nhwc.device)
+    L.check(L.lib().jdet_conv3x3_igemm_forward(
+        L.ptr(x_nhwc), N, H, W, Cin, L.ptr(w_krsc), Cout,
+        L.ptr(L.f32c(bias)) if bias is not None else None, int(bool(relu)),
+        L.ptr(L.f32c(rowmask)) if rowmask is not None else None,
+        L.ptr(L.f32c(offset)) if offset is not None else None,
+        int(tile), L.ptr(y), L.stream_ptr(x_nhwc)), "jdet_conv3x3_igemm_forward")
+    return y
+
+
+def conv3x3(x, weight, bias=None, relu=False, offset=None, tile=0):
+    """NCHW-logical convenience form: returns a channels_last (N, Cout, H, W) tensor"""
+    y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu, None, offset, tile)
+    return y.permute(0, 3, 1, 2)
+
+
+# fused path only where it measured faster than library conv + bias + ReLU (positions = N*H*W)
+MIN_POSITIONS = 8192
+DEFORM_MIN_POSITIONS = 32768
+ENABLED = os.environ.get("JDET_CONV_IGEMM", "1") == "1"     # A/B switch for measurements
+# In the train step the autotuned library forward (conv + bias fused by its own solver) is as fast as this kernel and
+# the step measured 0.25 ms SLOWER with the fused forward (30.75 vs 30.50 ms, profiles/r03_conv_igemm.md): the
+# differentiable route is off unless asked for.
+TRAIN = os.environ.get("JDET_CONV_IGEMM_TRAIN", "0") == "1"
+
+
+def needs_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def preferred(x, weight, min_positions=None):
+    """x (N, Cin, H, W) logical, weight (Cout, Cin, 3, 3): is the fused kernel the faster choice for this call?"""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4):
+        return False
+    N, Cin, H, W = x.shape
+    if tuple(weight.shape[1:]) != (Cin, 3, 3) or not supported(Cin, weight.shape[0]):
+        return False
+    if N * H * W * max(Cin, weight.shape[0]) >= 2 ** 31:
+        return False
+    return N * H * W >= (MIN_POSITIONS if min_positions is None else min_positions)
+
+
+class _Conv3x3BiasAct(torch.autograd.Function):
+    """y = [relu](conv3x3(x, w) + b): forward = the implicit-GEMM kernel, backward = the library's convolution
+    backward on the ReLU-masked gradient (one call yields grad_x, grad_w, grad_b)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu).permute(0, 3, 1, 2)
+        ctx.relu = bool(relu)
+        ctx.bias_sizes = None if bias is None else [weight.shape[0]]
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]]
+        gx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, ctx.bias_sizes, [1, 1], [1, 1], [1, 1], False,
+                                                         [0, 0], 1, need)
+        return (gx if need[0] else None), (gw if need[1] else None), (gb if need[2] else None), None
+
+
+def conv3x3_bias_act(x, weight, bias=None, relu=False):
+    """(N, Cin, H, W) logical (channels_last memory is free) -> (N, Cout, H, W) channels_last; differentiable"""
+    if needs_grad(x, weight, bias):
+        return _Conv3x3BiasAct.apply(x, weight, bias, relu)
+    return conv3x3(x, weight, bias, relu)

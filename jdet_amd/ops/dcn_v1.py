@@ -211,8 +211,28 @@ class DeformConvFunction(torch.autograd.Function):
                 None)
 
 
+def _fused_forward(input, offset, weight, stride, padding, dilation, groups, deformable_groups):
+    """No gradient needed (inference): 3x3 / stride 1 / pad 1 deformable conv as ONE implicit GEMM whose A operand is
+    gathered bilinearly (ops/conv_igemm.py) -- no column matrix.  Used where it measured faster than im2col + GEMM
+    (398 vs 464 us on a 2 x 128^2 x 256 map); None = not applicable."""
+    from jdet_amd.ops import conv_igemm
+    if conv_igemm.needs_grad(input, weight, offset):
+        return None
+    if (_pair(stride), _pair(padding), _pair(dilation), groups, deformable_groups) != ((1, 1), (1, 1), (1, 1), 1, 1):
+        return None
+    if not conv_igemm.preferred(input, weight, conv_igemm.DEFORM_MIN_POSITIONS):
+        return None
+    if tuple(offset.shape) != (input.shape[0], 18) + tuple(input.shape[-2:]):
+        return None
+    return conv_igemm.conv3x3(input, weight, offset=L.f32c(offset))
+
+
 def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
                 im2col_step=64):
+    if input is not None and input.dim() == 4 and input.is_cuda:
+        y = _fused_forward(input, offset, weight, stride, padding, dilation, groups, deformable_groups)
+        if y is not None:
+            return y
     return DeformConvFunction.apply(input, offset, weight, stride, padding, dilation, groups,
                                     deformable_groups, im2col_step)
 

@@ -1,0 +1,149 @@
+"""fp32-MFMA implicit-GEMM 3x3 conv (csrc/conv_igemm.hip) against float64 convolutions on the host and, for the
+deformable form, against the column-matrix path (jdet_deform_im2col_nhwc + GEMM) it replaces at inference.
+
+Tolerance: fp32 products and fp32 accumulation over K = 9 * Cin terms in a different order than the reference GEMM:
+|err| <= 2e-5 * sqrt(K) * max|x| * max|w| is generous (observed ~1e-6 relative to the output scale)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref64(x, w, b, relu):
+    y = F.conv2d(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu(), padding=1)
+    return torch.relu(y) if relu else y
+
+
+CASES = [
+    # N, H, W, Cin, Cout, bias, relu
+    (2, 16, 16, 256, 256, True, True),
+    (1, 7, 9, 32, 128, False, False),       # ragged M (63 positions: one partial tile)
+    (2, 13, 5, 64, 15, True, False),        # Cout below one tile (the classification conv of a head)
+    (1, 32, 32, 256, 5, True, False),       # the regression conv
+    (3, 20, 12, 96, 200, True, True),       # Cout straddles two N tiles
+    (1, 6, 6, 48, 40, True, True),          # Cin a multiple of 16 only
+    (1, 1, 1, 32, 32, True, False),         # a single position: every tap but the centre is padding
+    (1, 128, 128, 256, 256, False, True),   # S2ANet P3 tower conv at 1024^2
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,bias,relu", CASES)
+@pytest.mark.parametrize("tile", [0, 64, 65, 128, 129])     # odd = the 16-deep K step
+def test_conv3x3_matches_float64(N, H, W, Cin, Cout, bias, relu, tile):
+    from jdet_amd.ops import conv_igemm as CI
+    if tile and N * H * W > 4096:
+        pytest.skip("forced tile shapes are exercised on the small cases")
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    y = CI.conv3x3(x.cuda(), w.cuda(), None if b is None else b.cuda(), relu, tile=tile)
+    assert y.shape == (N, Cout, H, W)
+    ref = _ref64(x, w, b, relu)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
+
+
+def test_rowmask_and_empty_batch():
+    from jdet_amd.ops import conv_igemm as CI
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 10, 6, 64, generator=g).cuda()
+    w = torch.randn(128, 3, 3, 64, generator=g).cuda() * 0.05
+    mask = (torch.rand(2 * 10 * 6, generator=g) > 0.3).float().cuda()
+    y = CI.conv3x3_nhwc(x, w, None, True, mask)
+    y0 = CI.conv3x3_nhwc(x, w, None, True)
+    assert torch.equal(y, y0 * mask.view(2, 10, 6, 1))
+    assert CI.conv3x3_nhwc(x[:0], w).shape == (0, 10, 6, 128)
+
+
+def test_unsupported_shapes_raise():
+    from jdet_amd import _lib as L
+    from jdet_amd.ops import conv_igemm as CI
+    assert not CI.supported(40, 256) and CI.supported(32, 15)
+    x = torch.zeros(1, 4, 4, 40).cuda()
+    w = torch.zeros(16, 3, 3, 40).cuda()
+    with pytest.raises(L.JDetHipError):
+        CI.conv3x3_nhwc(x, w)
+    with pytest.raises(L.JDetHipError):
+        CI.conv3x3_nhwc(torch.zeros(1, 4, 4, 32), torch.zeros(16, 3, 3, 32))     # host tensors: no CPU fallback
+
+
+@pytest.mark.parametrize("tile", [64, 65, 128, 129])
+@pytest.mark.parametrize("N,H,W,C,Cout,scale", [(2, 16, 16, 256, 256, 1.5), (1, 9, 11, 64, 96, 4.0),
+                                                (1, 64, 64, 256, 256, 2.0)])
+def test_deformable_matches_column_path(N, H, W, C, Cout, scale, tile):
+    """same samples, same weights: the fused gather must agree with deformable im2col + GEMM, including samples that
+    land outside the image (offsets up to `scale` pixels push border taps past (-1, H))"""
+    from jdet_amd.ops import conv_igemm as CI
+    from jdet_amd.ops import dcn_v1
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda()
+    off = (torch.randn(N, 18, H, W, generator=g) * scale).cuda()
+    y = CI.conv3x3_nhwc(x, w, offset=off, tile=tile)
+    cols = dcn_v1.deformable_im2col_nhwc(x, off, 3, 3, (1, 1), (1, 1), (1, 1))
+    ref = (cols.double() @ w.reshape(Cout, -1).double().t()).view(N, H, W, Cout)
+    err = (y.double() - ref).abs().max().item()
+    assert err <= 2e-5 * ref.abs().max().item() + 1e-6, err
+
+
+def test_zero_offset_is_the_plain_convolution():
+    from jdet_amd.ops import conv_igemm as CI
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 12, 12, 64, generator=g).cuda()
+    w = (torch.randn(64, 3, 3, 64, generator=g) * 0.05).cuda()
+    y0 = CI.conv3x3_nhwc(x, w)
+    y1 = CI.conv3x3_nhwc(x, w, offset=torch.zeros(1, 18, 12, 12).cuda())
+    assert torch.equal(y0, y1)        # weights (1, 0, 0, 0): x * 1 + 0 + 0 + 0 is exact
+
+
+@pytest.mark.parametrize("act", [True, False])
+def test_conv_module_fused_path_matches_library_path(act):
+    """ConvModule routes 3x3 conv [+ ReLU] through the fused kernel above the measured break-even size: same output,
+    same gradients (the backward is the library's convolution backward on the ReLU-masked gradient)"""
+    from jdet_amd.models.utils.modules import ConvModule
+    from jdet_amd.ops import conv_igemm as CI
+    torch.manual_seed(5)
+    m = ConvModule(64, 128, 3, padding=1, act_cfg=dict(type="ReLU") if act else None).cuda()
+    torch.nn.init.normal_(m.conv.bias, std=0.1)
+    x = torch.randn(2, 64, 72, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    assert CI.preferred(x, m.conv.weight)
+    g = torch.randn(2, 128, 72, 64, device="cuda")
+    outs = []
+    for enabled in (True, False):
+        CI.ENABLED, CI.TRAIN = enabled, True
+        try:
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad()
+            y = m(xi)
+            y.backward(g)
+            outs.append((y.detach(), xi.grad, m.conv.weight.grad.clone(), m.conv.bias.grad.clone()))
+        finally:
+            CI.ENABLED, CI.TRAIN = True, False
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
+    with torch.no_grad():
+        assert torch.equal(m(x), outs[0][0])          # the no-grad route is the same kernel
+
+
+def test_deform_conv_inference_takes_the_fused_kernel():
+    from jdet_amd.ops import conv_igemm as CI
+    from jdet_amd.ops import dcn_v1
+    torch.manual_seed(6)
+    x = torch.randn(2, 32, 128, 128, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(48, 32, 3, 3, device="cuda") * 0.1
+    off = torch.randn(2, 18, 128, 128, device="cuda") * 3
+    with torch.no_grad():
+        y = dcn_v1.deform_conv(x, off, w, 1, 1, 1)
+        CI.ENABLED = False
+        try:
+            ref = dcn_v1.deform_conv(x, off, w, 1, 1, 1)
+        finally:
+            CI.ENABLED = True
+    assert y.shape == ref.shape and (y - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-6
+    # with gradients requested the column-matrix path (which has the backward) is taken
+    xr = x.clone().requires_grad_(True)
+    dcn_v1.deform_conv(xr, off, w, 1, 1, 1).sum().backward()
+    assert xr.grad is not None
