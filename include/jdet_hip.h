@@ -170,6 +170,36 @@ int jdet_deform_col2im_coord(const float* col, const float* im, const float* off
                              int stride_w, int dil_h, int dil_w, int deform_groups,
                              float* grad_offset, jdet_stream_t stream);
 
+/* Modulated deformable conv (DCN v2) sampling.  Replace modulated_deformable_im2col / _col2im / _col2im_coord of
+ * ops/dcn_v2.py:L86-149, L506-558, L560-627.  Layouts as jdet_deform_* plus mask (B, dg*kh*kw, Ho, Wo): the column
+ * element, the column gradient and the offset gradient are multiplied by the tap's mask; grad_mask (same shape as
+ * mask) = sum over the group's channels of column gradient x unmasked bilinear sample. */
+int jdet_modulated_deform_im2col(const float* im, const float* offset, const float* mask, int B, int C, int H,
+                                 int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                 int dil_w, int deform_groups, float* col, jdet_stream_t stream);
+int jdet_modulated_deform_col2im(const float* col, const float* offset, const float* mask, int B, int C, int H,
+                                 int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                 int dil_w, int deform_groups, float* grad_im, jdet_stream_t stream);
+int jdet_modulated_deform_col2im_coord(const float* col, const float* im, const float* offset, const float* mask,
+                                       int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w,
+                                       int stride_h, int stride_w, int dil_h, int dil_w, int deform_groups,
+                                       float* grad_offset, float* grad_mask, jdet_stream_t stream);
+
+/* Deformable position-sensitive RoI pooling.  Replace DeformablePSROIPoolForwardKernel / ...BackwardAccKernel of
+ * ops/dcn_v2.py:L855-932, L1007-1116.  input (N,C,H,W) with C = output_dim * group_size^2; rois (R,5)
+ * [batch,x1,y1,x2,y2]; trans (R, trans_channels, part, part) or NULL with no_trans; out / top_count
+ * (R, output_dim, P, P) (top_count = samples counted per bin, consumed by the backward).  The backward zero-fills
+ * grad_input (N,C,H,W) and grad_trans (shape of trans) and accumulates with fp32 atomics. */
+int jdet_deform_psroi_pool_forward(const float* input, const float* rois, const float* trans, int N, int C, int H,
+                                   int W, int R, int no_trans, float spatial_scale, int output_dim, int group_size,
+                                   int pooled_size, int part_size, int sample_per_part, float trans_std,
+                                   int trans_channels, float* out, float* top_count, jdet_stream_t stream);
+int jdet_deform_psroi_pool_backward(const float* grad_out, const float* top_count, const float* input,
+                                    const float* rois, const float* trans, int N, int C, int H, int W, int R,
+                                    int no_trans, float spatial_scale, int output_dim, int group_size,
+                                    int pooled_size, int part_size, int sample_per_part, float trans_std,
+                                    int trans_channels, float* grad_input, float* grad_trans, jdet_stream_t stream);
+
 /* Channels-last deformable sampling (groups = 1, deform_groups = 1, C % 4 == 0; else JDET_E_UNSUPPORTED).
  * Same arithmetic as jdet_deform_im2col / jdet_deform_col2im (dcn_v1.py:L130-184, L185-241), different
  * layout: x_nhwc (B,H,W,C); offset stays (B, 2*kh*kw, Ho, Wo); cols / grad_cols are

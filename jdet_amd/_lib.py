@@ -42,6 +42,11 @@ SIGNATURES = {
     "jdet_deform_im2col": (_i, [_p, _p] + [_i] * 13 + [_p, _p]),
     "jdet_deform_col2im": (_i, [_p, _p] + [_i] * 13 + [_p, _p]),
     "jdet_deform_col2im_coord": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_modulated_deform_im2col": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_modulated_deform_col2im": (_i, [_p, _p, _p] + [_i] * 13 + [_p, _p]),
+    "jdet_modulated_deform_col2im_coord": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _p, _p]),
+    "jdet_deform_psroi_pool_forward": (_i, [_p, _p, _p] + [_i] * 6 + [_f] + [_i] * 5 + [_f, _i, _p, _p, _p]),
+    "jdet_deform_psroi_pool_backward": (_i, [_p, _p, _p, _p, _p] + [_i] * 6 + [_f] + [_i] * 5 + [_f, _i, _p, _p, _p]),
     "jdet_set_roi_forward_mode": (_i, [_i]),
     "jdet_deform_im2col_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p]),
     "jdet_deform_col2im_nhwc_workspace": (_sz, [_i] * 12),

@@ -20,6 +20,11 @@
 //   * offset gradient: one thread per (b, g, tap, ho, wo) walks the group's channels in order and produces BOTH
 //     directions (d/dh, d/dw) from the same four pixel loads and the same column element; summation order per
 //     output = the reference's (bit-identical results).
+//
+// Modulated form (DCN v2, ops/dcn_v2.py:L86-149, L506-558, L560-627): the same three kernels with a mask plane per
+// (b, g, tap) -- (B, dg*kh*kw, Ho, Wo) -- multiplying the column element (im2col), the column gradient (col2im, offset
+// gradient), and with the mask gradient = sum over the group's channels of column gradient x unmasked sample
+// (produced next to the offset gradient from the same pixel loads).  mask == nullptr is the v1 arithmetic unchanged.
 #include "common.h"
 
 namespace {
@@ -52,6 +57,11 @@ __device__ __forceinline__ Geo geometry(const DcnP& p, const float* __restrict__
   return q;
 }
 
+__device__ __forceinline__ float mask_at(const DcnP& p, const float* __restrict__ mask, int b, int g, int tap, int ho,
+                                         int wo) {
+  return mask[((((size_t)b * p.dg + g) * p.kh * p.kw + tap) * p.Ho + ho) * p.Wo + wo];
+}
+
 // block -> (b, g, tap, ho, wo): blockIdx.x = wo segment, blockIdx.y = ho, blockIdx.z = (b * dg + g) * kk + tap
 struct Item {
   int b, g, tap, ho, wo;
@@ -72,12 +82,14 @@ __device__ __forceinline__ Item item_of(const DcnP& p) {
 }
 
 __global__ __launch_bounds__(256) void deform_im2col_nchw_kernel(const float* __restrict__ im,
-                                                                const float* __restrict__ offset, DcnP p,
+                                                                const float* __restrict__ offset,
+                                                                const float* __restrict__ mask, DcnP p,
                                                                 float* __restrict__ col) {
   const Item it = item_of(p);
   if (!it.ok) return;
   const int wave = threadIdx.x >> 6;
   const Geo q = geometry(p, offset, it.b, it.g, it.tap, it.ho, it.wo);
+  const float m = mask ? mask_at(p, mask, it.b, it.g, it.tap, it.ho, it.wo) : 1.f;
   const float lh = q.h - q.hl, lw = q.w - q.wl;
   const float hh = 1 - lh, hw = 1 - lw;
   const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
@@ -96,18 +108,20 @@ __global__ __launch_bounds__(256) void deform_im2col_nchw_kernel(const float* __
       const float v4 = q.c11 ? plane[o00 + p.W + 1] : 0.f;
       val = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
     }
-    col[(((size_t)c * kk + it.tap) * p.B + it.b) * hw_out + at] = val;
+    col[(((size_t)c * kk + it.tap) * p.B + it.b) * hw_out + at] = mask ? val * m : val;   // dcn_v2.py:L142
   }
 }
 
 __global__ __launch_bounds__(256) void deform_col2im_nchw_kernel(const float* __restrict__ col,
-                                                                const float* __restrict__ offset, DcnP p,
+                                                                const float* __restrict__ offset,
+                                                                const float* __restrict__ mask, DcnP p,
                                                                 float* __restrict__ grad_im) {
   const Item it = item_of(p);
   if (!it.ok) return;
   const int wave = threadIdx.x >> 6;
   const Geo q = geometry(p, offset, it.b, it.g, it.tap, it.ho, it.wo);
   if (!q.inside) return;   // contributes nothing (L58-64)
+  const float m = mask ? mask_at(p, mask, it.b, it.g, it.tap, it.ho, it.wo) : 1.f;
   // weights of the four neighbours: the factors (h + 1 - argmax) / (argmax + 1 - h) of L76-83
   const float a0 = q.hl + 1 - q.h, a1 = q.h + 1 - (q.hl + 1);
   const float b0 = q.wl + 1 - q.w, b1 = q.w + 1 - (q.wl + 1);
@@ -118,7 +132,8 @@ __global__ __launch_bounds__(256) void deform_col2im_nchw_kernel(const float* __
   const size_t at = (size_t)it.ho * p.Wo + it.wo;
   for (int cc = wave; cc < cpg; cc += 4) {
     const int c = it.g * cpg + cc;
-    const float top = col[(((size_t)c * kk + it.tap) * p.B + it.b) * hw_out + at];
+    float top = col[(((size_t)c * kk + it.tap) * p.B + it.b) * hw_out + at];
+    if (mask) top = top * m;                                                     // dcn_v2.py:L540
     float* plane = grad_im + ((size_t)it.b * p.C + c) * hw_in;
     if (q.c00 && g00 != 0.f) unsafeAtomicAdd(plane + o00, g00 * top);
     if (q.c01 && g01 != 0.f) unsafeAtomicAdd(plane + o00 + 1, g01 * top);
@@ -130,8 +145,10 @@ __global__ __launch_bounds__(256) void deform_col2im_nchw_kernel(const float* __
 // one thread per (b, g, tap, ho, wo): both offset-gradient channels (2*tap: d/dh, 2*tap + 1: d/dw)
 __global__ __launch_bounds__(256) void deform_col2im_coord_nchw_kernel(const float* __restrict__ col,
                                                                       const float* __restrict__ im,
-                                                                      const float* __restrict__ offset, DcnP p,
-                                                                      float* __restrict__ grad_offset) {
+                                                                      const float* __restrict__ offset,
+                                                                      const float* __restrict__ mask, DcnP p,
+                                                                      float* __restrict__ grad_offset,
+                                                                      float* __restrict__ grad_mask) {
   const int kk = p.kh * p.kw;
   const size_t hw_out = (size_t)p.Ho * p.Wo, hw_in = (size_t)p.H * p.W;
   const long n = (long)p.B * p.dg * kk * hw_out;
@@ -144,7 +161,8 @@ __global__ __launch_bounds__(256) void deform_col2im_coord_nchw_kernel(const flo
     const int g = (int)(z % p.dg);
     const int b = (int)(z / p.dg);
     const Geo q = geometry(p, offset, b, g, tap, ho, wo);
-    float dh = 0.f, dw = 0.f;
+    float dh = 0.f, dw = 0.f, mval = 0.f;
+    const float m = mask ? mask_at(p, mask, b, g, tap, ho, wo) : 1.f;
     if (q.inside) {   // (outside: the reference evaluates the weight at (-2, -2) = 0, L277-280)
       const int hl = q.hl, wl = q.wl;
       const int o00 = hl * p.W + wl;
@@ -162,10 +180,18 @@ __global__ __launch_bounds__(256) void deform_col2im_coord_nchw_kernel(const flo
         if (q.c01) { wh += -1 * (q.w - wl) * v01;     ww += (hl + 1 - q.h) * v01; }
         if (q.c10) { wh += (wl + 1 - q.w) * v10;      ww += -1 * (q.h - hl) * v10; }
         if (q.c11) { wh += (q.w - wl) * v11;          ww += (q.h - hl) * v11; }
-        dh += wh * top;
-        dw += ww * top;
+        if (mask) {          // dcn_v2.py:L611-617: val += weight * col * mask; mval += col * bilinear(im)
+          dh += wh * top * m;
+          dw += ww * top * m;
+          const float lh = q.h - hl, lw = q.w - wl, hh = 1 - lh, hw = 1 - lw;
+          mval += top * (hh * hw * v00 + hh * lw * v01 + lh * hw * v10 + lh * lw * v11);
+        } else {
+          dh += wh * top;
+          dw += ww * top;
+        }
       }
     }
+    if (grad_mask) grad_mask[(((size_t)b * p.dg + g) * kk + tap) * hw_out + (size_t)ho * p.Wo + wo] = mval;
     float* dst = grad_offset + (((size_t)b * p.dg + g) * 2 * kk + 2 * tap) * hw_out + (size_t)ho * p.Wo + wo;
     dst[0] = dh;
     dst[hw_out] = dw;
@@ -196,9 +222,9 @@ int item_grid(const DcnP& p, dim3& grid) {
 
 }  // namespace
 
-JDET_API int jdet_deform_im2col(const float* im, const float* offset, int B, int C, int H, int W, int kh,
-                                int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
-                                int dil_w, int dg, float* col, jdet_stream_t stream) {
+static int im2col_impl(const float* im, const float* offset, const float* mask, int B, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                       float* col, jdet_stream_t stream) {
   DcnP p;
   int e = fill_dcn(p, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg);
   if (e) return e;
@@ -206,13 +232,13 @@ JDET_API int jdet_deform_im2col(const float* im, const float* offset, int B, int
   if (!im || !offset || !col) return JDET_E_BADARG;
   dim3 grid;
   if ((e = item_grid(p, grid))) return e;
-  hipLaunchKernelGGL(deform_im2col_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, im, offset, p, col);
+  hipLaunchKernelGGL(deform_im2col_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, im, offset, mask, p, col);
   return jdet_launch_status();
 }
 
-JDET_API int jdet_deform_col2im(const float* col, const float* offset, int B, int C, int H, int W, int kh,
-                                int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
-                                int dil_w, int dg, float* grad_im, jdet_stream_t stream) {
+static int col2im_impl(const float* col, const float* offset, const float* mask, int B, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                       float* grad_im, jdet_stream_t stream) {
   DcnP p;
   int e = fill_dcn(p, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg);
   if (e) return e;
@@ -222,14 +248,13 @@ JDET_API int jdet_deform_col2im(const float* col, const float* offset, int B, in
   if ((e = item_grid(p, grid))) return e;
   int he = jdet_zero_async(grad_im, sizeof(float) * (size_t)B * C * H * W, (hipStream_t)stream);
   if (he) return he;
-  hipLaunchKernelGGL(deform_col2im_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, col, offset, p, grad_im);
+  hipLaunchKernelGGL(deform_col2im_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, col, offset, mask, p, grad_im);
   return jdet_launch_status();
 }
 
-JDET_API int jdet_deform_col2im_coord(const float* col, const float* im, const float* offset, int B, int C,
-                                      int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h,
-                                      int stride_w, int dil_h, int dil_w, int dg, float* grad_offset,
-                                      jdet_stream_t stream) {
+static int coord_impl(const float* col, const float* im, const float* offset, const float* mask, int B, int C, int H,
+                      int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                      int dg, float* grad_offset, float* grad_mask, jdet_stream_t stream) {
   DcnP p;
   int e = fill_dcn(p, B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg);
   if (e) return e;
@@ -239,6 +264,40 @@ JDET_API int jdet_deform_col2im_coord(const float* col, const float* im, const f
   long g = (n + 255) / 256;
   if (g > 262144) g = 262144;
   hipLaunchKernelGGL(deform_col2im_coord_nchw_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, col, im,
-                     offset, p, grad_offset);
+                     offset, mask, p, grad_offset, grad_mask);
   return jdet_launch_status();
+}
+
+#define JDET_DCN_GEOM_PARAMS int B, int C, int H, int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, \
+                             int dil_h, int dil_w, int dg
+#define JDET_DCN_GEOM_ARGS B, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg
+
+JDET_API int jdet_deform_im2col(const float* im, const float* offset, JDET_DCN_GEOM_PARAMS, float* col,
+                                jdet_stream_t stream) {
+  return im2col_impl(im, offset, nullptr, JDET_DCN_GEOM_ARGS, col, stream);
+}
+JDET_API int jdet_deform_col2im(const float* col, const float* offset, JDET_DCN_GEOM_PARAMS, float* grad_im,
+                                jdet_stream_t stream) {
+  return col2im_impl(col, offset, nullptr, JDET_DCN_GEOM_ARGS, grad_im, stream);
+}
+JDET_API int jdet_deform_col2im_coord(const float* col, const float* im, const float* offset, JDET_DCN_GEOM_PARAMS,
+                                      float* grad_offset, jdet_stream_t stream) {
+  return coord_impl(col, im, offset, nullptr, JDET_DCN_GEOM_ARGS, grad_offset, nullptr, stream);
+}
+
+JDET_API int jdet_modulated_deform_im2col(const float* im, const float* offset, const float* mask,
+                                          JDET_DCN_GEOM_PARAMS, float* col, jdet_stream_t stream) {
+  if (B > 0 && !mask) return JDET_E_BADARG;
+  return im2col_impl(im, offset, mask, JDET_DCN_GEOM_ARGS, col, stream);
+}
+JDET_API int jdet_modulated_deform_col2im(const float* col, const float* offset, const float* mask,
+                                          JDET_DCN_GEOM_PARAMS, float* grad_im, jdet_stream_t stream) {
+  if (B > 0 && !mask) return JDET_E_BADARG;
+  return col2im_impl(col, offset, mask, JDET_DCN_GEOM_ARGS, grad_im, stream);
+}
+JDET_API int jdet_modulated_deform_col2im_coord(const float* col, const float* im, const float* offset,
+                                                const float* mask, JDET_DCN_GEOM_PARAMS, float* grad_offset,
+                                                float* grad_mask, jdet_stream_t stream) {
+  if (B > 0 && (!mask || !grad_mask)) return JDET_E_BADARG;
+  return coord_impl(col, im, offset, mask, JDET_DCN_GEOM_ARGS, grad_offset, grad_mask, stream);
 }

@@ -689,6 +689,334 @@ JO_API void jo_deform_col2im_coord(const float* col, const float* im, const floa
 }
 
 // ---------------------------------------------------------------------------
+// Modulated deformable conv (DCN v2), operator level (ops/dcn_v2.py:L11-306 forward, L308-781 backward)
+//   input (B,C,H,W); offset (B, dg*2*kh*kw, Ho, Wo); mask (B, dg*kh*kw, Ho, Wo); weight (Cout, C, kh, kw); bias (Cout)
+// Parity status: UNPINNED by reference execution (CUDA-only text, cuBLAS calls: not buildable here); held to closed
+// forms in tests/test_dcn_v2_oracle.py (mask = 1 equals the pinned v1 sampling, integer offsets = shifted conv x mask,
+// linearity in the mask, adjoint identities, central differences).
+// ---------------------------------------------------------------------------
+namespace {
+
+// modulated_deformable_im2col_gpu_kernel L86-149 for ONE image: columns (C*kh*kw, Ho*Wo)
+void dcn2_im2col_image(const float* im, const float* offset, const float* mask, int C, int H, int W, int kh, int kw,
+                       int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, int Ho, int Wo,
+                       float* col) {
+  const int cpg = C / dg;
+  for (int c_im = 0; c_im < C; c_im++)
+    for (int h_col = 0; h_col < Ho; h_col++)
+      for (int w_col = 0; w_col < Wo; w_col++) {
+        const int g = c_im / cpg;
+        const int h_in = h_col * stride_h - pad_h;
+        const int w_in = w_col * stride_w - pad_w;
+        const float* im_ptr = im + (size_t)c_im * H * W;
+        const float* off_ptr = offset + (size_t)g * 2 * kh * kw * Ho * Wo;
+        const float* mask_ptr = mask + (size_t)g * kh * kw * Ho * Wo;
+        for (int i = 0; i < kh; ++i)
+          for (int j = 0; j < kw; ++j) {
+            const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_col) * Wo + w_col];
+            const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_col) * Wo + w_col];
+            const float m = mask_ptr[((i * kw + j) * Ho + h_col) * Wo + w_col];
+            float val = 0.f;
+            const float h_im = h_in + i * dil_h + offset_h;
+            const float w_im = w_in + j * dil_w + offset_w;
+            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) val = dcn_bilinear(im_ptr, W, H, W, h_im, w_im);
+            col[(((size_t)c_im * kh * kw + i * kw + j) * Ho + h_col) * Wo + w_col] = val * m;
+          }
+      }
+}
+
+}  // namespace
+
+// dcn_v2_conv_forward L11-306: output = bias (ones GEMM, L238-250) + weight . columns (L260-272), per image
+JO_API void jo_dcn_v2_forward(const float* input, const float* offset, const float* mask, const float* weight,
+                              const float* bias, int B, int C, int H, int W, int Cout, int kh, int kw, int pad_h,
+                              int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* output) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int K = C * kh * kw, P = Ho * Wo;
+  std::vector<float> col((size_t)K * P);
+  for (int b = 0; b < B; b++) {
+    dcn2_im2col_image(input + (size_t)b * C * H * W, offset + (size_t)b * dg * 2 * kh * kw * P,
+                      mask + (size_t)b * dg * kh * kw * P, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h,
+                      dil_w, dg, Ho, Wo, col.data());
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < Cout; co++)
+      for (int q = 0; q < P; q++) {
+        double acc = bias[co];
+        for (int k = 0; k < K; k++) acc += (double)weight[(size_t)co * K + k] * col[(size_t)k * P + q];
+        output[((size_t)b * Cout + co) * P + q] = (float)acc;
+      }
+  }
+}
+
+// dcn_v2_conv_backward L308-781, the per-image loop of L711-779.  All five gradients; grad_weight / grad_bias
+// accumulate over the batch (beta = 1, L757-776).  NOTE L651-653: modulated_deformable_col2im_cuda hands the kernel
+// (pad_h, pad_h) -- the input gradient uses pad_h for BOTH axes; reproduced (a symmetric padding hides it).
+JO_API void jo_dcn_v2_backward(const float* input, const float* offset, const float* mask, const float* weight,
+                               const float* grad_output, int B, int C, int H, int W, int Cout, int kh, int kw,
+                               int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                               float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight,
+                               float* grad_bias) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int K = C * kh * kw, P = Ho * Wo, kk = kh * kw;
+  std::vector<float> col((size_t)K * P);
+  std::vector<double> gw((size_t)Cout * K, 0.0), gb(Cout, 0.0);
+  memset(grad_input, 0, sizeof(float) * (size_t)B * C * H * W);
+  for (int b = 0; b < B; b++) {
+    const float* in_n = input + (size_t)b * C * H * W;
+    const float* off_n = offset + (size_t)b * dg * 2 * kk * P;
+    const float* mask_n = mask + (size_t)b * dg * kk * P;
+    const float* go_n = grad_output + (size_t)b * Cout * P;
+    float* gi_n = grad_input + (size_t)b * C * H * W;
+    float* goff_n = grad_offset + (size_t)b * dg * 2 * kk * P;
+    float* gmask_n = grad_mask + (size_t)b * dg * kk * P;
+    // columns = weight^T . grad_output   (L722-730)
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; k++)
+      for (int q = 0; q < P; q++) {
+        double acc = 0;
+        for (int co = 0; co < Cout; co++) acc += (double)weight[(size_t)co * K + k] * go_n[(size_t)co * P + q];
+        col[(size_t)k * P + q] = (float)acc;
+      }
+    // modulated_deformable_col2im_coord_gpu_kernel L560-627 with batch_size = 1
+    {
+      const int cpg = C * kk / dg;
+      const int offset_channels = 2 * kk * dg;
+      const long n = (long)Ho * Wo * offset_channels;
+      for (long index = 0; index < n; index++) {
+        float val = 0, mval = 0;
+        int w = index % Wo;
+        int h = (index / Wo) % Ho;
+        int c = (index / Wo / Ho) % offset_channels;
+        const int g = c / (2 * kk);
+        const int col_step = kk;
+        int cnt = 0;
+        const float* col_ptr = col.data() + (size_t)g * cpg * Wo * Ho;
+        const float* im_ptr = in_n + (size_t)g * cpg / kh / kw * H * W;
+        const float* off_ptr = off_n + (size_t)g * 2 * kk * P;
+        const float* mask_ptr = mask_n + (size_t)g * kk * P;
+        const int offset_c = c - g * 2 * kk;
+        for (int col_c = (offset_c / 2); col_c < cpg; col_c += col_step) {
+          const long col_pos = (((long)col_c * Ho) + h) * Wo + w;
+          const int bp_dir = offset_c % 2;
+          int j = (col_pos / Wo / Ho) % kw;
+          int i = (col_pos / Wo / Ho / kw) % kh;
+          int w_out = col_pos % Wo;
+          int h_out = (col_pos / Wo) % Ho;
+          int w_in = w_out * stride_w - pad_w;
+          int h_in = h_out * stride_h - pad_h;
+          const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_out) * Wo + w_out];
+          const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_out) * Wo + w_out];
+          const float m = mask_ptr[((i * kw + j) * Ho + h_out) * Wo + w_out];
+          float inv_h = h_in + i * dil_h + offset_h;
+          float inv_w = w_in + j * dil_w + offset_w;
+          if (inv_h <= -1 || inv_w <= -1 || inv_h >= H || inv_w >= W) {
+            inv_h = inv_w = -2;
+          } else {
+            mval += col_ptr[col_pos] * dcn_bilinear(im_ptr + (size_t)cnt * H * W, W, H, W, inv_h, inv_w);
+          }
+          const float weight_c = dcn_coordinate_weight(inv_h, inv_w, H, W, im_ptr + (size_t)cnt * H * W, W, bp_dir);
+          val += weight_c * col_ptr[col_pos] * m;
+          cnt += 1;
+        }
+        goff_n[index] = val;
+        if (offset_c % 2 == 0) gmask_n[(((size_t)g * kk + offset_c / 2) * Ho + h) * Wo + w] = mval;
+      }
+    }
+    // modulated_deformable_col2im_gpu_kernel L506-558, called with (pad_h, pad_h) (L651-653)
+    {
+      const int cpg = C / dg;
+      const int pad_w_used = pad_h;
+      const long n = (long)C * kk * Ho * Wo;
+      for (long index = 0; index < n; index++) {
+        const int j = (index / Wo / Ho) % kw;
+        const int i = (index / Wo / Ho / kw) % kh;
+        const int c = index / Wo / Ho / kw / kh;
+        const int g = c / cpg;
+        int w_out = index % Wo;
+        int h_out = (index / Wo) % Ho;
+        int w_in = w_out * stride_w - pad_w_used;
+        int h_in = h_out * stride_h - pad_h;
+        const float* off_ptr = off_n + (size_t)g * 2 * kk * P;
+        const float* mask_ptr = mask_n + (size_t)g * kk * P;
+        const float offset_h = off_ptr[((2 * (i * kw + j)) * Ho + h_out) * Wo + w_out];
+        const float offset_w = off_ptr[((2 * (i * kw + j) + 1) * Ho + h_out) * Wo + w_out];
+        const float m = mask_ptr[((i * kw + j) * Ho + h_out) * Wo + w_out];
+        const float cur_inv_h = h_in + i * dil_h + offset_h;
+        const float cur_inv_w = w_in + j * dil_w + offset_w;
+        const float cur_top_grad = col[index] * m;
+        const int cur_h = (int)cur_inv_h;
+        const int cur_w = (int)cur_inv_w;
+        for (int dy = -2; dy <= 2; dy++)
+          for (int dx = -2; dx <= 2; dx++)
+            if (cur_h + dy >= 0 && cur_h + dy < H && cur_w + dx >= 0 && cur_w + dx < W &&
+                fabsf(cur_inv_h - (cur_h + dy)) < 1 && fabsf(cur_inv_w - (cur_w + dx)) < 1) {
+              size_t pos = ((size_t)c * H + cur_h + dy) * W + cur_w + dx;
+              float wgt = dcn_gradient_weight(cur_inv_h, cur_inv_w, cur_h + dy, cur_w + dx, H, W);
+              gi_n[pos] += wgt * cur_top_grad;
+            }
+      }
+    }
+    // grad_weight += grad_output . columns(input)^T, grad_bias += grad_output . ones   (L746-776)
+    dcn2_im2col_image(in_n, off_n, mask_n, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, dg, Ho,
+                      Wo, col.data());
+#pragma omp parallel for schedule(static)
+    for (int co = 0; co < Cout; co++) {
+      for (int k = 0; k < K; k++) {
+        double acc = 0;
+        for (int q = 0; q < P; q++) acc += (double)go_n[(size_t)co * P + q] * col[(size_t)k * P + q];
+        gw[(size_t)co * K + k] += acc;
+      }
+      double sb = 0;
+      for (int q = 0; q < P; q++) sb += go_n[(size_t)co * P + q];
+      gb[co] += sb;
+    }
+  }
+  for (size_t i = 0; i < gw.size(); i++) grad_weight[i] = (float)gw[i];
+  for (int co = 0; co < Cout; co++) grad_bias[co] = (float)gb[co];
+}
+
+// ---------------------------------------------------------------------------
+// Deformable PSRoI pooling (ops/dcn_v2.py:L832-932 forward, L1007-1116 backward).  Parity status: UNPINNED by
+// reference execution (CUDA only); closed forms in tests/test_dcn_v2_oracle.py (affine map, adjoint, differences).
+// ---------------------------------------------------------------------------
+namespace {
+
+struct PsBin {
+  int n, ctop, ph, pw, batch, class_id, part_h, part_w, gh, gw;
+  float roi_w, roi_h, wstart, hstart, sub_w, sub_h;
+};
+
+// the per-element preamble shared by L866-902 and L1031-1062
+PsBin ps_bin(long index, const float* rois, const float* trans, int no_trans, float spatial_scale, int output_dim,
+             int group_size, int P, int part_size, int spp, float trans_std, int num_classes, int ch_each_class) {
+  PsBin b;
+  b.pw = index % P;
+  b.ph = (index / P) % P;
+  b.ctop = (index / P / P) % output_dim;
+  b.n = index / P / P / output_dim;
+  const float* r = rois + (size_t)b.n * 5;
+  b.batch = (int)r[0];
+  float roi_start_w = static_cast<float>(roundf(r[1])) * spatial_scale - 0.5;
+  float roi_start_h = static_cast<float>(roundf(r[2])) * spatial_scale - 0.5;
+  float roi_end_w = static_cast<float>(roundf(r[3]) + 1.) * spatial_scale - 0.5;
+  float roi_end_h = static_cast<float>(roundf(r[4]) + 1.) * spatial_scale - 0.5;
+  b.roi_w = std::max((double)(roi_end_w - roi_start_w), 0.1);
+  b.roi_h = std::max((double)(roi_end_h - roi_start_h), 0.1);
+  float bin_size_h = b.roi_h / static_cast<float>(P);
+  float bin_size_w = b.roi_w / static_cast<float>(P);
+  b.sub_h = bin_size_h / static_cast<float>(spp);
+  b.sub_w = bin_size_w / static_cast<float>(spp);
+  b.part_h = (int)floorf(static_cast<float>(b.ph) / P * part_size);
+  b.part_w = (int)floorf(static_cast<float>(b.pw) / P * part_size);
+  b.class_id = b.ctop / ch_each_class;
+  float trans_x = no_trans ? 0.f
+                           : trans[((((size_t)b.n * num_classes + b.class_id) * 2) * part_size + b.part_h) * part_size +
+                                   b.part_w] * trans_std;
+  float trans_y = no_trans ? 0.f
+                           : trans[((((size_t)b.n * num_classes + b.class_id) * 2 + 1) * part_size + b.part_h) *
+                                       part_size + b.part_w] * trans_std;
+  b.wstart = static_cast<float>(b.pw) * bin_size_w + roi_start_w;
+  b.wstart += trans_x * b.roi_w;
+  b.hstart = static_cast<float>(b.ph) * bin_size_h + roi_start_h;
+  b.hstart += trans_y * b.roi_h;
+  int gw = (int)floorf(static_cast<float>(b.pw) * group_size / P);
+  int gh = (int)floorf(static_cast<float>(b.ph) * group_size / P);
+  b.gw = std::min(std::max(gw, 0), group_size - 1);
+  b.gh = std::min(std::max(gh, 0), group_size - 1);
+  return b;
+}
+
+}  // namespace
+
+JO_API void jo_deform_psroi_forward(const float* input, const float* rois, const float* trans, int C, int H, int W,
+                                    int R, int no_trans, float spatial_scale, int output_dim, int group_size, int P,
+                                    int part_size, int spp, float trans_std, int trans_channels, float* out,
+                                    float* top_count) {
+  const int num_classes = no_trans ? 1 : trans_channels / 2;
+  const int cec = no_trans ? output_dim : output_dim / num_classes;
+  const long count = (long)R * output_dim * P * P;
+  for (long index = 0; index < count; index++) {
+    const PsBin b = ps_bin(index, rois, trans, no_trans, spatial_scale, output_dim, group_size, P, part_size, spp,
+                           trans_std, num_classes, cec);
+    float sum = 0;
+    int cnt = 0;
+    const float* data = input + (size_t)b.batch * C * H * W;
+    for (int ih = 0; ih < spp; ih++)
+      for (int iw = 0; iw < spp; iw++) {
+        float w = b.wstart + iw * b.sub_w;
+        float h = b.hstart + ih * b.sub_h;
+        if (w < -0.5 || w > W - 0.5 || h < -0.5 || h > H - 0.5) continue;
+        w = std::min(std::max((double)w, 0.), W - 1.);
+        h = std::min(std::max((double)h, 0.), H - 1.);
+        int c = (b.ctop * group_size + b.gh) * group_size + b.gw;
+        const float* plane = data + (size_t)c * H * W;
+        // bilinear_interp L832-854
+        int x1 = (int)floorf(w), x2 = (int)ceilf(w), y1 = (int)floorf(h), y2 = (int)ceilf(h);
+        float dist_x = static_cast<float>(w - x1), dist_y = static_cast<float>(h - y1);
+        float value11 = plane[y1 * W + x1], value12 = plane[y2 * W + x1];
+        float value21 = plane[y1 * W + x2], value22 = plane[y2 * W + x2];
+        float value = (1 - dist_x) * (1 - dist_y) * value11 + (1 - dist_x) * dist_y * value12 +
+                      dist_x * (1 - dist_y) * value21 + dist_x * dist_y * value22;
+        sum += value;
+        cnt++;
+      }
+    out[index] = cnt == 0 ? 0.f : sum / cnt;
+    top_count[index] = cnt;
+  }
+}
+
+JO_API void jo_deform_psroi_backward(const float* top_diff, const float* top_count, const float* input,
+                                     const float* rois, const float* trans, int N, int C, int H, int W, int R,
+                                     int no_trans, float spatial_scale, int output_dim, int group_size, int P,
+                                     int part_size, int spp, float trans_std, int trans_channels, float* grad_input,
+                                     float* grad_trans) {
+  const int num_classes = no_trans ? 1 : trans_channels / 2;
+  const int cec = no_trans ? output_dim : output_dim / num_classes;
+  memset(grad_input, 0, sizeof(float) * (size_t)N * C * H * W);
+  if (!no_trans) memset(grad_trans, 0, sizeof(float) * (size_t)R * trans_channels * part_size * part_size);
+  const long count = (long)R * output_dim * P * P;
+  for (long index = 0; index < count; index++) {
+    if (top_count[index] <= 0) continue;
+    const PsBin b = ps_bin(index, rois, trans, no_trans, spatial_scale, output_dim, group_size, P, part_size, spp,
+                           trans_std, num_classes, cec);
+    float diff_val = top_diff[index] / top_count[index];
+    const float* data = input + (size_t)b.batch * C * H * W;
+    float* gdata = grad_input + (size_t)b.batch * C * H * W;
+    for (int ih = 0; ih < spp; ih++)
+      for (int iw = 0; iw < spp; iw++) {
+        float w = b.wstart + iw * b.sub_w;
+        float h = b.hstart + ih * b.sub_h;
+        if (w < -0.5 || w > W - 0.5 || h < -0.5 || h > H - 0.5) continue;
+        w = std::min(std::max((double)w, 0.), W - 1.);
+        h = std::min(std::max((double)h, 0.), H - 1.);
+        int c = (b.ctop * group_size + b.gh) * group_size + b.gw;
+        int x0 = (int)floorf(w), x1 = (int)ceilf(w), y0 = (int)floorf(h), y1 = (int)ceilf(h);
+        float dist_x = w - x0, dist_y = h - y0;
+        float q00 = (1 - dist_x) * (1 - dist_y), q01 = (1 - dist_x) * dist_y;
+        float q10 = dist_x * (1 - dist_y), q11 = dist_x * dist_y;
+        size_t base = (size_t)c * H * W;
+        gdata[base + y0 * W + x0] += q00 * diff_val;
+        gdata[base + y1 * W + x0] += q01 * diff_val;
+        gdata[base + y0 * W + x1] += q10 * diff_val;
+        gdata[base + y1 * W + x1] += q11 * diff_val;
+        if (no_trans) continue;
+        float U00 = data[base + y0 * W + x0], U01 = data[base + y1 * W + x0];
+        float U10 = data[base + y0 * W + x1], U11 = data[base + y1 * W + x1];
+        float diff_x = (U11 * dist_y + U10 * (1 - dist_y) - U01 * dist_y - U00 * (1 - dist_y)) * trans_std * diff_val;
+        diff_x *= b.roi_w;
+        float diff_y = (U11 * dist_x + U01 * (1 - dist_x) - U10 * dist_x - U00 * (1 - dist_x)) * trans_std * diff_val;
+        diff_y *= b.roi_h;
+        grad_trans[((((size_t)b.n * num_classes + b.class_id) * 2) * part_size + b.part_h) * part_size + b.part_w] +=
+            diff_x;
+        grad_trans[((((size_t)b.n * num_classes + b.class_id) * 2 + 1) * part_size + b.part_h) * part_size +
+                   b.part_w] += diff_y;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Active rotating filter (ops/orn.py:L138-211 CPU kernels)
 //   weight (nOut, nIn, nOri, kH, kW) ; indices (nOri, kH, kW, nRot) uint8, 1-based
 //   output (nOut*nRot, nIn*nOri, kH, kW)

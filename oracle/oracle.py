@@ -152,6 +152,66 @@ def deform_col2im_coord(col, im, offset, kh, kw, pad, stride, dil, dg, _l=None,
     return goff
 
 
+def dcn_v2_forward(x, offset, mask, weight, bias, pad, stride, dil, dg):
+    """ops/dcn_v2.py:L11-306: (B,C,H,W), (B,dg*2*kk,Ho,Wo), (B,dg*kk,Ho,Wo), (Cout,C,kh,kw), (Cout,) -> (B,Cout,Ho,Wo)"""
+    x, offset, mask, weight, bias = _c(x), _c(offset), _c(mask), _c(weight), _c(bias)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = _dcn_out(H, W, kh, kw, pad, stride, dil)
+    out = np.zeros((B, Cout, Ho, Wo), np.float32)
+    lib().jo_dcn_v2_forward(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(bias), _i(B), _i(C), _i(H), _i(W),
+                            _i(Cout), _i(kh), _i(kw), _i(pad[0]), _i(pad[1]), _i(stride[0]), _i(stride[1]),
+                            _i(dil[0]), _i(dil[1]), _i(dg), _ptr(out))
+    return out
+
+
+def dcn_v2_backward(x, offset, mask, weight, grad_out, pad, stride, dil, dg):
+    """ops/dcn_v2.py:L308-781 -> (grad_input, grad_offset, grad_mask, grad_weight, grad_bias)"""
+    x, offset, mask, weight, grad_out = _c(x), _c(offset), _c(mask), _c(weight), _c(grad_out)
+    B, C, H, W = x.shape
+    Cout, _, kh, kw = weight.shape
+    gi, go, gm = np.zeros_like(x), np.zeros_like(offset), np.zeros_like(mask)
+    gw, gb = np.zeros_like(weight), np.zeros((Cout,), np.float32)
+    lib().jo_dcn_v2_backward(_ptr(x), _ptr(offset), _ptr(mask), _ptr(weight), _ptr(grad_out), _i(B), _i(C), _i(H),
+                             _i(W), _i(Cout), _i(kh), _i(kw), _i(pad[0]), _i(pad[1]), _i(stride[0]), _i(stride[1]),
+                             _i(dil[0]), _i(dil[1]), _i(dg), _ptr(gi), _ptr(go), _ptr(gm), _ptr(gw), _ptr(gb))
+    return gi, go, gm, gw, gb
+
+
+def _psroi_args(x, R, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, spp, trans_std, tch):
+    return (_i(x.shape[1]), _i(x.shape[2]), _i(x.shape[3]), _i(R), _i(int(no_trans)), _f(spatial_scale),
+            _i(output_dim), _i(group_size), _i(pooled_size), _i(part_size), _i(spp), _f(trans_std), _i(tch))
+
+
+def deform_psroi_forward(x, rois, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size,
+                         spp, trans_std):
+    """ops/dcn_v2.py:L808-985 -> (out, top_count), both (R, output_dim, P, P)"""
+    x, rois = _c(x), _c(rois)
+    trans = _c(trans) if trans is not None and not no_trans else np.zeros((0, 2, part_size, part_size), np.float32)
+    R = rois.shape[0]
+    out = np.zeros((R, output_dim, pooled_size, pooled_size), np.float32)
+    cnt = np.zeros_like(out)
+    tch = 2 if no_trans else trans.shape[1]
+    lib().jo_deform_psroi_forward(_ptr(x), _ptr(rois), _ptr(trans), *_psroi_args(
+        x, R, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, spp, trans_std, tch),
+        _ptr(out), _ptr(cnt))
+    return out, cnt
+
+
+def deform_psroi_backward(grad_out, top_count, x, rois, trans, no_trans, spatial_scale, output_dim, group_size,
+                          pooled_size, part_size, spp, trans_std):
+    """ops/dcn_v2.py:L988-1175 -> (grad_input, grad_trans)"""
+    grad_out, top_count, x, rois = _c(grad_out), _c(top_count), _c(x), _c(rois)
+    trans = _c(trans) if trans is not None and not no_trans else np.zeros((0, 2, part_size, part_size), np.float32)
+    R = rois.shape[0]
+    gi, gt = np.zeros_like(x), np.zeros_like(trans)
+    tch = 2 if no_trans else trans.shape[1]
+    a = _psroi_args(x, R, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, spp, trans_std, tch)
+    lib().jo_deform_psroi_backward(_ptr(grad_out), _ptr(top_count), _ptr(x), _ptr(rois), _ptr(trans), _i(x.shape[0]),
+                                   *a, _ptr(gi), _ptr(gt))
+    return gi, gt
+
+
 def arf_forward(weight, indices, _l=None, _name="jo_arf_forward"):
     weight, indices = _c(weight), _c(indices, np.uint8)
     nOut, nIn, nOri, kH, kW = weight.shape

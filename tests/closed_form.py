@@ -102,9 +102,10 @@ def roi_align_expected(variant, coefs, rois, scale, PH, PW, n_orient=1):
     return out
 
 
-def deform_conv_integer_expected(x, w, dy, dx, pad, stride=1, dil=1):
+def deform_conv_integer_expected(x, w, dy, dx, pad, stride=1, dil=1, mask=None):
     """y[b,o,i,j] = sum_{c,ky,kx} w[o,c,ky,kx] * X[b,c, i*stride - pad + ky*dil + dy[ky,kx], j*stride - pad + kx*dil + dx[ky,kx]]
-    with zeros outside the image; dy, dx integer arrays (kh, kw).  float64."""
+    with zeros outside the image; dy, dx integer arrays (kh, kw).  float64.  mask (B, kh*kw, Ho, Wo): the modulated
+    (DCN v2) form, every tap's contribution scaled by its mask value at the output position."""
     B, C, H, W = x.shape
     O, _, kh, kw = w.shape
     Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -118,7 +119,8 @@ def deform_conv_integer_expected(x, w, dy, dx, pad, stride=1, dil=1):
             oy = big - pad + ky * dil + int(dy[ky, kx])
             ox = big - pad + kx * dil + int(dx[ky, kx])
             patch = xp[:, :, oy:oy + (Ho - 1) * stride + 1:stride, ox:ox + (Wo - 1) * stride + 1:stride]
-            y += np.einsum("oc,bchw->bohw", w[:, :, ky, kx].astype(np.float64), patch)
+            t = np.einsum("oc,bchw->bohw", w[:, :, ky, kx].astype(np.float64), patch)
+            y += t if mask is None else t * mask[:, ky * kw + kx][:, None].astype(np.float64)
     return y
 
 
@@ -271,3 +273,44 @@ def boundary_roi(variant, sx, sy, w=1.0, h=1.0):
 # a 2x2-sample bin straddling the left border: RoI 2x2 centred at (-1, 1): samples x in {-1.5, -0.5}, y in {0.5, 1.5};
 # x = -1.5 is dropped, x = -0.5 moves to column 0: (1 + 4)/2 + (4 + 7)/2 = 8, divisor 4 -> 2.0
 BOUNDARY_STRADDLE = (-1.0, 1.0, 2.0, 2.0, 2.0)   # (centre x, centre y, w, h, expected)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Deformable PSRoI pooling (ops/dcn_v2.py:L855-932) on an affine map: bilinear interpolation reproduces an affine
+# function exactly, so with every sample inside the image the pooled value is the map at the MEAN sample position:
+#   roi_start = round(x1) * scale - 0.5,  roi_end = (round(x2) + 1) * scale - 0.5,  roi_w = max(end - start, 0.1)
+#   bin (ph, pw) starts at pw * roi_w / P + roi_start_w + trans_x * trans_std * roi_w; samples step by bin / spp
+#   channel of output channel ctop in that bin: (ctop * G + floor(ph * G / P)) * G + floor(pw * G / P)
+#   trans_x = trans[n, 2 * class, part_h, part_w], trans_y = trans[n, 2 * class + 1, ...], class = ctop // (dim / classes)
+def psroi_expected(coef, rois, trans, scale, output_dim, G, P, part, spp, trans_std):
+    """coef = (a, b, d) per input channel (f_c(x, y) = a_c x + b_c y + d_c); returns (R, output_dim, P, P) float64 and
+    the derivative of every output w.r.t. its own (trans_x, trans_y) pair, (R, output_dim, P, P, 2)"""
+    a, b, d = [np.asarray(v, np.float64) for v in coef]
+    R = rois.shape[0]
+    ncls = 1 if trans is None else trans.shape[1] // 2
+    cec = output_dim // ncls
+    out = np.zeros((R, output_dim, P, P))
+    dtr = np.zeros((R, output_dim, P, P, 2))
+    for n in range(R):
+        x1, y1, x2, y2 = [float(np.round(v)) for v in rois[n, 1:5]]
+        sw, sh = x1 * scale - 0.5, y1 * scale - 0.5
+        ew, eh = (x2 + 1.0) * scale - 0.5, (y2 + 1.0) * scale - 0.5
+        rw, rh = max(ew - sw, 0.1), max(eh - sh, 0.1)
+        bw, bh = rw / P, rh / P
+        for ct in range(output_dim):
+            cls = ct // cec
+            for ph in range(P):
+                for pw in range(P):
+                    part_h, part_w = int(np.floor(ph / P * part)), int(np.floor(pw / P * part))
+                    tx = ty = 0.0
+                    if trans is not None:
+                        tx = float(trans[n, 2 * cls, part_h, part_w]) * trans_std
+                        ty = float(trans[n, 2 * cls + 1, part_h, part_w]) * trans_std
+                    mw = pw * bw + sw + tx * rw + (spp - 1) / 2.0 * (bw / spp)
+                    mh = ph * bh + sh + ty * rh + (spp - 1) / 2.0 * (bh / spp)
+                    gw = min(max(int(np.floor(pw * G / P)), 0), G - 1)
+                    gh = min(max(int(np.floor(ph * G / P)), 0), G - 1)
+                    c = (ct * G + gh) * G + gw
+                    out[n, ct, ph, pw] = a[c] * mw + b[c] * mh + d[c]
+                    dtr[n, ct, ph, pw] = (a[c] * trans_std * rw, b[c] * trans_std * rh)
+    return out, dtr
