@@ -182,3 +182,154 @@ def oriented_rpn_proposals_single(cls_scores, bbox_preds, mlvl_anchors, nms_pre=
     keep = hbb_nms(h, sc, nms_thresh)                                                                   # L214-215
     dets = np.concatenate([prop, sc[:, None]], 1)[keep]
     return dets[:nms_post]
+
+
+def softmax_cross_entropy(cls_score, labels, weights, avg_factor):
+    """models/losses/cross_entropy_loss.py:L6-13 (weighted_cross_entropy): sum(w * CE) / avg_factor"""
+    z = cls_score.astype(np.float64)
+    z = z - z.max(1, keepdims=True)
+    logp = z - np.log(np.exp(z).sum(1, keepdims=True))
+    raw = -logp[np.arange(z.shape[0]), labels]
+    return float((raw * weights).sum() / avg_factor)
+
+
+def oriented_head_targets(proposals, gt_rboxes, gt_labels_1based, num_classes=15, pos_iou_thr=0.5, neg_iou_thr=0.5,
+                          min_pos_iou=0.5, means=(0.,) * 5, stds=(0.1, 0.1, 0.2, 0.2, 0.1)):
+    """models/roi_heads/oriented_head.py:L444-501 + L339-392 for ONE image when the sampler keeps every candidate
+    (fewer than `num` candidates, positives within the quota): angle negation (L459-466), 0-based labels (L472),
+    MaxIoUAssigner on the v1 rotated IoU with match_low_quality=False, gts prepended as proposals matched to
+    themselves (sampler.py:L92-99), then get_bboxes_target_single: positives first, negatives after.
+    Returns (boxes (n,5), labels (n,), label_weights (n,), bbox_targets (n,5), bbox_weights (n,5))."""
+    gt = np.asarray(gt_rboxes, np.float32).copy()
+    gt[:, -1] *= -1
+    gl = np.asarray(gt_labels_1based, np.int64) - 1
+    props = np.asarray(proposals, np.float32)[:, :5]
+    overlaps = O.box_iou_rotated(gt, props, version=1)
+    gt_inds, _, _ = B.assign_wrt_overlaps(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_quality=False,
+                                          gt_labels=gl.astype(np.int32), labels_filled=-1)
+    boxes = np.concatenate([gt, props], 0)
+    gt_inds = np.concatenate([np.arange(1, gt.shape[0] + 1), gt_inds.astype(np.int64)])
+    pos, neg = np.nonzero(gt_inds > 0)[0], np.nonzero(gt_inds == 0)[0]
+    n = len(pos) + len(neg)
+    labels = np.full((n,), num_classes, np.int64)
+    labels[:len(pos)] = gl[gt_inds[pos] - 1]
+    label_weights = np.ones((n,), np.float32)
+    bbox_targets = np.zeros((n, 5), np.float32)
+    bbox_weights = np.zeros((n, 5), np.float32)
+    if len(pos):
+        bbox_targets[:len(pos)] = B.oriented_delta_encode(boxes[pos], gt[gt_inds[pos] - 1], means, stds)
+        bbox_weights[:len(pos)] = 1
+    return np.concatenate([boxes[pos], boxes[neg]], 0), labels, label_weights, bbox_targets, bbox_weights
+
+
+def oriented_head_loss(per_image_targets, trunk, num_classes=15, beta=1.0):
+    """oriented_head.py:L318-343: per_image_targets = list of oriented_head_targets(...) tuples; trunk(boxes (n,5)) ->
+    (cls_score (n, C+1), bbox_pred (n, 5)) stands for RoI extraction + the FC layers (class-agnostic regression)."""
+    boxes, labels, lw, bt, bw = [np.concatenate([t[k] for t in per_image_targets], 0) for k in range(5)]
+    cls_score, bbox_pred = trunk(boxes)
+    avg = max(float((lw > 0).sum()), 1.0)
+    loss_cls = softmax_cross_entropy(cls_score, labels, lw, avg)
+    pos = (labels >= 0) & (labels < num_classes)
+    loss_bbox = 0.0
+    if pos.any():
+        loss_bbox = float(smooth_l1_loss(bbox_pred[pos], bt[pos], bw[pos], beta, avg_factor=bt.shape[0]))
+    return dict(loss_cls=loss_cls, orcnn_bbox_loss=loss_bbox)
+
+
+def oriented_head_detections(proposals, cls_score, bbox_pred, scale_factor=1.0, score_thresh=0.05, means=(0.,) * 5,
+                             stds=(0.1, 0.1, 0.2, 0.2, 0.1)):
+    """oriented_head.py:L404-440 + get_results L242-268 for one image: softmax, class-agnostic decode, rescale the
+    first four box parameters, every (row, class) pair above the threshold in row-major order -> (polys (k,8),
+    scores (k,), labels (k,) 0-based).  (No NMS here: the network's merge step applies it.)"""
+    z = cls_score.astype(np.float64)
+    z = z - z.max(1, keepdims=True)
+    scores = (np.exp(z) / np.exp(z).sum(1, keepdims=True)).astype(np.float32)
+    dec = B.oriented_delta_decode(np.asarray(proposals, np.float32)[:, :5], bbox_pred, means, stds).reshape(-1, 5).copy()
+    dec[:, :4] /= scale_factor
+    fg = scores[:, :-1]
+    ri, ci = np.nonzero(fg > score_thresh)
+    return B.obb2poly(dec[ri]), fg[ri, ci], ci
+
+
+def hbb_overlaps(b1, b2, version=0, eps=1e-6):
+    """models/boxes/iou_calculator.py:L302-343 (mode "iou", not aligned): `version` is the +1 px convention"""
+    b1, b2 = np.asarray(b1, np.float32), np.asarray(b2, np.float32)
+    v = np.float32(version)
+    a1 = (b1[:, 2] - b1[:, 0] + v) * (b1[:, 3] - b1[:, 1] + v)
+    a2 = (b2[:, 2] - b2[:, 0] + v) * (b2[:, 3] - b2[:, 1] + v)
+    lt = np.maximum(b1[:, None, :2], b2[None, :, :2])
+    rb = np.minimum(b1[:, None, 2:], b2[None, :, 2:])
+    wh = np.clip(rb - lt + v, 0, None)
+    overlap = wh[..., 0] * wh[..., 1]
+    union = np.maximum(a1[:, None] + a2[None, :] - overlap, np.float32(eps))
+    return (overlap / union).astype(np.float32)
+
+
+def _sampled_all(boxes, gt_inds, is_gt):
+    """RandomSampler when every candidate fits (sampler.py:L114-168): positives first, then negatives"""
+    pos, neg = np.nonzero(gt_inds > 0)[0], np.nonzero(gt_inds == 0)[0]
+    order = np.concatenate([pos, neg])
+    return boxes[order], gt_inds[order], is_gt[order], len(pos)
+
+
+def roitrans_rcnn_losses(proposals, gt_hbbs, gt_obbs, gt_labels, trunk1, trunk2, w_enlarge=1.2, h_enlarge=1.4,
+                         stds1=(0.1, 0.1, 0.2, 0.2, 0.1), stds2=(0.05, 0.05, 0.1, 0.1, 0.05), num_classes=16):
+    """models/networks/roi_transformer.py:L71-134 with rbbox_head.py (targets L9-121, loss L398-423, refinement
+    L425-448), for samplers that keep every candidate.  proposals: per image (P, 4) horizontal boxes; labels 1-based
+    (0 = background).  trunk1(rois (n,5) [img, hbb]) -> (cls (n,C), reg (n,5)); trunk2(rrois (n,6) [img, obb]) ->
+    (cls (n,C), reg (n,5*C)).  Returns {"s0.rbbox_loss_cls", "s0.rbbox_loss_bbox", "s1...."}."""
+    zeros5 = (0.,) * 5
+    # ---- stage 1: horizontal proposals -> rotated RoIs
+    rows = []
+    for i, (p, gh, go, gl) in enumerate(zip(proposals, gt_hbbs, gt_obbs, gt_labels)):
+        ov = hbb_overlaps(gh, p, version=1)                                    # BboxOverlaps2D_v1
+        gt_inds, _, _ = B.assign_wrt_overlaps(ov, 0.5, 0.5, 0.5, match_low_quality=True, gt_labels=None)
+        boxes = np.concatenate([gh.astype(np.float32), p.astype(np.float32)], 0)
+        gt_inds = np.concatenate([np.arange(1, gh.shape[0] + 1), gt_inds.astype(np.int64)])
+        is_gt = np.concatenate([np.ones(gh.shape[0], bool), np.zeros(p.shape[0], bool)])
+        boxes, gt_inds, is_gt, npos = _sampled_all(boxes, gt_inds, is_gt)
+        labels = np.zeros(boxes.shape[0], np.int64)
+        labels[:npos] = gl[gt_inds[:npos] - 1]
+        bt, bw = np.zeros((boxes.shape[0], 5), np.float32), np.zeros((boxes.shape[0], 5), np.float32)
+        bt[:npos] = B.dbbox2delta_v3(B.hbb2obb_v2(boxes[:npos]), B.choose_best_obb_batch(go[gt_inds[:npos] - 1]),
+                                     zeros5, stds1)
+        bw[:npos] = 1
+        rows.append((np.concatenate([np.full((boxes.shape[0], 1), i, np.float32), boxes], 1), labels, bt, bw, is_gt))
+    rois, labels, bt, bw = [np.concatenate([r[k] for r in rows], 0) for k in range(4)]
+    cls, reg = trunk1(rois)
+    n = float(rois.shape[0])
+    out = {"s0.rbbox_loss_cls": softmax_cross_entropy(cls, labels, np.ones(len(labels), np.float32), n),
+           "s0.rbbox_loss_bbox": float(smooth_l1_loss(reg[labels > 0], bt[labels > 0], bw[labels > 0], 1.0,
+                                                      avg_factor=n))}
+    # ---- refinement: regress every sampled row, keep the ones that were not gts (L425-448)
+    droi = np.concatenate([rois[:, :1], B.hbb2obb_v2(rois[:, 1:])], 1)
+    refined = B.choose_best_Rroi_batch(B.delta2dbbox(droi[:, 1:], reg, zeros5, stds1, 1.0))
+    # ---- stage 2: rotated RoIs -> detections
+    rows2, start = [], 0
+    for i, (r, go, gl) in enumerate(zip(rows, gt_obbs, gt_labels)):
+        k = r[0].shape[0]
+        cand = refined[start:start + k][~r[4]]
+        start += k
+        gbest = B.choose_best_Rroi_batch(go.astype(np.float32))
+        ov = O.box_iou_rotated(gbest, cand, version=0)                         # BboxOverlaps2D_rotated
+        gt_inds, _, _ = B.assign_wrt_overlaps(ov, 0.5, 0.5, 0.5, match_low_quality=True, gt_labels=None)
+        boxes = np.concatenate([gbest, cand], 0)
+        gt_inds = np.concatenate([np.arange(1, gbest.shape[0] + 1), gt_inds.astype(np.int64)])
+        boxes, gt_inds, _, npos = _sampled_all(boxes, gt_inds, np.zeros(boxes.shape[0], bool))
+        labels = np.zeros(boxes.shape[0], np.int64)
+        labels[:npos] = gl[gt_inds[:npos] - 1]
+        bt, bw = np.zeros((boxes.shape[0], 5), np.float32), np.zeros((boxes.shape[0], 5), np.float32)
+        bt[:npos] = B.best_match_dbbox2delta(boxes[:npos], gbest[gt_inds[:npos] - 1], zeros5, stds2)
+        bw[:npos] = 1
+        rows2.append((np.concatenate([np.full((boxes.shape[0], 1), i, np.float32), boxes], 1), labels, bt, bw))
+    rrois, labels, bt, bw = [np.concatenate([r[k] for r in rows2], 0) for k in range(4)]
+    enl = rrois.copy()
+    enl[:, 3] *= w_enlarge
+    enl[:, 4] *= h_enlarge
+    cls, reg = trunk2(enl)
+    n = float(rrois.shape[0])
+    pos = labels > 0
+    pred = reg.reshape(reg.shape[0], num_classes, 5)[np.nonzero(pos)[0], labels[pos]]
+    out["s1.rbbox_loss_cls"] = softmax_cross_entropy(cls, labels, np.ones(len(labels), np.float32), n)
+    out["s1.rbbox_loss_bbox"] = float(smooth_l1_loss(pred, bt[pos], bw[pos], 1.0, avg_factor=n))
+    return out
