@@ -229,6 +229,20 @@ int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin
                                const float* bias, int relu, const float* rowmask, const float* offset,
                                int tile, float* y_nhwc, jdet_stream_t stream);
 
+/* RepPoints geometry on 9-point sets (pointsets (N,18) = 9 (x,y) pairs) and the Graham scan of the polygon-IoU loss.
+ * jdet_convex_iou: replaces convex_iou_kernel (ops/reppoints_convex_iou/convex_iou_kernel.cu:L258-305): IoU of the
+ *   convex hull of every point set with every quadrilateral polygons (M,8) -> ious (N,M), computed in double.
+ * jdet_min_area_bbox: replaces minareabbox_kernel (ops/reppoints_min_area_bbox/min_area_bbox.cu:L49-203, L301-461):
+ *   minimum-area rectangle of the hull -> bboxes (N,8), corners (xmax,ymin) (xmin,ymin) (xmin,ymax) (xmax,ymax) of the
+ *   rotated frame.
+ * jdet_convex_sort: replaces convex_sort_gpu (ops/convex_sort.py:L4-65, L159-194): pts (nbs,npts,2), masks (nbs,npts)
+ *   as float 0/1 -> index (nbs, npts + circular) int32 hull indices in scan order, -1 in unused slots (the kernel
+ *   writes every slot); npts <= 64, else JDET_E_UNSUPPORTED. */
+int jdet_convex_iou(const float* pointsets, int N, const float* polygons, int M, float* ious, jdet_stream_t stream);
+int jdet_min_area_bbox(const float* pointsets, int N, float* bboxes, jdet_stream_t stream);
+int jdet_convex_sort(const float* pts, const float* masks, int nbs, int npts, int circular, int32_t* index,
+                     jdet_stream_t stream);
+
 /* Sigmoid focal loss, replaces the tensor-op chain of models/losses/focal_loss.py:L5-96 (sigmoid_focal_loss with
  * binary_cross_entropy_with_logits): logits (M, C) row-major, labels (M) int32 (0 = background, k = class k),
  * weight (M) or NULL; alpha < 0 disables the alpha term.  *loss_sum = sum over all M*C elements (the caller divides

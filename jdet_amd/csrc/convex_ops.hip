@@ -1,0 +1,372 @@
+// RepPoints geometry on 9-point sets, and the Graham scan of the polygon-IoU loss, for gfx950.
+//
+// Reference (CUDA only):
+//   convex_iou      ops/reppoints_convex_iou/convex_iou_kernel.cu   (IoU of the hull of 9 points with a quadrilateral)
+//   min_area_bbox   ops/reppoints_min_area_bbox/min_area_bbox.cu    (minimum-area rectangle of the hull of 9 points)
+//   convex_sort     ops/convex_sort.py:L4-65, L159-194              (start point, angular order, Graham scan -> indices)
+// What has to come out:
+//   * hull: Jarvis march in two chains from the lowest point (ties: smaller x) to the highest (ties: larger x), the
+//     right chain by the most clockwise candidate, the left chain by the most counter-clockwise one, collinear
+//     candidates resolved by the larger distance; turn test in double, distances in the coordinate type (double for
+//     the IoU, float for the rectangle) -- convex_iou_kernel.cu:L157-256, min_area_bbox.cu:L205-299
+//   * IoU: both polygons made counter-clockwise, intersection area = sum over edge pairs of the signed area of
+//     triangle(0, a, b) /\ triangle(0, c, d), each by three half-plane cuts with eps = 1e-8 sign tests (L60-155);
+//     iou = inter / (|hull| + |quad| - inter), all in double, returned as float (L258-290)
+//   * rectangle: for every distinct edge direction (atan2 folded into [0, pi/2), float), rotate the hull by
+//     R = [[cos a, cos(a - pi/2)], [cos(a + pi/2), cos a]] (pi = 3.1415926f), keep the smallest axis-aligned extent;
+//     corners (xmax,ymin) (xmin,ymin) (xmin,ymax) (xmax,ymax) rotated back (L49-203, L301-399)
+//   * convex_sort: start = first lowest unmasked point, candidates by decreasing cosine to the start (stable), Graham
+//     scan skipping masked points and points closer than 1e-3 to the stack top; -1 fills the unused index slots
+// Execution: one thread per (point set, polygon) pair resp. per point set; the work is a few hundred flops on
+// thread-private arrays, tens of thousands of pairs per call: latency-insensitive, nowhere near any roofline.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct Pt {
+  T x, y;
+};
+
+__device__ __forceinline__ double crossd(double ox, double oy, double ax, double ay, double bx, double by) {
+  return (ax - ox) * (by - oy) - (bx - ox) * (ay - oy);
+}
+
+template <typename T>
+__device__ __forceinline__ T dis2(const Pt<T>& a, const Pt<T>& b) {
+  return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);
+}
+
+// Jarvis march of the reference (see header).  p[0..n) is reordered in place into the hull, n becomes its size.
+// Loop caps (the reference has none): a chain of 9 points has at most 9 steps.
+template <typename T>
+__device__ void jarvis(Pt<T>* p, int& n) {
+  Pt<T> p_max = p[0], p_k;
+  int max_index = 0, k_index;
+  int stack[20], top1, top2;
+  Pt<T> right[20], left[20];
+  for (int i = 0; i < n; i++) {
+    if (p[i].y < p[0].y || (p[i].y == p[0].y && p[i].x < p[0].x)) {
+      const Pt<T> t = p[0];
+      p[0] = p[i];
+      p[i] = t;
+    }
+    if (i == 0) {
+      p_max = p[0];
+      max_index = 0;
+    }
+    if (p[i].y > p_max.y || (p[i].y == p_max.y && p[i].x > p_max.x)) {
+      p_max = p[i];
+      max_index = i;
+    }
+  }
+  if (max_index == 0) {
+    max_index = 1;
+    p_max = p[max_index];
+  }
+  k_index = 0, stack[0] = 0, top1 = 0;
+  while (k_index != max_index && top1 < 18) {
+    p_k = p_max;
+    k_index = max_index;
+    const Pt<T> s = p[stack[top1]];
+    for (int i = 1; i < n; i++) {
+      const double sign = crossd(s.x, s.y, p[i].x, p[i].y, p_k.x, p_k.y);
+      if (sign > 0 || (sign == 0 && dis2(s, p[i]) > dis2(s, p_k))) {
+        p_k = p[i];
+        k_index = i;
+      }
+    }
+    top1++;
+    stack[top1] = k_index;
+  }
+  for (int i = 0; i <= top1; i++) right[i] = p[stack[i]];
+  k_index = 0, stack[0] = 0, top2 = 0;
+  while (k_index != max_index && top2 < 18) {
+    p_k = p_max;
+    k_index = max_index;
+    const Pt<T> s = p[stack[top2]];
+    for (int i = 1; i < n; i++) {
+      const double sign = crossd(s.x, s.y, p[i].x, p[i].y, p_k.x, p_k.y);
+      if (sign < 0 || (sign == 0 && dis2(s, p[i]) > dis2(s, p_k))) {
+        p_k = p[i];
+        k_index = i;
+      }
+    }
+    top2++;
+    stack[top2] = k_index;
+  }
+  for (int i = top2 - 1; i >= 0; i--) left[i] = p[stack[i]];
+  const int m = min(top1 + top2, 19);
+  for (int i = 0; i < m; i++) p[i] = i <= top1 ? right[i] : left[top2 - (i - top1)];
+  n = m;
+}
+
+// ------------------------------------------------------------------------------------------------ convex IoU (double)
+typedef Pt<double> P2;
+constexpr double kEps = 1E-8;
+
+__device__ __forceinline__ int sig(double d) { return (int)(d > kEps) - (int)(d < -kEps); }
+__device__ __forceinline__ bool same_pt(const P2& a, const P2& b) { return sig(a.x - b.x) == 0 && sig(a.y - b.y) == 0; }
+__device__ __forceinline__ double cross3(const P2& o, const P2& a, const P2& b) {
+  return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y);
+}
+
+// shoelace area of ps[0..n); writes the closing point ps[n] like the reference (callers provide n + 1 slots)
+__device__ double poly_area(P2* ps, int n) {
+  ps[n] = ps[0];
+  double res = 0;
+  for (int i = 0; i < n; i++) res += ps[i].x * ps[i + 1].y - ps[i].y * ps[i + 1].x;
+  return res / 2.0;
+}
+
+__device__ void line_cross(const P2& a, const P2& b, const P2& c, const P2& d, P2& p) {
+  const double s1 = cross3(a, b, c), s2 = cross3(a, b, d);
+  if (sig(s1) == 0 && sig(s2) == 0) return;
+  if (sig(s2 - s1) == 0) return;
+  p.x = (c.x * s2 - d.x * s1) / (s2 - s1);
+  p.y = (c.y * s2 - d.y * s1) / (s2 - s1);
+}
+
+// keep the part of p left of a -> b (L82-110); p has room for 10 points
+__device__ void polygon_cut(P2* p, int& n, const P2& a, const P2& b) {
+  P2 pp[12];
+  int m = 0;
+  p[n] = p[0];
+  for (int i = 0; i < n && m < 11; i++) {
+    if (sig(cross3(a, b, p[i])) > 0) pp[m++] = p[i];
+    if (sig(cross3(a, b, p[i])) != sig(cross3(a, b, p[i + 1]))) {
+      pp[m] = P2{0., 0.};     // (the reference leaves the slot as it was when the lines do not cross)
+      line_cross(a, b, p[i], p[i + 1], pp[m]);
+      m++;
+    }
+  }
+  n = 0;
+  for (int i = 0; i < m; i++)
+    if (!i || !same_pt(pp[i], pp[i - 1])) p[n++] = pp[i];
+  while (n > 1 && same_pt(p[n - 1], p[0])) n--;
+}
+
+// signed area of triangle(0, a, b) /\ triangle(0, c, d) (L113-140)
+__device__ double intersect_area(P2 a, P2 b, P2 c, P2 d) {
+  const P2 o{0., 0.};
+  const int s1 = sig(cross3(o, a, b)), s2 = sig(cross3(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.0;
+  if (s1 == -1) { const P2 t = a; a = b; b = t; }
+  if (s2 == -1) { const P2 t = c; c = d; d = t; }
+  P2 p[12] = {o, a, b};
+  int n = 3;
+  polygon_cut(p, n, o, c);
+  polygon_cut(p, n, c, d);
+  polygon_cut(p, n, d, o);
+  double res = poly_area(p, n);
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+
+__device__ void make_ccw(P2* ps, int n) {
+  if (poly_area(ps, n) < 0)
+    for (int i = 0; i < n / 2; i++) {
+      const P2 t = ps[i];
+      ps[i] = ps[n - 1 - i];
+      ps[n - 1 - i] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void convex_iou_kernel(const float* __restrict__ pointsets,
+                                                       const float* __restrict__ polygons, int N, int M,
+                                                       float* __restrict__ ious) {
+  const long idx = (long)blockIdx.x * 64 + threadIdx.x;
+  if (idx >= (long)N * M) return;
+  const int i = (int)(idx / M), j = (int)(idx - (long)i * M);
+  P2 hull[20], quad[6];
+  for (int k = 0; k < 9; k++) hull[k] = P2{(double)pointsets[(size_t)i * 18 + 2 * k], (double)pointsets[(size_t)i * 18 + 2 * k + 1]};
+  int n1 = 9;
+  jarvis<double>(hull, n1);
+  for (int k = 0; k < 4; k++) quad[k] = P2{(double)polygons[(size_t)j * 8 + 2 * k], (double)polygons[(size_t)j * 8 + 2 * k + 1]};
+  const int n2 = 4;
+  make_ccw(hull, n1);
+  make_ccw(quad, n2);
+  hull[n1] = hull[0];
+  quad[n2] = quad[0];
+  double inter = 0;
+  for (int a = 0; a < n1; a++)
+    for (int b = 0; b < n2; b++) inter += intersect_area(hull[a], hull[a + 1], quad[b], quad[b + 1]);
+  const double s_pred = poly_area(hull, n1);
+  const double uni = fabs(s_pred) + fabs(poly_area(quad, n2)) - inter;
+  ious[idx] = (float)(inter / uni);
+}
+
+// ------------------------------------------------------------------------------------------- minimum-area rectangle
+typedef Pt<float> P2f;
+
+__global__ __launch_bounds__(64) void min_area_bbox_kernel(const float* __restrict__ pointsets, int N,
+                                                          float* __restrict__ bboxes) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= N) return;
+  const float pi = 3.1415926f;
+  P2f ps[21];
+  for (int k = 0; k < 9; k++) ps[k] = P2f{pointsets[(size_t)idx * 18 + 2 * k], pointsets[(size_t)idx * 18 + 2 * k + 1]};
+  int n1 = 9;
+  jarvis<float>(ps, n1);
+  ps[n1] = ps[0];
+  const int n_points = n1 + 1, n_edges = n1;
+  // edge directions folded into [0, pi/2) (L68-84), distinct values only (L85-104)
+  float uniq[20];
+  int n_unique = 0;
+  for (int i = 0; i < n_edges; i++) {
+    const float ex = ps[i + 1].x - ps[i].x, ey = ps[i + 1].y - ps[i].y;
+    float ang = (float)atan2((double)ey, (double)ex);
+    if (ang >= 0)
+      ang = (float)fmod((double)ang, (double)pi / 2);
+    else
+      ang = ang - (int)(ang / (pi / 2) - 1) * (pi / 2);
+    bool seen = false;
+    for (int j = 0; j < n_unique; j++) seen = seen || ang == uniq[j];
+    if (i == 0 || !seen) uniq[n_unique++] = ang;
+  }
+  float minarea = 1e12f, box[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < n_unique; u++) {
+    const float r00 = cosf(uniq[u]), r01 = cosf(uniq[u] - pi / 2), r10 = cosf(uniq[u] + pi / 2), r11 = cosf(uniq[u]);
+    float xmin = 1e12f, ymin = 1e12f, xmax = -1e12f, ymax = -1e12f;
+    for (int k = 0; k < n_points; k++) {
+      float rx = 0.0f, ry = 0.0f;
+      rx = rx + r00 * ps[k].x;
+      rx = rx + r01 * ps[k].y;
+      ry = ry + r10 * ps[k].x;
+      ry = ry + r11 * ps[k].y;
+      if (!(isinf(rx) || isnan(rx))) {
+        if (rx < xmin) xmin = rx;
+        if (rx > xmax) xmax = rx;
+      }
+      if (!(isinf(ry) || isnan(ry))) {
+        if (ry < ymin) ymin = ry;
+        if (ry > ymax) ymax = ry;
+      }
+    }
+    const float area = (xmax - xmin) * (ymax - ymin);
+    if (area < minarea) {
+      minarea = area;
+      box[0] = uniq[u]; box[1] = xmin; box[2] = ymin; box[3] = xmax; box[4] = ymax;
+    }
+  }
+  const float a = box[0];
+  const float r00 = cosf(a), r01 = cosf(a - pi / 2), r10 = cosf(a + pi / 2), r11 = cosf(a);
+  const float cx[4] = {box[3], box[1], box[1], box[3]}, cy[4] = {box[2], box[2], box[4], box[4]};
+  for (int k = 0; k < 4; k++) {      // row vector x R (L330-396)
+    float sx = 0.0f, sy = 0.0f;
+    sx = sx + cx[k] * r00;
+    sx = sx + cy[k] * r10;
+    sy = sy + cx[k] * r01;
+    sy = sy + cy[k] * r11;
+    bboxes[(size_t)idx * 8 + 2 * k] = sx;
+    bboxes[(size_t)idx * 8 + 2 * k + 1] = sy;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- convex_sort
+constexpr int kSortMax = 64;
+
+__global__ __launch_bounds__(64) void convex_sort_kernel(const float* __restrict__ pts, const float* __restrict__ masks,
+                                                        int nbs, int npts, int circular, int* __restrict__ out) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= nbs) return;
+  const float* p = pts + (size_t)b * npts * 2;
+  const float* m = masks + (size_t)b * npts;
+  const int index_size = circular ? npts + 1 : npts;
+  int* idx = out + (size_t)b * index_size;
+  for (int i = 0; i < index_size; i++) idx[i] = -1;
+  // start: argmin of m * y + (1 - m) * 1e7, first minimum (convex_sort.py:L169-171)
+  int start = 0;
+  float best = 0.f;
+  for (int i = 0; i < npts; i++) {
+    const float v = m[i] * p[2 * i + 1] + (1 - m[i]) * 10000000.f;
+    if (i == 0 || v < best) {
+      best = v;
+      start = i;
+    }
+  }
+  const float sx = p[2 * start], sy = p[2 * start + 1];
+  // order: stable argsort of the cosine to the start point, descending (L175-176)
+  float key[kSortMax];
+  int order[kSortMax];
+  for (int i = 0; i < npts; i++) {
+    const float dx = p[2 * i] - sx, dy = p[2 * i + 1] - sy;
+    const float c = dx / sqrtf(dx * dx + dy * dy + 0.000001f);
+    int j = i;
+    while (j > 0 && key[j - 1] < c) {
+      key[j] = key[j - 1];
+      order[j] = order[j - 1];
+      j--;
+    }
+    key[j] = c;
+    order[j] = i;
+  }
+  // Graham scan (L4-65)
+  idx[0] = start;
+  int c_i = 0;
+  for (int _j = 0; _j < npts; _j++) {
+    const int j = order[_j];
+    if (j == start) continue;
+    if (m[j] < 0.5f) continue;
+    const float x0 = p[2 * j], y0 = p[2 * j + 1];
+    float x1 = p[2 * idx[c_i]], y1 = p[2 * idx[c_i] + 1];
+    const float d = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+    if ((double)d < 0.000001) continue;
+    if (c_i < 2) {
+      idx[++c_i] = j;
+    } else {
+      float x2 = p[2 * idx[c_i - 1]], y2 = p[2 * idx[c_i - 1] + 1];
+      while (1) {
+        const float t = (x1 - x2) * (y0 - y2) - (y1 - y2) * (x0 - x2);
+        if (t >= 0) {
+          idx[++c_i] = j;
+          break;
+        }
+        if (c_i <= 1) {
+          idx[c_i] = j;
+          break;
+        }
+        c_i--;
+        x1 = p[2 * idx[c_i]];
+        y1 = p[2 * idx[c_i] + 1];
+        x2 = p[2 * idx[c_i - 1]];
+        y2 = p[2 * idx[c_i - 1] + 1];
+      }
+    }
+  }
+  if (circular) idx[++c_i] = idx[0];
+}
+
+}  // namespace
+
+JDET_API int jdet_convex_iou(const float* pointsets, int N, const float* polygons, int M, float* ious,
+                             jdet_stream_t stream) {
+  if (N < 0 || M < 0) return JDET_E_BADARG;
+  if (N == 0 || M == 0) return JDET_OK;
+  if (!pointsets || !polygons || !ious) return JDET_E_BADARG;
+  const long pairs = (long)N * M;
+  if (pairs > (1L << 37)) return JDET_E_UNSUPPORTED;
+  hipLaunchKernelGGL(convex_iou_kernel, dim3((unsigned)((pairs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pointsets,
+                     polygons, N, M, ious);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_min_area_bbox(const float* pointsets, int N, float* bboxes, jdet_stream_t stream) {
+  if (N < 0) return JDET_E_BADARG;
+  if (N == 0) return JDET_OK;
+  if (!pointsets || !bboxes) return JDET_E_BADARG;
+  hipLaunchKernelGGL(min_area_bbox_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pointsets, N,
+                     bboxes);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_convex_sort(const float* pts, const float* masks, int nbs, int npts, int circular, int32_t* index,
+                              jdet_stream_t stream) {
+  if (nbs < 0 || npts < 0) return JDET_E_BADARG;
+  if (npts > kSortMax) return JDET_E_UNSUPPORTED;
+  if (nbs == 0 || npts == 0) return JDET_OK;     // (npts == 0: the caller's -1 fill is the result, L180-181)
+  if (!pts || !masks || !index) return JDET_E_BADARG;
+  hipLaunchKernelGGL(convex_sort_kernel, dim3((unsigned)((nbs + 63) / 64)), dim3(64), 0, (hipStream_t)stream, pts, masks,
+                     nbs, npts, circular ? 1 : 0, index);
+  return jdet_launch_status();
+}

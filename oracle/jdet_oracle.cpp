@@ -1017,6 +1017,396 @@ JO_API void jo_deform_psroi_backward(const float* top_diff, const float* top_cou
 }
 
 // ---------------------------------------------------------------------------
+// RepPoints geometry: convex IoU, minimum-area rectangle (CUDA-only reference text restated statement by statement),
+// and the Graham scan of convex_sort.  Parity status: UNPINNED by reference execution; pinned by exact geometry in
+// tests/test_convex_oracle.py (hulls of known point sets, analytic overlaps, rectangles of rotated boxes,
+// scipy.spatial.ConvexHull).
+// ---------------------------------------------------------------------------
+namespace cvx {
+
+const double eps = 1E-8;
+const int maxn = 100;
+
+inline int sig(double d) { return int(d > eps) - int(d < -eps); }
+
+struct Point {
+  double x, y;
+  Point() {}
+  Point(double x, double y) : x(x), y(y) {}
+};
+
+inline bool point_same(Point& a, Point& b) { return sig(a.x - b.x) == 0 && sig(a.y - b.y) == 0; }
+inline void swap1(Point* a, Point* b) {
+  Point temp = *a;
+  *a = *b;
+  *b = temp;
+}
+inline void reverse1(Point* a, const int n) {
+  Point temp[maxn];
+  for (int i = 0; i < n; i++) temp[i] = a[i];
+  for (int i = 0; i < n; i++) a[i] = temp[n - 1 - i];
+}
+inline double cross(Point o, Point a, Point b) { return (a.x - o.x) * (b.y - o.y) - (b.x - o.x) * (a.y - o.y); }
+inline double dis(Point a, Point b) { return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y); }
+inline double area(Point* ps, int n) {
+  ps[n] = ps[0];
+  double res = 0;
+  for (int i = 0; i < n; i++) res += ps[i].x * ps[i + 1].y - ps[i].y * ps[i + 1].x;
+  return res / 2.0;
+}
+inline int lineCross(Point a, Point b, Point c, Point d, Point& p) {
+  double s1 = cross(a, b, c), s2 = cross(a, b, d);
+  if (sig(s1) == 0 && sig(s2) == 0) return 2;
+  if (sig(s2 - s1) == 0) return 0;
+  p.x = (c.x * s2 - d.x * s1) / (s2 - s1);
+  p.y = (c.y * s2 - d.y * s1) / (s2 - s1);
+  return 1;
+}
+// convex_iou_kernel.cu:L82-110
+inline void polygon_cut(Point* p, int& n, Point a, Point b) {
+  Point pp[maxn];
+  for (int i = 0; i < maxn; i++) pp[i] = Point(0, 0);   // (device stack garbage in the reference)
+  int m = 0;
+  p[n] = p[0];
+  for (int i = 0; i < n; i++) {
+    if (sig(cross(a, b, p[i])) > 0) {
+      pp[m] = p[i];
+      m++;
+    }
+    if (sig(cross(a, b, p[i])) != sig(cross(a, b, p[i + 1]))) {
+      lineCross(a, b, p[i], p[i + 1], pp[m]);
+      m++;
+    }
+  }
+  n = 0;
+  for (int i = 0; i < m; i++)
+    if (!i || !(point_same(pp[i], pp[i - 1]))) {
+      p[n] = pp[i];
+      n++;
+    }
+  while (n > 1 && point_same(p[n - 1], p[0])) n--;
+}
+// L113-140
+inline double intersectArea(Point a, Point b, Point c, Point d) {
+  Point o(0, 0);
+  int s1 = sig(cross(o, a, b));
+  int s2 = sig(cross(o, c, d));
+  if (s1 == 0 || s2 == 0) return 0.0;
+  if (s1 == -1) swap1(&a, &b);
+  if (s2 == -1) swap1(&c, &d);
+  Point p[10] = {o, a, b};
+  int n = 3;
+  polygon_cut(p, n, o, c);
+  polygon_cut(p, n, c, d);
+  polygon_cut(p, n, d, o);
+  double res = area(p, n);
+  if (s1 * s2 == -1) res = -res;
+  return res;
+}
+// L141-155
+inline double intersectAreaO(Point* ps1, int n1, Point* ps2, int n2) {
+  if (area(ps1, n1) < 0) reverse1(ps1, n1);
+  if (area(ps2, n2) < 0) reverse1(ps2, n2);
+  ps1[n1] = ps1[0];
+  ps2[n2] = ps2[0];
+  double res = 0;
+  for (int i = 0; i < n1; i++)
+    for (int j = 0; j < n2; j++) res += intersectArea(ps1[i], ps1[i + 1], ps2[j], ps2[j + 1]);
+  return res;
+}
+
+// Jarvis_and_index, convex_iou_kernel.cu:L157-256 (T = double) and min_area_bbox.cu:L205-299 (T = float: points and
+// distances in float, the turn test in double).  The index output is not needed by either caller restated here.
+template <typename T>
+struct PT {
+  T x, y;
+};
+template <typename T>
+inline T disT(PT<T> a, PT<T> b) { return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y); }
+
+template <typename T>
+void Jarvis(PT<T>* in_poly, int& n_poly) {
+  PT<T> p_max = in_poly[0], p_k;
+  int max_index = 0, k_index;
+  int Stack[40], top1, top2;
+  double sign;
+  PT<T> right_point[40], left_point[40];
+  for (int i = 0; i < n_poly; i++) {
+    if (in_poly[i].y < in_poly[0].y || (in_poly[i].y == in_poly[0].y && in_poly[i].x < in_poly[0].x))
+      std::swap(in_poly[0], in_poly[i]);
+    if (i == 0) {
+      p_max = in_poly[0];
+      max_index = 0;
+    }
+    if (in_poly[i].y > p_max.y || (in_poly[i].y == p_max.y && in_poly[i].x > p_max.x)) {
+      p_max = in_poly[i];
+      max_index = i;
+    }
+  }
+  if (max_index == 0) {
+    max_index = 1;
+    p_max = in_poly[max_index];
+  }
+  k_index = 0, Stack[0] = 0, top1 = 0;
+  while (k_index != max_index && top1 < 18) {      // (cap: the reference loops unbounded)
+    p_k = p_max;
+    k_index = max_index;
+    for (int i = 1; i < n_poly; i++) {
+      const PT<T> s = in_poly[Stack[top1]];
+      sign = ((double)in_poly[i].x - (double)s.x) * ((double)p_k.y - (double)s.y) -
+             ((double)p_k.x - (double)s.x) * ((double)in_poly[i].y - (double)s.y);
+      if ((sign > 0) || ((sign == 0) && (disT(s, in_poly[i]) > disT(s, p_k)))) {
+        p_k = in_poly[i];
+        k_index = i;
+      }
+    }
+    top1++;
+    Stack[top1] = k_index;
+  }
+  for (int i = 0; i <= top1; i++) right_point[i] = in_poly[Stack[i]];
+  k_index = 0, Stack[0] = 0, top2 = 0;
+  while (k_index != max_index && top2 < 18) {
+    p_k = p_max;
+    k_index = max_index;
+    for (int i = 1; i < n_poly; i++) {
+      const PT<T> s = in_poly[Stack[top2]];
+      sign = ((double)in_poly[i].x - (double)s.x) * ((double)p_k.y - (double)s.y) -
+             ((double)p_k.x - (double)s.x) * ((double)in_poly[i].y - (double)s.y);
+      if ((sign < 0) || ((sign == 0) && (disT(s, in_poly[i]) > disT(s, p_k)))) {
+        p_k = in_poly[i];
+        k_index = i;
+      }
+    }
+    top2++;
+    Stack[top2] = k_index;
+  }
+  for (int i = top2 - 1; i >= 0; i--) left_point[i] = in_poly[Stack[i]];
+  int total = top1 + top2;
+  if (total > 19) total = 19;
+  for (int i = 0; i < total; i++) {
+    if (i <= top1)
+      in_poly[i] = right_point[i];
+    else
+      in_poly[i] = left_point[top2 - (i - top1)];
+  }
+  n_poly = total;
+}
+
+}  // namespace cvx
+
+// convex_iou_kernel.cu:L258-305: ious (N, M); pointsets (N, 18), polygons (M, 8)
+JO_API void jo_convex_iou(const float* pointsets, int N, const float* polygons, int M, float* ious) {
+  using namespace cvx;
+  for (int a = 0; a < N; a++)
+    for (int b = 0; b < M; b++) {
+      const float* p = pointsets + (size_t)a * 18;
+      const float* q = polygons + (size_t)b * 8;
+      Point ps1[maxn], ps2[maxn];
+      PT<double> convex[maxn];
+      for (int i = 0; i < 9; i++) {
+        convex[i].x = (double)p[i * 2];
+        convex[i].y = (double)p[i * 2 + 1];
+      }
+      int n_convex = 9;
+      Jarvis<double>(convex, n_convex);
+      int n1 = n_convex;
+      for (int i = 0; i < n1; i++) ps1[i] = Point(convex[i].x, convex[i].y);
+      int n2 = 4;
+      for (int i = 0; i < n2; i++) ps2[i] = Point((double)q[i * 2], (double)q[i * 2 + 1]);
+      double inter_area = intersectAreaO(ps1, n1, ps2, n2);
+      double S_pred = area(ps1, n1);
+      double union_area = fabs(S_pred) + fabs(area(ps2, n2)) - inter_area;
+      ious[(size_t)a * M + b] = (float)(inter_area / union_area);
+    }
+}
+
+// the hull alone (test aid): hull (N, 9, 2) padded with NaN, counts (N)
+JO_API void jo_convex_hull9(const float* pointsets, int N, float* hull, int* counts) {
+  for (int a = 0; a < N; a++) {
+    cvx::PT<double> c[40];
+    for (int i = 0; i < 9; i++) c[i] = {(double)pointsets[(size_t)a * 18 + 2 * i], (double)pointsets[(size_t)a * 18 + 2 * i + 1]};
+    int n = 9;
+    cvx::Jarvis<double>(c, n);
+    counts[a] = n;
+    for (int i = 0; i < 9; i++) {
+      hull[((size_t)a * 9 + i) * 2] = i < n ? (float)c[i].x : NAN;
+      hull[((size_t)a * 9 + i) * 2 + 1] = i < n ? (float)c[i].y : NAN;
+    }
+  }
+}
+
+// min_area_bbox.cu:L49-203 (minBoundingRect), L301-399 (Findminbox): bboxes (N, 8)
+JO_API void jo_min_area_bbox(const float* pointsets, int N, float* bboxes) {
+  const int maxn = 20;
+  for (int a = 0; a < N; a++) {
+    const float* p = pointsets + (size_t)a * 18;
+    float* minpoints = bboxes + (size_t)a * 8;
+    cvx::PT<float> convex[40], ps[40];
+    float pi = 3.1415926;
+    for (int i = 0; i < 9; i++) {
+      convex[i].x = p[i * 2];
+      convex[i].y = p[i * 2 + 1];
+    }
+    int n_convex = 9;
+    cvx::Jarvis<float>(convex, n_convex);
+    int n1 = n_convex;
+    for (int i = 0; i < n1; i++) ps[i] = convex[i];
+    ps[n1] = convex[0];
+    // ---- minBoundingRect(ps, n1 + 1, minbbox)
+    const int n_points = n1 + 1;
+    float minbox[5] = {0};
+    {
+      float convex_points[2][maxn];
+      for (int j = 0; j < n_points; j++) convex_points[0][j] = ps[j].x;
+      for (int j = 0; j < n_points; j++) convex_points[1][j] = ps[j].y;
+      cvx::PT<float> edges[maxn];
+      float edges_angles[maxn];
+      float unique_angles[maxn];
+      int n_edges = n_points - 1;
+      int n_unique = 0;
+      int unique_flag = 0;
+      for (int i = 0; i < n_edges; i++) {
+        edges[i].x = ps[i + 1].x - ps[i].x;
+        edges[i].y = ps[i + 1].y - ps[i].y;
+      }
+      for (int i = 0; i < n_edges; i++) {
+        edges_angles[i] = atan2((double)edges[i].y, (double)edges[i].x);
+        if (edges_angles[i] >= 0)
+          edges_angles[i] = fmod((double)edges_angles[i], (double)pi / 2);
+        else
+          edges_angles[i] = edges_angles[i] - (int)(edges_angles[i] / (pi / 2) - 1) * (pi / 2);
+      }
+      unique_angles[0] = edges_angles[0];
+      n_unique += 1;
+      for (int i = 1; i < n_edges; i++) {
+        for (int j = 0; j < n_unique; j++)
+          if (edges_angles[i] == unique_angles[j]) unique_flag += 1;
+        if (unique_flag == 0) {
+          unique_angles[n_unique] = edges_angles[i];
+          n_unique += 1;
+          unique_flag = 0;
+        } else {
+          unique_flag = 0;
+        }
+      }
+      float minarea = 1e12;
+      for (int i = 0; i < n_unique; i++) {
+        float R[2][2];
+        float rot_points[2][maxn];
+        R[0][0] = cosf(unique_angles[i]);
+        R[0][1] = cosf(unique_angles[i] - pi / 2);
+        R[1][0] = cosf(unique_angles[i] + pi / 2);
+        R[1][1] = cosf(unique_angles[i]);
+        for (int m = 0; m < 2; m++)
+          for (int n = 0; n < n_points; n++) {
+            float sum = 0.0;
+            for (int k = 0; k < 2; k++) sum = sum + R[m][k] * convex_points[k][n];
+            rot_points[m][n] = sum;
+          }
+        float xmin = 1e12, ymin = 1e12, xmax = -1e12, ymax = -1e12;
+        for (int j = 0; j < n_points; j++) {
+          if (!(std::isinf(rot_points[0][j]) || std::isnan(rot_points[0][j]))) {
+            if (rot_points[0][j] < xmin) xmin = rot_points[0][j];
+            if (rot_points[0][j] > xmax) xmax = rot_points[0][j];
+          }
+          if (!(std::isinf(rot_points[1][j]) || std::isnan(rot_points[1][j]))) {
+            if (rot_points[1][j] < ymin) ymin = rot_points[1][j];
+            if (rot_points[1][j] > ymax) ymax = rot_points[1][j];
+          }
+        }
+        float area = (xmax - xmin) * (ymax - ymin);
+        if (area < minarea) {
+          minarea = area;
+          minbox[0] = unique_angles[i];
+          minbox[1] = xmin;
+          minbox[2] = ymin;
+          minbox[3] = xmax;
+          minbox[4] = ymax;
+        }
+      }
+    }
+    float angle = minbox[0], xmin = minbox[1], ymin = minbox[2], xmax = minbox[3], ymax = minbox[4];
+    float R[2][2];
+    R[0][0] = cosf(angle);
+    R[0][1] = cosf(angle - pi / 2);
+    R[1][0] = cosf(angle + pi / 2);
+    R[1][1] = cosf(angle);
+    const float corner[4][2] = {{xmax, ymin}, {xmin, ymin}, {xmin, ymax}, {xmax, ymax}};
+    for (int c = 0; c < 4; c++)
+      for (int n = 0; n < 2; n++) {
+        float sum = 0.0;
+        for (int k = 0; k < 2; k++) sum = sum + corner[c][k] * R[k][n];
+        minpoints[c * 2 + n] = sum;
+      }
+  }
+}
+
+// convex_sort.py:L159-194 (start index, order) + L4-65 (scan): index (nbs, npts + circular), -1 filled
+JO_API void jo_convex_sort(const float* pts, const float* masks, int nbs, int npts, int circular, int* index) {
+  const int index_size = circular ? npts + 1 : npts;
+  for (int i = 0; i < nbs * index_size; i++) index[i] = -1;
+  if (npts == 0) return;
+  std::vector<float> cosv(npts);
+  std::vector<int> order(npts);
+  for (int b = 0; b < nbs; b++) {
+    const float* px = pts + (size_t)b * npts * 2;
+    const float* m = masks + (size_t)b * npts;
+    int start = 0;
+    float best = 0;
+    for (int i = 0; i < npts; i++) {
+      float masked_y = m[i] * px[2 * i + 1] + (1 - m[i]) * 10000000.f;
+      if (i == 0 || masked_y < best) {
+        best = masked_y;
+        start = i;
+      }
+    }
+    const float sx = px[2 * start], sy = px[2 * start + 1];
+    for (int i = 0; i < npts; i++) {
+      float dx = px[2 * i] - sx, dy = px[2 * i + 1] - sy;
+      cosv[i] = dx / sqrtf(dx * dx + dy * dy + 0.000001f);
+      order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cosv[a] > cosv[c]; });
+    int* sub = index + (size_t)b * index_size;
+    sub[0] = start;
+    int c_i = 0;
+    for (int _j = 0; _j < npts; _j++) {
+      const int j = order[_j];
+      if (j == start) continue;
+      if (m[j] < 0.5) continue;
+      const float x0 = px[2 * j], y0 = px[2 * j + 1];
+      float x1 = px[2 * sub[c_i]], y1 = px[2 * sub[c_i] + 1];
+      float d = (x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0);
+      if (d < 0.000001) continue;
+      if (c_i < 2) {
+        sub[++c_i] = j;
+      } else {
+        float x2 = px[2 * sub[c_i - 1]], y2 = px[2 * sub[c_i - 1] + 1];
+        while (1) {
+          float t = (x1 - x2) * (y0 - y2) - (y1 - y2) * (x0 - x2);
+          if (t >= 0) {
+            sub[++c_i] = j;
+            break;
+          } else {
+            if (c_i <= 1) {
+              sub[c_i] = j;
+              break;
+            } else {
+              c_i--;
+              x1 = px[2 * sub[c_i]];
+              y1 = px[2 * sub[c_i] + 1];
+              x2 = px[2 * sub[c_i - 1]];
+              y2 = px[2 * sub[c_i - 1] + 1];
+            }
+          }
+        }
+      }
+    }
+    if (circular) sub[++c_i] = sub[0];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Active rotating filter (ops/orn.py:L138-211 CPU kernels)
 //   weight (nOut, nIn, nOri, kH, kW) ; indices (nOri, kH, kW, nRot) uint8, 1-based
 //   output (nOut*nRot, nIn*nOri, kH, kW)

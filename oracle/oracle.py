@@ -212,6 +212,44 @@ def deform_psroi_backward(grad_out, top_count, x, rois, trans, no_trans, spatial
     return gi, gt
 
 
+def convex_iou(pointsets, polygons):
+    """reppoints_convex_iou (ops/reppoints_convex_iou/convex_iou.py:L29-45): (N,18), (M,8) -> (N,M)"""
+    ps, pg = _c(pointsets), _c(polygons)
+    out = np.zeros((ps.shape[0], pg.shape[0]), np.float32)
+    if out.size:
+        lib().jo_convex_iou(_ptr(ps), _i(ps.shape[0]), _ptr(pg), _i(pg.shape[0]), _ptr(out))
+    return out
+
+
+def convex_hull9(pointsets):
+    """the Jarvis hull both RepPoints ops start from: list of (k, 2) arrays in the reference's vertex order"""
+    ps = _c(pointsets)
+    n = ps.shape[0]
+    hull, cnt = np.zeros((n, 9, 2), np.float32), np.zeros((n,), np.int32)
+    if n:
+        lib().jo_convex_hull9(_ptr(ps), _i(n), _ptr(hull), _ptr(cnt))
+    return [hull[i, :cnt[i]] for i in range(n)]
+
+
+def min_area_bbox(pointsets):
+    """reppoints_min_area_bbox (ops/reppoints_min_area_bbox/min_area_bbox.py:L22-34): (N,18) -> (N,8)"""
+    ps = _c(pointsets)
+    out = np.zeros((ps.shape[0], 8), np.float32)
+    if ps.shape[0]:
+        lib().jo_min_area_bbox(_ptr(ps), _i(ps.shape[0]), _ptr(out))
+    return out
+
+
+def convex_sort(pts, masks, circular=True):
+    """convex_sort (ops/convex_sort.py:L196-201): (nbs,npts,2), (nbs,npts) -> (nbs, npts + circular) int32"""
+    pts, masks = _c(pts), _c(masks)
+    nbs, npts = pts.shape[:2]
+    out = np.full((nbs, npts + (1 if circular else 0)), -1, np.int32)
+    if nbs:
+        lib().jo_convex_sort(_ptr(pts), _ptr(masks), _i(nbs), _i(npts), _i(int(circular)), _ptr(out))
+    return out
+
+
 def arf_forward(weight, indices, _l=None, _name="jo_arf_forward"):
     weight, indices = _c(weight), _c(indices, np.uint8)
     nOut, nIn, nOri, kH, kW = weight.shape
