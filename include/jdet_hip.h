@@ -222,7 +222,7 @@ int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, 
  * x (N,H,W,Cin); w (Cout,3,3,Cin) [= torch channels_last memory of a (Cout,Cin,3,3) weight]; bias (Cout) or NULL;
  * rowmask (N*H*W) or NULL multiplies the finished output rows (gap rows of a level pack); offset (N,18,H,W) with
  * (dy,dx) per tap or NULL; y (N,H,W,Cout); tile = 0 (chosen from the problem size), 64 or 128 (edge of the
- * workgroup's output tile).  Cin % 16 == 0 and 16-byte aligned x / w, else JDET_E_UNSUPPORTED / JDET_E_BADARG
+ * workgroup's output tile; + 1 / + 2 select the 16-deep K step / no intra-workgroup K split, for measurements).  Cin % 16 == 0 and 16-byte aligned x / w, else JDET_E_UNSUPPORTED / JDET_E_BADARG
  * (query: jdet_conv3x3_igemm_supported).  Products are fp32 in, fp32 accumulate (v_mfma_f32_32x32x2). */
 int jdet_conv3x3_igemm_supported(int Cin, int Cout);
 int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,

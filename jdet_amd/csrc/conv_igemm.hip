@@ -9,18 +9,24 @@
 //   plain conv : A[m, (tap, c)] = X[pixel(m) + tap, c]   (0 outside the image)
 //   deformable : A[m, (tap, c)] = bilinear sample of X[., c] at pixel(m) + tap + offset[m, tap]  (dcn_v1.py:L132-166)
 //
-// Tiling (one workgroup = 256 threads = 4 waves as 2 x 2, BT x BT outputs with BT = 128 or 64, K step = 16 channels of
-// one tap):
-//   * v_mfma_f32_32x32x2_f32: a wave owns (BT/2)^2 outputs = T x T tiles of 32 x 32 (T = 2: 64 accumulator registers).
+// Tiling (one workgroup = 4 * KG waves, BT x BT outputs with BT = 128 or 64, K step = BK = 32 or 16 channels of one tap):
+//   * v_mfma_f32_32x32x2_f32: the waves form KG groups of 2 x 2; a wave owns (BT/2)^2 outputs = T x T tiles of 32 x 32
+//     (T = 2: 64 accumulator registers) and, with KG = 2, every other 8-deep slice of each K step (intra-workgroup
+//     split-K: twice the waves per SIMD for the same LDS bytes per MFMA; the two partial tiles meet in LDS at the end).
 //     The instruction takes ONE f32 of A and of B per lane (lane l: row / column l & 31, k = l >> 5); which two k of
 //     the tile a given instruction consumes is free as long as A and B agree, so lanes 0-31 take k = 8q .. 8q+3 and
-//     lanes 32-63 take k = 8q+4 .. 8q+7 of an 8-wide group: ONE ds_read_b128 per operand tile feeds four MFMAs.
-//   * both operand tiles sit in LDS as [row][16 k] = rows of four 16-byte chunks, chunk c of row r stored at position
-//     c ^ ((r >> 2) & 3): the loader's stores (4 lanes = one row's 64 bytes, 16 rows per instruction) and the fragment
-//     reads (16 consecutive rows, one chunk) both touch every bank once -- no padding, 8 KB per 128-row tile.  The
-//     weight tile [n][k] is the weight tensor's own (Cout, 3, 3, Cin) memory order: no transposition anywhere.
-//   * double-buffered LDS, register-staged: the global loads of K step t+1 are issued before the MFMAs of step t and
-//     stored to the other buffer after them: one barrier per K step.
+//     lanes 32-63 take k = 8q+4 .. 8q+7 of an 8-wide slice: ONE ds_read_b128 per operand tile feeds four MFMAs.
+//   * both operand tiles sit in LDS as [row][BK k] = rows of 16-byte chunks, chunk c of row r stored at position
+//     c ^ f(r) (BK = 16: f = (r >> 2) & 3, BK = 32: f = (r >> 1) & 7): each 16-lane group of a ds_read_b128 (lanes
+//     {0-3, 12-15, 20-27}, ...) and each 8-lane group of a ds_write_b128 covers every bank once -- measured
+//     SQ_LDS_BANK_CONFLICT = 0 -- without padding.  The weight tile [n][k] is the weight tensor's own
+//     (Cout, 3, 3, Cin) memory order: no transposition anywhere.  Fragment addresses are per-lane constants
+//     (the XOR commutes with the slice index), tile / buffer selection goes into the instruction's immediate offset.
+//   * global loads are raw buffer loads: per-thread byte offsets fixed per tap (A) / per kernel (B), the K step's
+//     channel offset in the scalar offset operand, rows outside the image / past Cout get an out-of-range offset and
+//     read as zero -- no address arithmetic, no selects in the K loop.
+//   * double-buffered LDS, register-staged: the loads of K step t+1 are issued before the MFMAs of step t and stored
+//     to the other buffer after them: one barrier per K step.
 //   * workgroup -> tile mapping is XCD-aware: consecutive workgroup ids go round-robin over the 8 XCDs (each with its
 //     own L2), so XCD x takes the x-th contiguous band of M tiles with the N tiles of one M tile adjacent: the input
 //     rows (incl. the halo shared by neighbouring tiles) of a band stay in one L2.
@@ -31,8 +37,8 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
-
 
 struct ConvArgs {
   const float* x;        // (N, H, W, Cin)
@@ -44,28 +50,32 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, relu;
 };
 
-// chunk (4 floats) `chunk` of LDS row `row`: BK = 16 -> 4 chunks, position c ^ ((r >> 2) & 3); BK = 32 -> 8 chunks,
-// position c ^ ((r >> 1) & 7): 16 consecutive rows of one chunk, and the 16 lanes of a store, cover the 64 banks once
-template <int BK>
-__device__ __forceinline__ int swz(int row, int chunk) {
-  return row * BK + ((chunk ^ (BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7)) << 2);
+constexpr unsigned kOob = 0xFFFFFFF0u;   // a byte offset past every buffer: the load returns zeros
+
+__device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-// what a (row, tap) pair reads: plain conv = one pixel (or nothing); deformable = four weighted corners
-struct Tap {
-  int off[4];     // element offset of the corner pixel's channel 0, or -1
-  float wt[4];
-};
+// byte position of chunk (4 floats) `chunk` of LDS row `row` (see header)
+template <int BK>
+__device__ __forceinline__ int swz_bytes(int row, int chunk) {
+  return (row * BK + ((chunk ^ (BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7)) << 2)) * 4;
+}
 
-template <int BT, int BK, bool DEFORM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ? (BK == 32 ? 2 : (DEFORM ? 3 : 4)) : 4))) void conv3x3_igemm_kernel(ConvArgs a) {
+template <int BT, int BK, int KG, bool DEFORM>
+__global__ __launch_bounds__(256 * KG)
+__attribute__((amdgpu_waves_per_eu(BT == 128 ? (KG == 2 ? 4 : (BK == 32 ? 2 : (DEFORM ? 3 : 4))) : 4)))
+void conv3x3_igemm_kernel(ConvArgs a) {
+  constexpr int NTHR = 256 * KG;
   constexpr int T = BT / 64;             // 32 x 32 tiles per wave and direction
   constexpr int CH = BK / 4;             // 16-byte chunks per LDS row
-  constexpr int RPP = 256 / CH;          // loader: RPP rows x CH chunks per pass
+  constexpr int RPP = NTHR / CH;         // loader: RPP rows x CH chunks per pass
   constexpr int PASSES = BT / RPP;
   constexpr int NC = DEFORM ? 4 : 1;
-  __shared__ __attribute__((aligned(16))) float s_a[2][BT * BK];
-  __shared__ __attribute__((aligned(16))) float s_b[2][BT * BK];
+  constexpr int TILE = BT * BK * 4;      // bytes of one operand tile
+  constexpr int QN = BK / 8 / KG;        // 8-deep slices per wave and K step
+  static_assert(PASSES >= 1 && QN >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) char s_raw[4 * TILE];     // [buffer][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long M = (long)a.N * a.H * a.W;
   // ---- XCD-aware tile id ----
@@ -75,11 +85,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
   if ((total & 7) == 0) logical = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
   const long m0 = (long)(logical / NT) * BT;
   const int n0 = (logical % NT) * BT;
-  // ---- loader role: pass p covers rows p*64 + tid/4, chunk tid%4 (4 channels of the 16 of a K step) ----
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)(M * a.Cin * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((long)a.Cout * 9 * a.Cin * 4), 0x00020000);
+  // ---- loader role: pass p covers row p * RPP + tid / CH, chunk tid % CH (4 channels of the BK of a K step) ----
   const int lchunk = tid % CH, lrow = tid / CH;
   int img[PASSES], py[PASSES], px[PASSES];
-  bool m_ok[PASSES], n_ok[PASSES];
-  const float* wrow[PASSES];
+  bool m_ok[PASSES];
+  unsigned wv[PASSES];                   // byte offset of this thread's weight chunk at (tap 0, channel 0)
+  int st_off[PASSES];                    // byte position of this thread's chunk inside an operand tile
 #pragma unroll
   for (int p = 0; p < PASSES; p++) {
     const int row = p * RPP + lrow;
@@ -92,26 +107,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
       py[p] = rem / a.W;
       px[p] = rem - py[p] * a.W;
     }
-    n_ok[p] = n0 + row < a.Cout;
-    wrow[p] = a.w + (size_t)(n_ok[p] ? n0 + row : 0) * 9 * a.Cin + lchunk * 4;
+    wv[p] = n0 + row < a.Cout ? (unsigned)(((n0 + row) * 9 * a.Cin + lchunk * 4) * 4) : kOob;
+    st_off[p] = swz_bytes<BK>(row, lchunk);
   }
-  const int ksteps_per_tap = a.Cin / BK;   // (host: BK = 32 only when Cin % 32 == 0)
-  const int nsteps = 9 * ksteps_per_tap;
+  const int nsteps = 9 * (a.Cin / BK);   // (host: BK = 32 only when Cin % 32 == 0)
 
-  Tap tp[PASSES];
+  unsigned av[PASSES][NC];               // byte offsets of the tap's source pixel(s), or kOob
+  float aw[PASSES][NC];                  // deformable: bilinear weights
   auto set_tap = [&](int tap) {
     const int r = tap / 3, s = tap - r * 3;
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
 #pragma unroll
       for (int k = 0; k < NC; k++) {
-        tp[p].off[k] = -1;
-        tp[p].wt[k] = 0.f;
+        av[p][k] = kOob;
+        aw[p][k] = 0.f;
       }
       if (!m_ok[p]) continue;
       if (!DEFORM) {
         const int yy = py[p] + r - 1, xx = px[p] + s - 1;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) tp[p].off[0] = ((img[p] * a.H + yy) * a.W + xx) * a.Cin;
+        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
+          av[p][0] = (unsigned)((((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4) * 4);
       } else {
         // dcn_v1.py:L132-166 (deformable_im2col): h_im = h_in + i*dil + offset_h, zero outside (-1, H) x (-1, W),
         // corners outside the image contribute 0 (dmcn_im2col_bilinear L25-56)
@@ -125,9 +141,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
           const int cy[4] = {hl, hl, hl + 1, hl + 1}, cx[4] = {wl, wl + 1, wl, wl + 1};
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            tp[p].wt[k] = wt[k];
+            aw[p][k] = wt[k];
             if (cy[k] >= 0 && cy[k] < a.H && cx[k] >= 0 && cx[k] < a.W)
-              tp[p].off[k] = ((img[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin;
+              av[p][k] = (unsigned)((((img[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin + lchunk * 4) * 4);
           }
         }
       }
@@ -136,38 +152,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
 
   v4f ra[PASSES], rb[PASSES];
   auto load_step = [&](int tap, int c) {     // c: first channel of the K step
-    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    const unsigned sa = (unsigned)(c * 4), sb = (unsigned)((tap * a.Cin + c) * 4);
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
       if (!DEFORM) {
-        const v4f v = *reinterpret_cast<const v4f*>(a.x + (size_t)max(tp[p].off[0], 0) + c + lchunk * 4);
-        ra[p] = tp[p].off[0] >= 0 ? v : z;     // unconditional load of a valid address + select: no branches
+        ra[p] = buf_load(rx, av[p][0], sa);
       } else {
         v4f v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-          const v4f t = *reinterpret_cast<const v4f*>(a.x + (size_t)max(tp[p].off[k], 0) + c + lchunk * 4);
-          v[k] = tp[p].off[k] >= 0 ? t : z;
-        }
-        ra[p] = tp[p].wt[0] * v[0] + tp[p].wt[1] * v[1] + tp[p].wt[2] * v[2] + tp[p].wt[3] * v[3];
+        for (int k = 0; k < 4; k++) v[k] = buf_load(rx, av[p][k], sa);
+        ra[p] = aw[p][0] * v[0] + aw[p][1] * v[1] + aw[p][2] * v[2] + aw[p][3] * v[3];
       }
-      const v4f wv = *reinterpret_cast<const v4f*>(wrow[p] + (size_t)tap * a.Cin + c);
-      rb[p] = n_ok[p] ? wv : z;
+      rb[p] = buf_load(rw, wv[p], sb);
     }
   };
   auto store_step = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      const int row = p * RPP + lrow;
-      *reinterpret_cast<v4f*>(&s_a[buf][swz<BK>(row, lchunk)]) = ra[p];
-      *reinterpret_cast<v4f*>(&s_b[buf][swz<BK>(row, lchunk)]) = rb[p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + st_off[p]) = ra[p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + TILE + st_off[p]) = rb[p];
     }
   };
 
-  // ---- compute role: wave (wm, wn) owns outputs [wm*BT/2, +BT/2) x [wn*BT/2, +BT/2) of the block tile ----
-  const int wm = wave >> 1, wn = wave & 1;
+  // ---- compute role: wave (kg, wm, wn) owns outputs [wm*BT/2, +BT/2) x [wn*BT/2, +BT/2) and the 8-deep slices
+  // q = qq * KG + kg of every K step ----
+  const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
   const int frow = lane & 31, fhalf = lane >> 5;
+  int fa_off[QN], fb_off[QN];            // byte positions of this lane's fragments (tile 0, buffer 0)
+#pragma unroll
+  for (int qq = 0; qq < QN; qq++) {
+    const int chunk = (qq * KG + kg) * 2 + fhalf;
+    fa_off[qq] = swz_bytes<BK>(wm * (BT / 2) + frow, chunk);
+    fb_off[qq] = TILE + swz_bytes<BK>(wn * (BT / 2) + frow, chunk);
+  }
   v16f acc[T][T];
 #pragma unroll
   for (int i = 0; i < T; i++)
@@ -193,13 +210,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
       }
       load_step(tap, c);            // in flight during the MFMAs below
     }
+    const char* sb = s_raw + buf * 2 * TILE;
 #pragma unroll
-    for (int q = 0; q < BK / 8; q++) {
+    for (int qq = 0; qq < QN; qq++) {
       v4f fa[T], fb[T];
 #pragma unroll
-      for (int i = 0; i < T; i++) {
-        fa[i] = *reinterpret_cast<const v4f*>(&s_a[buf][swz<BK>(wm * (BT / 2) + i * 32 + frow, q * 2 + fhalf)]);
-        fb[i] = *reinterpret_cast<const v4f*>(&s_b[buf][swz<BK>(wn * (BT / 2) + i * 32 + frow, q * 2 + fhalf)]);
+      for (int i = 0; i < T; i++) {       // tile i: 32 rows further = the same swizzle (f repeats every 16 / 32 rows)
+        fa[i] = *reinterpret_cast<const v4f*>(sb + fa_off[qq] + i * 32 * BK * 4);
+        fb[i] = *reinterpret_cast<const v4f*>(sb + fb_off[qq] + i * 32 * BK * 4);
       }
 #pragma unroll
       for (int kk = 0; kk < 4; kk++)
@@ -211,6 +229,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
     }
     if (more) store_step(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous step
     __syncthreads();
+  }
+
+  // ---- KG = 2: the second group hands its partial tile over through LDS (the operand buffers are free now) ----
+  if (KG == 2) {
+    float* red = reinterpret_cast<float*>(s_raw);           // [wave & 3][T*T*16][64 lanes]
+    static_assert(KG == 1 || 4 * T * T * 16 * 64 * 4 <= 4 * TILE, "reduction buffer");
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < T; i++)
+#pragma unroll
+        for (int j = 0; j < T; j++)
+#pragma unroll
+          for (int e = 0; e < 16; e++) red[(((wave & 3) * T * T + i * T + j) * 16 + e) * 64 + lane] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kg == 1) return;
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -230,7 +264,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
       for (int e = 0; e < 16; e++) {
         const long m = m0 + wm * (BT / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (m < M && n < a.Cout) {
-          float v = acc[i][j][e] + b;
+          float v = acc[i][j][e];
+          if (KG == 2)      // the other wave group's partial sum (read tile by tile: no second accumulator set live)
+            v += reinterpret_cast<const float*>(s_raw)[(((wave & 3) * T * T + i * T + j) * 16 + e) * 64 + lane];
+          v += b;
           if (a.relu) v = fmaxf(v, 0.f);
           if (a.rowmask) v *= mk[e];
           a.y[(size_t)m * a.Cout + n] = v;
@@ -240,20 +277,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BT == 128 ?
   }
 }
 
-template <int BT, int BK>
+template <int BT, int BK, int KG>
 int launch(const ConvArgs& a, hipStream_t st) {
   const long M = (long)a.N * a.H * a.W;
   const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
   if (a.offset)
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, true>), dim3((unsigned)tiles), dim3(256 * KG), 0, st, a);
   else
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false>), dim3((unsigned)tiles), dim3(256 * KG), 0, st, a);
   return jdet_launch_status();
 }
 
 }  // namespace
 
-// Supported: Cin % 16 == 0, 16-byte aligned tensors, N*H*W*max(Cin, Cout) < 2^31; any Cout, any N, H, W.
+// Supported: Cin % 16 == 0, 16-byte aligned tensors, N*H*W*max(Cin, Cout) < 2^30; any Cout, any N, H, W.
 JDET_API int jdet_conv3x3_igemm_supported(int Cin, int Cout) { return Cin > 0 && Cin % 16 == 0 && Cout > 0; }
 
 JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,
@@ -265,17 +302,23 @@ JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W
   if (!x_nhwc || !w_krsc || !y_nhwc) return JDET_E_BADARG;
   if ((((uintptr_t)x_nhwc) | ((uintptr_t)w_krsc)) & 15) return JDET_E_BADARG;
   const long M = (long)N * H * W;
-  if (M * (Cin > Cout ? Cin : Cout) >= (1L << 31)) return JDET_E_UNSUPPORTED;
+  if (M * (Cin > Cout ? Cin : Cout) >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
   ConvArgs a{x_nhwc, w_krsc, bias, rowmask, offset, y_nhwc, N, H, W, Cin, Cout, relu ? 1 : 0};
   // 128 x 128 tiles once they fill the chip (2 workgroups per CU), 64 x 64 below: four times the workgroups, a
   // quarter of the per-tile latency chain
-  // tile: 0 = automatic; 64 / 128 = edge of the output tile; + 1 selects the 16-deep K step (65, 129: measurement aid)
-  const int edge = tile & ~1;
+  // tile: 0 = automatic; 64 / 128 = edge of the output tile; + 1 selects the 16-deep K step, + 2 a single wave group
+  // (no intra-workgroup K split) -- measurement aids
+  const int edge = tile & ~3;
   if (tile != 0 && edge != 64 && edge != 128) return JDET_E_BADARG;
   const long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
   const bool big = tile ? edge == 128 : tiles128 >= 512;
   const bool k32 = Cin % 32 == 0 && !(tile & 1);
+  // intra-workgroup K split (8 waves): always for the 128 tile (4 waves per SIMD at 2 workgroups per CU); for the 64
+  // tile only while the grid is small (the per-tile latency chain is the floor there: 56 vs 59 us), not once 64-tiles
+  // alone fill the chip (87 vs 94 us at 2 x 64^2 positions).  Never for the gather (its registers do not fit).
+  const long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
+  const bool split = k32 && !(tile & 2) && !offset && (big || tile || tiles64 < 512);
   hipStream_t st = (hipStream_t)stream;
-  if (big) return k32 ? launch<128, 32>(a, st) : launch<128, 16>(a, st);
-  return k32 ? launch<64, 32>(a, st) : launch<64, 16>(a, st);
+  if (big) return k32 ? (split ? launch<128, 32, 2>(a, st) : launch<128, 32, 1>(a, st)) : launch<128, 16, 1>(a, st);
+  return k32 ? (split ? launch<64, 32, 2>(a, st) : launch<64, 32, 1>(a, st)) : launch<64, 16, 1>(a, st);
 }

@@ -54,14 +54,12 @@ def conv3x3(x, weight, bias=None, relu=False, offset=None, tile=0):
 
 
 # fused path only where it measured faster than library conv + bias + ReLU (positions = N*H*W)
-MIN_POSITIONS = 8192
+MIN_POSITIONS = 4096
 DEFORM_MIN_POSITIONS = 32768
 ENABLED = os.environ.get("JDET_CONV_IGEMM", "1") == "1"     # A/B switch for measurements
-# In the train step the autotuned library forward (conv + bias fused by its own solver) is as fast as this kernel and
-# the step measured 0.25 ms SLOWER with the fused forward (30.75 vs 30.50 ms, profiles/r03_conv_igemm.md): the
-# differentiable route is off unless asked for.
-TRAIN = os.environ.get("JDET_CONV_IGEMM_TRAIN", "0") == "1"
-
+# Train step: the fused forward + the library's data / weight gradients (`_Conv3x3BiasAct`).  S2ANet step 30.05 ms with
+# it, 30.37 ms without (two A/B pairs, profiles/r03_conv_igemm.md); JDET_CONV_IGEMM_TRAIN=0 switches it off.
+TRAIN = os.environ.get("JDET_CONV_IGEMM_TRAIN", "1") == "1"
 
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)

@@ -37,7 +37,7 @@ for hw in (128, 64, 32, 16, 8):
     t_lib = timeit(lambda: torch.relu_(F.conv2d(x, w, b, padding=1)))
     t_conv = timeit(lambda: F.conv2d(x, w, None, padding=1))
     row = dict(hw=hw, lib_conv_only_us=round(t_conv, 1), lib_conv_bias_relu_us=round(t_lib, 1))
-    for tile in (64, 65, 128, 129):
+    for tile in (64, 65, 66, 128, 129, 130):
         row["igemm_t%d_us" % tile] = round(timeit(lambda: CI.conv3x3_nhwc(xn, wk, b, True, tile=tile)), 1)
     row["igemm_auto_us"] = t = round(timeit(lambda: CI.conv3x3_nhwc(xn, wk, b, True)), 1)
     row["igemm_auto_tflops"] = round(flop / t / 1e6, 1)

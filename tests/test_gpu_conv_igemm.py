@@ -30,7 +30,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,bias,relu", CASES)
-@pytest.mark.parametrize("tile", [0, 64, 65, 128, 129])     # odd = the 16-deep K step
+@pytest.mark.parametrize("tile", [0, 64, 65, 66, 128, 129, 130])     # +1: 16-deep K step, +2: no K split
 def test_conv3x3_matches_float64(N, H, W, Cin, Cout, bias, relu, tile):
     from jdet_amd.ops import conv_igemm as CI
     if tile and N * H * W > 4096:
@@ -70,7 +70,7 @@ def test_unsupported_shapes_raise():
         CI.conv3x3_nhwc(torch.zeros(1, 4, 4, 32), torch.zeros(16, 3, 3, 32))     # host tensors: no CPU fallback
 
 
-@pytest.mark.parametrize("tile", [64, 65, 128, 129])
+@pytest.mark.parametrize("tile", [64, 65, 66, 128, 129, 130])
 @pytest.mark.parametrize("N,H,W,C,Cout,scale", [(2, 16, 16, 256, 256, 1.5), (1, 9, 11, 64, 96, 4.0),
                                                 (1, 64, 64, 256, 256, 2.0)])
 def test_deformable_matches_column_path(N, H, W, C, Cout, scale, tile):
@@ -94,8 +94,8 @@ def test_zero_offset_is_the_plain_convolution():
     g = torch.Generator().manual_seed(11)
     x = torch.randn(1, 12, 12, 64, generator=g).cuda()
     w = (torch.randn(64, 3, 3, 64, generator=g) * 0.05).cuda()
-    y0 = CI.conv3x3_nhwc(x, w)
-    y1 = CI.conv3x3_nhwc(x, w, offset=torch.zeros(1, 18, 12, 12).cuda())
+    y0 = CI.conv3x3_nhwc(x, w, tile=66)           # same tile shape and K order on both sides
+    y1 = CI.conv3x3_nhwc(x, w, offset=torch.zeros(1, 18, 12, 12).cuda(), tile=66)
     assert torch.equal(y0, y1)        # weights (1, 0, 0, 0): x * 1 + 0 + 0 + 0 is exact
 
 
@@ -111,6 +111,13 @@ def test_conv_module_fused_path_matches_library_path(act):
     x = torch.randn(2, 64, 72, 64, device="cuda").contiguous(memory_format=torch.channels_last)
     assert CI.preferred(x, m.conv.weight)
     g = torch.randn(2, 128, 72, 64, device="cuda")
+    if act:      # outputs within rounding of the ReLU threshold may land on either side of it in the two summation
+        CI.ENABLED = False          # orders: no upstream gradient there, so the mask decision cannot matter
+        try:
+            with torch.no_grad():
+                g = g * (m(x).abs() > 1e-4)
+        finally:
+            CI.ENABLED = True
     outs = []
     for enabled in (True, False):
         CI.ENABLED, CI.TRAIN = enabled, True
@@ -126,6 +133,7 @@ def test_conv_module_fused_path_matches_library_path(act):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
     with torch.no_grad():
         assert torch.equal(m(x), outs[0][0])          # the no-grad route is the same kernel
+    assert not act or (outs[0][0] == 0).float().mean().item() > 0.2     # the ReLU is active
 
 
 def test_deform_conv_inference_takes_the_fused_kernel():
