@@ -20,6 +20,7 @@ from torch import nn
 from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
 from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
 from jdet_amd.models.utils.level_pack import run_levels
+from jdet_amd.ops import conv_igemm
 from jdet_amd.ops.bbox_transforms import bbox2delta, delta2bbox
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, build_from_cfg
 
@@ -168,7 +169,7 @@ class FasterrcnnHead(AnchorHead):
         return [self.rpn_conv, self.rpn_cls, self.rpn_reg]
 
     def forward_single(self, x, mask=None):
-        x = F.relu(self.rpn_conv(x))      # the 1x1 layers below read no neighbours: a packed input needs no mask
+        x = conv_igemm.conv3x3_module(self.rpn_conv, x, relu=True)      # the 1x1 layers below read no neighbours: a packed input needs no mask
         return self.rpn_cls(x), self.rpn_reg(x)
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, gt_bboxes_ignore=None):

@@ -105,3 +105,14 @@ def conv3x3_bias_act(x, weight, bias=None, relu=False):
     if needs_grad(x, weight, bias):
         return _Conv3x3BiasAct.apply(x, weight, bias, relu)
     return conv3x3(x, weight, bias, relu)
+
+
+def conv3x3_module(conv, x, relu=False):
+    """`[relu](conv(x))` for an nn.Conv2d: the fused kernel when the layer is a 3x3 / stride 1 / pad 1 convolution and
+    `preferred()` says so (and, with gradients, the train route is on), the library otherwise."""
+    if (type(conv).__name__ == "Conv2d" and (conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
+            == ((3, 3), (1, 1), (1, 1), (1, 1), 1) and conv.padding_mode == "zeros" and preferred(x, conv.weight)
+            and (TRAIN or not needs_grad(x, conv.weight, conv.bias))):
+        return conv3x3_bias_act(x, conv.weight, conv.bias, relu)
+    y = conv(x)
+    return torch.relu(y) if relu else y
