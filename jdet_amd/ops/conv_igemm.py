@@ -77,9 +77,26 @@ def preferred(x, weight, min_positions=None):
     return N * H * W >= (MIN_POSITIONS if min_positions is None else min_positions)
 
 
+_FLIPPED = {}          # id(weight) -> (data_ptr, version, tensor): the data-gradient weights of the current step
+# grad_x through this kernel (flipped weights): 296 vs 341 us against the library's data gradient in isolation
+# (scripts/wgrad_bar.py), but no difference inside the autotuned train step (30.30 vs 30.30 ms): off by default.
+DGRAD = os.environ.get("JDET_CONV_IGEMM_DGRAD", "0") == "1"
+
+
+def dgrad_weight(weight):
+    """(Cout, Cin, 3, 3) -> (Cin, 3, 3, Cout) contiguous with the taps flipped: grad_x = conv3x3(grad_y, this).  Cached
+    per weight version (a tower's weight serves three pyramid calls per step)."""
+    key, stamp = id(weight), (weight.data_ptr(), weight._version)
+    hit = _FLIPPED.get(key)
+    if hit is None or hit[0] != stamp:
+        hit = (stamp, weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+        _FLIPPED[key] = hit
+    return hit[1]
+
+
 class _Conv3x3BiasAct(torch.autograd.Function):
-    """y = [relu](conv3x3(x, w) + b): forward = the implicit-GEMM kernel, backward = the library's convolution
-    backward on the ReLU-masked gradient (one call yields grad_x, grad_w, grad_b)."""
+    """y = [relu](conv3x3(x, w) + b): forward = the implicit-GEMM kernel; backward = the library's convolution backward
+    on the ReLU-masked gradient (with DGRAD: grad_x by this kernel on the flipped / transposed weights)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
@@ -95,9 +112,13 @@ class _Conv3x3BiasAct(torch.autograd.Function):
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]]
-        gx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, ctx.bias_sizes, [1, 1], [1, 1], [1, 1], False,
-                                                         [0, 0], 1, need)
-        return (gx if need[0] else None), (gw if need[1] else None), (gb if need[2] else None), None
+        gx = None
+        if need[0] and DGRAD and supported(weight.shape[0], weight.shape[1]):
+            gx = conv3x3_nhwc(L.f32c(g.permute(0, 2, 3, 1)), dgrad_weight(weight)).permute(0, 3, 1, 2)
+            need[0] = False
+        lx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, ctx.bias_sizes, [1, 1], [1, 1], [1, 1], False,
+                                                         [0, 0], 1, need) if any(need) else (None, None, None)
+        return (gx if gx is not None else lx), (gw if need[1] else None), (gb if need[2] else None), None
 
 
 def conv3x3_bias_act(x, weight, bias=None, relu=False):

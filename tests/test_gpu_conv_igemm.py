@@ -99,8 +99,9 @@ def test_zero_offset_is_the_plain_convolution():
     assert torch.equal(y0, y1)        # weights (1, 0, 0, 0): x * 1 + 0 + 0 + 0 is exact
 
 
+@pytest.mark.parametrize("dgrad", [False, True])
 @pytest.mark.parametrize("act", [True, False])
-def test_conv_module_fused_path_matches_library_path(act):
+def test_conv_module_fused_path_matches_library_path(act, dgrad):
     """ConvModule routes 3x3 conv [+ ReLU] through the fused kernel above the measured break-even size: same output,
     same gradients (the backward is the library's convolution backward on the ReLU-masked gradient)"""
     from jdet_amd.models.utils.modules import ConvModule
@@ -120,7 +121,7 @@ def test_conv_module_fused_path_matches_library_path(act):
             CI.ENABLED = True
     outs = []
     for enabled in (True, False):
-        CI.ENABLED, CI.TRAIN = enabled, True
+        CI.ENABLED, CI.TRAIN, CI.DGRAD = enabled, True, dgrad
         try:
             xi = x.clone().requires_grad_(True)
             m.zero_grad()
@@ -128,7 +129,7 @@ def test_conv_module_fused_path_matches_library_path(act):
             y.backward(g)
             outs.append((y.detach(), xi.grad, m.conv.weight.grad.clone(), m.conv.bias.grad.clone()))
         finally:
-            CI.ENABLED, CI.TRAIN = True, False
+            CI.ENABLED, CI.TRAIN, CI.DGRAD = True, True, False
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
     with torch.no_grad():
