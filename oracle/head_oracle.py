@@ -116,13 +116,13 @@ def multiclass_nms_rotated(boxes, scores_with_bg, score_thr, iou_thr, max_num, c
 
 
 def s2anet_get_bboxes_single(odm_cls, odm_box, refine_anchors, score_thr=0.05, iou_thr=0.1, max_per_img=2000,
-                             nms_pre=2000, scale_factor=1.0, cmp_ge=1):
+                             nms_pre=2000, scale_factor=1.0, cmp_ge=1, num_classes=None):
     """s2anet_head.py:L546-601 for one image: per level sigmoid scores, top nms_pre by the best class, decode against
     the refined anchors (delta2bbox_rotated, unit stds), concatenate, rescale, background column, multi-class NMS.
     odm_cls / odm_box: lists over levels of (C, H, W); refine_anchors: list over levels of (H*W, 5)."""
     mb, ms = [], []
     for cls, box, anchors in zip(odm_cls, odm_box, refine_anchors):
-        C = cls.shape[0]
+        C = cls.shape[0] if num_classes is None else num_classes       # (A*C, H, W): A anchors per location, A-fastest
         sc = 1.0 / (1.0 + np.exp(-np.transpose(cls, (1, 2, 0)).reshape(-1, C).astype(np.float64)))
         bp = np.transpose(box, (1, 2, 0)).reshape(-1, 5)
         if 0 < nms_pre < sc.shape[0]:
@@ -333,3 +333,41 @@ def roitrans_rcnn_losses(proposals, gt_hbbs, gt_obbs, gt_labels, trunk1, trunk2,
     out["s1.rbbox_loss_cls"] = softmax_cross_entropy(cls, labels, np.ones(len(labels), np.float32), n)
     out["s1.rbbox_loss_bbox"] = float(smooth_l1_loss(pred, bt[pos], bw[pos], 1.0, avg_factor=n))
     return out
+
+
+def l1_loss(pred, target, weight, avg_factor):
+    """models/losses/l1_loss.py (reduction "mean" with avg_factor): sum(|pred - target| * weight) / avg_factor"""
+    return float((np.abs(pred.astype(np.float64) - target.astype(np.float64)) * weight).sum() / avg_factor)
+
+
+def retina_anchors(strides, sizes, octave_base_scale=4, scales_per_octave=3, ratios=(1.0, 0.5, 2.0)):
+    """AnchorGeneratorRotatedRetinaNet (models/boxes/anchor_generator.py:L7-91): scales = base * 2^(i / per_octave)"""
+    scales = [octave_base_scale * 2 ** (i / scales_per_octave) for i in range(scales_per_octave)]
+    return [B.grid_anchors_s2anet(s, scales, list(ratios), sz, s) for s, sz in zip(strides, sizes)]
+
+
+def retina_loss(cls_scores, bbox_preds, gts, labels, strides, cfg=None, gamma=2.0, alpha=0.25, **anchor_kw):
+    """models/roi_heads/rotated_retina_head.py:L132-215 with the config's L1Loss: per-level loss lists.
+    cls_scores: list over levels of (N, A*C, H, W); bbox_preds: (N, A*5, H, W)."""
+    cfg = cfg or dict(pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0)
+    N = cls_scores[0].shape[0]
+    sizes = [tuple(t.shape[-2:]) for t in cls_scores]
+    anchors = retina_anchors(strides, sizes, **anchor_kw)
+    nla = [a.shape[0] for a in anchors]
+    A = nla[0] // (sizes[0][0] * sizes[0][1])
+    C = cls_scores[0].shape[1] // A
+    lab, lw, bt, bw, num_pos = anchor_targets([np.concatenate(anchors, 0)] * N, gts, labels, cfg, nla)
+    out = dict(loss_cls=[], loss_bbox=[])
+    for l in range(len(sizes)):
+        out["loss_cls"].append(sigmoid_focal_loss(_nhwc_rows(cls_scores[l], C), lab[l].reshape(-1), lw[l].reshape(-1),
+                                                  gamma, alpha, num_pos))
+        out["loss_bbox"].append(l1_loss(_nhwc_rows(bbox_preds[l], 5), bt[l].reshape(-1, 5), bw[l].reshape(-1, 5),
+                                        num_pos))
+    return out
+
+
+def retina_get_bboxes_single(cls_scores, bbox_preds, strides, num_classes=15, **kw):
+    """rotated_retina_head.py:L342-398 for one image (cls (A*C, H, W), box (A*5, H, W) per level)"""
+    sizes = [tuple(t.shape[-2:]) for t in cls_scores]
+    anchors = retina_anchors(strides, sizes)
+    return s2anet_get_bboxes_single(cls_scores, bbox_preds, anchors, num_classes=num_classes, **kw)
