@@ -282,6 +282,15 @@ int jdet_frozen_bn_act_backward(const float* grad_y_nhwc, const float* y_nhwc, c
                                 float* grad_residual_nhwc, float* grad_weight, float* grad_bias,
                                 void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
+/* Bias [+ ReLU] backward of a convolution, channels-last rows (P, C): grad_pre = grad_y * [y > 0] when relu != 0
+ * (without ReLU the gradient passes unchanged and grad_pre / y may be NULL) and grad_bias (C) = sum over the P rows of
+ * grad_pre.  Replaces the threshold-backward + per-channel-sum pair behind nn.Conv(..., bias=True) [+ relu] of
+ * ConvModule (models/utils/modules.py:L91-175): one pass, deterministic two-stage sum.  Workspace:
+ * jdet_frozen_bn_act_backward_workspace(P, C); C % 4 == 0 and the same channel counts as the BN kernels. */
+int jdet_bias_act_backward(const float* grad_y_nhwc, const float* y_nhwc, long P, int C, int relu,
+                           float* grad_pre_nhwc, float* grad_bias, void* workspace, size_t workspace_bytes,
+                           jdet_stream_t stream);
+
 /* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
  * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
  * out (nOut*nRot, nIn*nOri, kH, kW). */

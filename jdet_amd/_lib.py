@@ -63,6 +63,7 @@ SIGNATURES = {
     "jdet_frozen_bn_act_forward": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
     "jdet_frozen_bn_act_backward_workspace": (_sz, [_l, _i]),
     "jdet_frozen_bn_act_backward": (_i, [_p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "jdet_bias_act_backward": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _sz, _p]),
     "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),

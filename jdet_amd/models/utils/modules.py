@@ -59,21 +59,18 @@ class ConvModule(nn.Module):
             nn.init.constant_(self.norm.bias, 0)
 
     def _fused_conv_relu(self, x, activate):
-        """3x3 / stride 1 / pad 1 conv [+ bias] [+ ReLU] with nothing in between: one implicit-GEMM kernel with the
-        epilogue applied to the accumulators (ops/conv_igemm.py), where that measured faster than the library"""
+        """conv [+ bias] [+ ReLU] with nothing in between (ops/conv_igemm.conv_module): one implicit-GEMM kernel with
+        the epilogue on the accumulators for the 3x3 / stride 1 layers where that measured faster than the library, and
+        a one-pass bias / ReLU backward for every layer with a bias"""
         conv = self.conv
         if self.with_norm or self.order.index("conv") > self.order.index("act") or type(conv) is not nn.Conv2d:
-            return None
-        if (conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups) != ((3, 3), (1, 1), (1, 1), (1, 1), 1):
-            return None
-        if conv.padding_mode != "zeros" or not conv_igemm.preferred(x, conv.weight):
-            return None
-        if conv_igemm.needs_grad(x, conv.weight, conv.bias) and not conv_igemm.TRAIN:
             return None
         relu = bool(activate and self.with_activation)
         if relu and type(self.activate) is not nn.ReLU:
             return None
-        return conv_igemm.conv3x3_bias_act(x, conv.weight, conv.bias, relu)
+        if not (x.is_cuda and x.dtype == conv.weight.dtype):
+            return None
+        return conv_igemm.conv_module(conv, x, relu)
 
     def forward(self, x, activate=True, norm=True):
         y = self._fused_conv_relu(x, activate)

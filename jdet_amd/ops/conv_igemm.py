@@ -94,46 +94,105 @@ def dgrad_weight(weight):
     return hit[1]
 
 
-class _Conv3x3BiasAct(torch.autograd.Function):
-    """y = [relu](conv3x3(x, w) + b): forward = the implicit-GEMM kernel; backward = the library's convolution backward
-    on the ReLU-masked gradient (with DGRAD: grad_x by this kernel on the flipped / transposed weights)."""
+# bias [+ ReLU] backward as ONE pass (csrc/frozen_bn.hip: jdet_bias_act_backward) instead of the framework's
+# threshold_backward + per-channel reduce pair; JDET_BIAS_ACT_BWD=0 switches back (A/B: profiles/r03_conv_igemm.md).
+BIAS_ACT_BWD = os.environ.get("JDET_BIAS_ACT_BWD", "1") == "1"
+_BWD_WS = {}
+
+
+def _bias_bwd_supported(c):
+    q = c // 4
+    return c % 4 == 0 and ((q <= 256 and 256 % q == 0) or 256 < q <= 1024)
+
+
+def bias_act_backward(g, y, relu):
+    """g, y (N, C, H, W) logical -> (grad of the pre-activation (same logical shape, channels_last), grad_bias (C,)):
+    grad_pre = g * [y > 0] when relu, else g itself; grad_bias = grad_pre.sum((0, 2, 3))."""
+    N, C, H, W = g.shape
+    if not (BIAS_ACT_BWD and g.is_cuda and g.dtype == torch.float32 and _bias_bwd_supported(C) and N * H * W > 0):
+        gp = torch.ops.aten.threshold_backward(g, y, 0) if relu else g
+        return gp, gp.sum((0, 2, 3))
+    gn = L.f32c(g.permute(0, 2, 3, 1))
+    P = N * H * W
+    nbytes = L.lib().jdet_frozen_bn_act_backward_workspace(P, C)
+    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+    ws = _BWD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _BWD_WS[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=g.device)
+    gb = torch.empty((C,), dtype=torch.float32, device=g.device)
+    gp = torch.empty_like(gn) if relu else gn
+    yn = L.f32c(y.permute(0, 2, 3, 1)) if relu else None
+    L.check(L.lib().jdet_bias_act_backward(L.ptr(gn), L.ptr(yn), P, C, int(bool(relu)), L.ptr(gp) if relu else None,
+                                           L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_ptr(gn)),
+            "jdet_bias_act_backward")
+    return gp.permute(0, 3, 1, 2), gb
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """y = [relu](conv(x, w) + b).  Forward: the implicit-GEMM kernel (`igemm`: 3x3 / stride 1 / pad 1 only) or the
+    library convolution; backward: bias gradient and ReLU mask in one pass (`bias_act_backward`), then the library's
+    data / weight gradients (with DGRAD, for the igemm shapes: grad_x by the igemm kernel on the flipped weights)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
-        y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu).permute(0, 3, 1, 2)
-        ctx.relu = bool(relu)
-        ctx.bias_sizes = None if bias is None else [weight.shape[0]]
+    def forward(ctx, x, weight, bias, relu, stride, padding, dilation, groups, igemm):
+        if igemm:
+            y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu).permute(0, 3, 1, 2)
+        else:
+            y = torch.ops.aten.convolution(x, weight, bias, stride, padding, dilation, False, [0, 0], groups)
+            if relu:
+                y = torch.relu_(y)
+        ctx.cfg = (bool(relu), list(stride), list(padding), list(dilation), groups, bool(igemm), bias is not None)
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, weight, y = ctx.saved_tensors
-        if ctx.relu:
+        relu, stride, padding, dilation, groups, igemm, has_bias = ctx.cfg
+        gb = None
+        if has_bias and ctx.needs_input_grad[2]:
+            g, gb = bias_act_backward(g, y, relu)
+        elif relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
-        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.bias_sizes is not None and ctx.needs_input_grad[2]]
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False]
         gx = None
-        if need[0] and DGRAD and supported(weight.shape[0], weight.shape[1]):
+        if need[0] and igemm and DGRAD and supported(weight.shape[0], weight.shape[1]):
             gx = conv3x3_nhwc(L.f32c(g.permute(0, 2, 3, 1)), dgrad_weight(weight)).permute(0, 3, 1, 2)
             need[0] = False
-        lx, gw, gb = torch.ops.aten.convolution_backward(g, x, weight, ctx.bias_sizes, [1, 1], [1, 1], [1, 1], False,
-                                                         [0, 0], 1, need) if any(need) else (None, None, None)
-        return (gx if gx is not None else lx), (gw if need[1] else None), (gb if need[2] else None), None
+        lx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
+                                                        groups, need) if any(need) else (None, None, None)
+        return (gx if gx is not None else lx), gw, gb, None, None, None, None, None, None
+
+
+_Conv3x3BiasAct = _ConvBiasAct      # (name used by the round-3 notes)
 
 
 def conv3x3_bias_act(x, weight, bias=None, relu=False):
     """(N, Cin, H, W) logical (channels_last memory is free) -> (N, Cout, H, W) channels_last; differentiable"""
     if needs_grad(x, weight, bias):
-        return _Conv3x3BiasAct.apply(x, weight, bias, relu)
+        return _ConvBiasAct.apply(x, weight, bias, relu, (1, 1), (1, 1), (1, 1), 1, True)
     return conv3x3(x, weight, bias, relu)
 
 
-def conv3x3_module(conv, x, relu=False):
-    """`[relu](conv(x))` for an nn.Conv2d: the fused kernel when the layer is a 3x3 / stride 1 / pad 1 convolution and
-    `preferred()` says so (and, with gradients, the train route is on), the library otherwise."""
-    if (type(conv).__name__ == "Conv2d" and (conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
-            == ((3, 3), (1, 1), (1, 1), (1, 1), 1) and conv.padding_mode == "zeros" and preferred(x, conv.weight)
-            and (TRAIN or not needs_grad(x, conv.weight, conv.bias))):
+def _is_igemm_conv(conv):
+    return ((conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
+            == ((3, 3), (1, 1), (1, 1), (1, 1), 1))
+
+
+def conv_module(conv, x, relu=False):
+    """`[relu](conv(x))` for a plain nn.Conv2d (zeros padding).  3x3 / stride 1 / pad 1 layers take the fused kernel
+    when `preferred()` says so; any layer WITH a bias that needs gradients goes through `_ConvBiasAct`, whose backward
+    produces the bias gradient and the ReLU mask in one pass; everything else is the library call it always was."""
+    plain = type(conv).__name__ == "Conv2d" and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+    grad = needs_grad(x, conv.weight, conv.bias)
+    if plain and _is_igemm_conv(conv) and preferred(x, conv.weight) and (TRAIN or not grad):
         return conv3x3_bias_act(x, conv.weight, conv.bias, relu)
+    if (plain and grad and BIAS_ACT_BWD and conv.bias is not None and x.is_cuda and x.dtype == torch.float32
+            and _bias_bwd_supported(conv.out_channels)):
+        return _ConvBiasAct.apply(x, conv.weight, conv.bias, relu, conv.stride, conv.padding, conv.dilation,
+                                  conv.groups, False)
     y = conv(x)
     return torch.relu(y) if relu else y
+
+
+conv3x3_module = conv_module

@@ -156,3 +156,44 @@ def test_deform_conv_inference_takes_the_fused_kernel():
     xr = x.clone().requires_grad_(True)
     dcn_v1.deform_conv(xr, off, w, 1, 1, 1).sum().backward()
     assert xr.grad is not None
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 33, 17), (1, 64, 8, 8), (3, 512, 5, 7), (1, 1024, 4, 4), (2, 60, 9, 9)])
+def test_bias_act_backward_matches_framework(N, C, H, W, relu):
+    """one-pass bias gradient + ReLU mask (jdet_bias_act_backward) vs threshold_backward + sum; C = 60: the framework
+    fallback (channel count outside the kernel's shapes)"""
+    from jdet_amd.ops import conv_igemm as CI
+    g = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    y = torch.relu(torch.randn(N, C, H, W, device="cuda")).contiguous(memory_format=torch.channels_last)
+    gp, gb = CI.bias_act_backward(g, y, relu)
+    ref = g * (y > 0) if relu else g
+    assert torch.equal(gp, ref)
+    ref_b = ref.double().sum((0, 2, 3))
+    assert (gb.double() - ref_b).abs().max().item() <= 1e-5 * ref.abs().sum((0, 2, 3)).max().item() + 1e-6
+
+
+@pytest.mark.parametrize("k,pad,stride", [(1, 0, 1), (3, 1, 2), (3, 1, 1)])
+def test_conv_module_library_forward_with_fused_bias_backward(k, pad, stride):
+    """layers the implicit GEMM does not take (1x1, strided, small maps) still get the one-pass bias / ReLU backward"""
+    from jdet_amd.models.utils.modules import ConvModule
+    from jdet_amd.ops import conv_igemm as CI
+    torch.manual_seed(9)
+    m = ConvModule(64, 128, k, stride=stride, padding=pad).cuda()
+    torch.nn.init.normal_(m.conv.bias, std=0.1)
+    x = torch.randn(2, 64, 20, 24, device="cuda").contiguous(memory_format=torch.channels_last)
+    outs = []
+    for on in (True, False):
+        CI.BIAS_ACT_BWD = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad()
+            y = m(xi)
+            if on:
+                g = torch.randn_like(y) * (y.detach().abs() > 1e-4)
+            y.backward(g)
+            outs.append((y.detach(), xi.grad, m.conv.weight.grad.clone(), m.conv.bias.grad.clone()))
+        finally:
+            CI.BIAS_ACT_BWD = True
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-6
