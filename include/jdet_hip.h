@@ -227,7 +227,12 @@ int jdet_deform_col2im_nhwc(const float* grad_cols, const float* offset, int B, 
 int jdet_conv3x3_igemm_supported(int Cin, int Cout);
 int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,
                                const float* bias, int relu, const float* rowmask, const float* offset,
-                               int tile, float* y_nhwc, jdet_stream_t stream);
+                               int tile, float* y_nhwc, void* workspace, size_t workspace_bytes,
+                               jdet_stream_t stream);
+/* optional workspace: maps too small to fill the chip with output tiles are split along K over workgroups (partial
+ * tiles summed by a second launch that also applies the epilogue) when a workspace of this size is passed; NULL / 0 =
+ * single pass.  0 when the shape is not split. */
+size_t jdet_conv3x3_igemm_workspace(int N, int H, int W, int Cin, int Cout);
 
 /* RepPoints geometry on 9-point sets (pointsets (N,18) = 9 (x,y) pairs) and the Graham scan of the polygon-IoU loss.
  * jdet_convex_iou: replaces convex_iou_kernel (ops/reppoints_convex_iou/convex_iou_kernel.cu:L258-305): IoU of the

@@ -47,7 +47,8 @@ struct ConvArgs {
   const float* rowmask;  // (N*H*W) or null: multiplies the finished row (after bias / ReLU)
   const float* offset;   // deformable: (N, 18, H, W) [per tap (dy, dx), dcn_v1.py:L132-140]; null = plain conv
   float* y;              // (N, H, W, Cout)
-  int N, H, W, Cin, Cout, relu;
+  float* partial;        // cross-workgroup K split: (ksplit, N*H*W, Cout) partial sums (no epilogue), else null
+  int N, H, W, Cin, Cout, relu, ksplit;
 };
 
 constexpr unsigned kOob = 0xFFFFFFF0u;   // a byte offset past every buffer: the load returns zeros
@@ -110,7 +111,11 @@ void conv3x3_igemm_kernel(ConvArgs a) {
     wv[p] = n0 + row < a.Cout ? (unsigned)(((n0 + row) * 9 * a.Cin + lchunk * 4) * 4) : kOob;
     st_off[p] = swz_bytes<BK>(row, lchunk);
   }
-  const int nsteps = 9 * (a.Cin / BK);   // (host: BK = 32 only when Cin % 32 == 0)
+  const int all_steps = 9 * (a.Cin / BK);   // (host: BK = 32 only when Cin % 32 == 0)
+  // cross-workgroup K split: blockIdx.y takes the K steps [step0, step0 + nsteps) and leaves a partial tile
+  const int step0 = (int)((long)all_steps * blockIdx.y / a.ksplit);
+  const int nsteps = (int)((long)all_steps * (blockIdx.y + 1) / a.ksplit) - step0;
+  const int spt = a.Cin / BK;
 
   unsigned av[PASSES][NC];               // byte offsets of the tap's source pixel(s), or kOob
   float aw[PASSES][NC];                  // deformable: bilinear weights
@@ -193,9 +198,9 @@ void conv3x3_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  int tap = 0, c = 0;
-  set_tap(0);
-  load_step(0, 0);
+  int tap = step0 / spt, c = (step0 - tap * spt) * BK;
+  set_tap(tap);
+  load_step(tap, c);
   store_step(0);
   __syncthreads();
   for (int step = 0; step < nsteps; step++) {
@@ -267,13 +272,38 @@ void conv3x3_igemm_kernel(ConvArgs a) {
           float v = acc[i][j][e];
           if (KG == 2)      // the other wave group's partial sum (read tile by tile: no second accumulator set live)
             v += reinterpret_cast<const float*>(s_raw)[(((wave & 3) * T * T + i * T + j) * 16 + e) * 64 + lane];
-          v += b;
-          if (a.relu) v = fmaxf(v, 0.f);
-          if (a.rowmask) v *= mk[e];
-          a.y[(size_t)m * a.Cout + n] = v;
+          if (a.partial) {
+            a.partial[((size_t)blockIdx.y * M + m) * a.Cout + n] = v;
+          } else {
+            v += b;
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.rowmask) v *= mk[e];
+            a.y[(size_t)m * a.Cout + n] = v;
+          }
         }
       }
     }
+  }
+}
+
+// second stage of the cross-workgroup K split: y = [mask *] [relu] (sum of the partial tiles + bias); one float4 of
+// channels per thread, the partial planes read in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void conv_ksplit_finish_kernel(const float* __restrict__ partial, int ksplit, long M,
+                                                                int Cout, const float* __restrict__ bias, int relu,
+                                                                const float* __restrict__ rowmask,
+                                                                float* __restrict__ y) {
+  const long n4 = M * Cout / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    v4f v = reinterpret_cast<const v4f*>(partial)[i];
+    for (int k = 1; k < ksplit; k++) v += reinterpret_cast<const v4f*>(partial)[(size_t)k * n4 + i];
+    const long m = i * 4 / Cout;
+    const int n = (int)(i * 4 - m * Cout);
+    if (bias) v += *reinterpret_cast<const v4f*>(bias + n);
+    if (relu)
+#pragma unroll
+      for (int k = 0; k < 4; k++) v[k] = fmaxf(v[k], 0.f);
+    if (rowmask) v *= rowmask[m];
+    reinterpret_cast<v4f*>(y)[i] = v;
   }
 }
 
@@ -282,9 +312,9 @@ int launch(const ConvArgs& a, hipStream_t st) {
   const long M = (long)a.N * a.H * a.W;
   const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
   if (a.offset)
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, true>), dim3((unsigned)tiles), dim3(256 * KG), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, true>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
   else
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false>), dim3((unsigned)tiles), dim3(256 * KG), 0, st, a);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
   return jdet_launch_status();
 }
 
@@ -293,9 +323,29 @@ int launch(const ConvArgs& a, hipStream_t st) {
 // Supported: Cin % 16 == 0, 16-byte aligned tensors, N*H*W*max(Cin, Cout) < 2^30; any Cout, any N, H, W.
 JDET_API int jdet_conv3x3_igemm_supported(int Cin, int Cout) { return Cin > 0 && Cin % 16 == 0 && Cout > 0; }
 
+// Cross-workgroup K split for small maps (a tile's 2304-deep reduction is otherwise the floor of the launch): how many
+// ways a problem is split when a workspace is offered, and the bytes that takes.  1 = no split.
+static int ksplit_for(long M, int Cin, int Cout, bool deform) {
+  const long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
+  if (deform || Cout % 4 != 0 || tiles64 >= 384) return 1;
+  const int steps = 9 * (Cin / (Cin % 32 == 0 ? 32 : 16));
+  int k = (int)(768 / tiles64);                 // aim at ~3 workgroups per CU
+  if (k > 8) k = 8;
+  if (k > steps / 4) k = steps / 4;             // at least 4 K steps per part
+  return k < 2 ? 1 : k;
+}
+
+JDET_API size_t jdet_conv3x3_igemm_workspace(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || !jdet_conv3x3_igemm_supported(Cin, Cout)) return 0;
+  const long M = (long)N * H * W;
+  const int k = ksplit_for(M, Cin, Cout, false);
+  return k > 1 ? sizeof(float) * (size_t)k * M * Cout : 0;
+}
+
 JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout,
                                         const float* bias, int relu, const float* rowmask, const float* offset,
-                                        int tile, float* y_nhwc, jdet_stream_t stream) {
+                                        int tile, float* y_nhwc, void* workspace, size_t workspace_bytes,
+                                        jdet_stream_t stream) {
   if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return JDET_E_BADARG;
   if (!jdet_conv3x3_igemm_supported(Cin, Cout)) return JDET_E_UNSUPPORTED;
   if (N == 0) return JDET_OK;
@@ -303,11 +353,9 @@ JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W
   if ((((uintptr_t)x_nhwc) | ((uintptr_t)w_krsc)) & 15) return JDET_E_BADARG;
   const long M = (long)N * H * W;
   if (M * (Cin > Cout ? Cin : Cout) >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
-  ConvArgs a{x_nhwc, w_krsc, bias, rowmask, offset, y_nhwc, N, H, W, Cin, Cout, relu ? 1 : 0};
-  // 128 x 128 tiles once they fill the chip (2 workgroups per CU), 64 x 64 below: four times the workgroups, a
-  // quarter of the per-tile latency chain
+  ConvArgs a{x_nhwc, w_krsc, bias, rowmask, offset, y_nhwc, nullptr, N, H, W, Cin, Cout, relu ? 1 : 0, 1};
   // tile: 0 = automatic; 64 / 128 = edge of the output tile; + 1 selects the 16-deep K step, + 2 a single wave group
-  // (no intra-workgroup K split) -- measurement aids
+  // (no intra-workgroup K split) -- measurement aids.  A forced tile never uses the cross-workgroup split.
   const int edge = tile & ~3;
   if (tile != 0 && edge != 64 && edge != 128) return JDET_E_BADARG;
   const long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
@@ -319,6 +367,21 @@ JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W
   const long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
   const bool split = k32 && !(tile & 2) && !offset && (big || tile || tiles64 < 512);
   hipStream_t st = (hipStream_t)stream;
+  if (tile == 0 && !big) {
+    const int ks = ksplit_for(M, Cin, Cout, offset != nullptr);
+    if (ks > 1 && workspace && workspace_bytes >= sizeof(float) * (size_t)ks * M * Cout) {
+      a.partial = (float*)workspace;
+      a.ksplit = ks;
+      int e = k32 ? launch<64, 32, 1>(a, st) : launch<64, 16, 1>(a, st);
+      if (e) return e;
+      const long n4 = M * Cout / 4;
+      long g = (n4 + 255) / 256;
+      if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(conv_ksplit_finish_kernel, dim3((unsigned)g), dim3(256), 0, st, a.partial, ks, M, Cout, bias,
+                         relu ? 1 : 0, rowmask, y_nhwc);
+      return jdet_launch_status();
+    }
+  }
   if (big) return k32 ? (split ? launch<128, 32, 2>(a, st) : launch<128, 32, 1>(a, st)) : launch<128, 16, 1>(a, st);
   return k32 ? (split ? launch<64, 32, 2>(a, st) : launch<64, 32, 1>(a, st)) : launch<64, 16, 1>(a, st);
 }

@@ -38,12 +38,17 @@ def conv3x3_nhwc(x_nhwc, w_krsc, bias=None, relu=False, rowmask=None, offset=Non
         raise ValueError("offset must be (N, 18, H, W), got %r" % (tuple(offset.shape),))
     x_nhwc, w_krsc = L.f32c(x_nhwc), L.f32c(w_krsc)
     y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=x_nhwc.device)
+    ws, nbytes = None, 0
+    if tile == 0 and offset is None:      # small maps: K split over workgroups through a scratch buffer
+        nbytes = L.lib().jdet_conv3x3_igemm_workspace(N, H, W, Cin, Cout)
+        if nbytes:
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=x_nhwc.device)
     L.check(L.lib().jdet_conv3x3_igemm_forward(
         L.ptr(x_nhwc), N, H, W, Cin, L.ptr(w_krsc), Cout,
         L.ptr(L.f32c(bias)) if bias is not None else None, int(bool(relu)),
         L.ptr(L.f32c(rowmask)) if rowmask is not None else None,
         L.ptr(L.f32c(offset)) if offset is not None else None,
-        int(tile), L.ptr(y), L.stream_ptr(x_nhwc)), "jdet_conv3x3_igemm_forward")
+        int(tile), L.ptr(y), L.ptr(ws), nbytes, L.stream_ptr(x_nhwc)), "jdet_conv3x3_igemm_forward")
     return y
 
 
@@ -54,7 +59,7 @@ def conv3x3(x, weight, bias=None, relu=False, offset=None, tile=0):
 
 
 # fused path only where it measured faster than library conv + bias + ReLU (positions = N*H*W)
-MIN_POSITIONS = 4096
+MIN_POSITIONS = int(os.environ.get("JDET_CONV_MIN_POS", "1"))
 DEFORM_MIN_POSITIONS = 32768
 ENABLED = os.environ.get("JDET_CONV_IGEMM", "1") == "1"     # A/B switch for measurements
 # Train step: the fused forward + the library's data / weight gradients (`_Conv3x3BiasAct`).  S2ANet step 30.05 ms with
