@@ -77,7 +77,7 @@ def preferred(x, weight, min_positions=None):
     N, Cin, H, W = x.shape
     if tuple(weight.shape[1:]) != (Cin, 3, 3) or not supported(Cin, weight.shape[0]):
         return False
-    if N * H * W * max(Cin, weight.shape[0]) >= 2 ** 31:
+    if N * H * W * max(Cin, weight.shape[0]) >= 2 ** 30:          # the kernel addresses with 32-bit byte offsets
         return False
     return N * H * W >= (MIN_POSITIONS if min_positions is None else min_positions)
 
