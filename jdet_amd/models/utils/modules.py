@@ -1,6 +1,7 @@
 """ConvModule = conv (+bias iff no norm) -> [norm] -> [act].  Mirrors python/jdet/models/utils/modules.py
 (L43-175): parameter names `.conv.weight/.conv.bias/.bn.*`, default act ReLU, `act_cfg=None` disables
 the activation (FPN)."""
+import torch
 from torch import nn
 
 from jdet_amd.ops import conv_igemm
@@ -68,8 +69,8 @@ class ConvModule(nn.Module):
         relu = bool(activate and self.with_activation)
         if relu and type(self.activate) is not nn.ReLU:
             return None
-        if not (x.is_cuda and x.dtype == conv.weight.dtype):
-            return None
+        if not (x.is_cuda and x.dtype == conv.weight.dtype) or torch.is_autocast_enabled():
+            return None      # (autocast: the framework path casts per op; the fused route is fp32 only)
         return conv_igemm.conv_module(conv, x, relu)
 
     def forward(self, x, activate=True, norm=True):

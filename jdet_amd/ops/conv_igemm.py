@@ -188,7 +188,8 @@ def conv_module(conv, x, relu=False):
     """`[relu](conv(x))` for a plain nn.Conv2d (zeros padding).  3x3 / stride 1 / pad 1 layers take the fused kernel
     when `preferred()` says so; any layer WITH a bias that needs gradients goes through `_ConvBiasAct`, whose backward
     produces the bias gradient and the ReLU mask in one pass; everything else is the library call it always was."""
-    plain = type(conv).__name__ == "Conv2d" and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+    plain = (type(conv).__name__ == "Conv2d" and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+             and not torch.is_autocast_enabled())
     grad = needs_grad(x, conv.weight, conv.bias)
     if plain and _is_igemm_conv(conv) and preferred(x, conv.weight) and (TRAIN or not grad):
         return conv3x3_bias_act(x, conv.weight, conv.bias, relu)

@@ -9,11 +9,13 @@ Two kinds of expected outputs, said per file:
     (oracle/_ref, see oracle/build_ref.py).  While generating, the restatement oracle/jdet_oracle.cpp is checked
     against them bit for bit -- that is how those parts of the oracle are pinned.  (`iou_cudasort` in
     box_iou_rotated.npz, the reference's CUDA exchange-sort ordering, is restatement output: CUDA-only source.)
-  * roi_align.npz, riroi_align.npz, deform_conv.npz: the reference has these operators as CUDA kernels only, which
+  * roi_align.npz, riroi_align.npz, deform_conv.npz, dcn_v2.npz, convex_ops.npz: the reference has these operators as
+    CUDA kernels only, which
     cannot be built in this image without stand-ins for the CUDA built-ins (not done: build_ref.py).  The expected
     outputs are those of the restatement oracle/jdet_oracle.cpp, written only AFTER the restatement has passed the
-    closed-form pins (tests/closed_form.py: affine-map RoIAlign for all five dialects, integer-offset DeformConv --
-    neither involves the restatement's own arithmetic).  They serve the GPU box, where they are the regression
+    closed-form pins (tests/closed_form.py: affine-map RoIAlign for all five dialects, integer-offset DeformConv;
+    tests/test_dcn_v2_oracle.py, tests/test_convex_oracle.py for the round-3 operators -- none involves the
+    restatement's own arithmetic).  They serve the GPU box, where they are the regression
     vectors of the HIP kernels.
 """
 import os
@@ -171,6 +173,70 @@ def gen_dcn_arf():
     save("arf", idx=idx, w=w, y=y, g=g, gw=gw, idx1=idx1, w1=w1, y1=y1)
 
 
+def gen_dcn_v2():
+    rng = np.random.default_rng(400)
+    out = {}
+    for nm, (B, C, Cout, H, W, k, pad, stride, dil, dg) in {
+        "a": (2, 8, 6, 9, 11, 3, (1, 1), 1, 1, 2),
+        "b": (1, 6, 4, 10, 8, 3, (2, 1), 1, 1, 3),          # asymmetric padding: the (pad_h, pad_h) input gradient
+        "c": (2, 4, 5, 12, 9, 3, (2, 2), 2, 2, 1),
+    }.items():
+        Ho = (H + 2 * pad[0] - (dil * (k - 1) + 1)) // stride + 1
+        Wo = (W + 2 * pad[1] - (dil * (k - 1) + 1)) // stride + 1
+        x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((Cout, C, k, k)) / np.sqrt(C * k * k)).astype(np.float32)
+        bias = rng.standard_normal((Cout,)).astype(np.float32)
+        off = (rng.standard_normal((B, dg * 2 * k * k, Ho, Wo)) * 2.0).astype(np.float32)
+        off.flat[::7] = np.round(off.flat[::7])
+        mask = rng.uniform(0, 1, size=(B, dg * k * k, Ho, Wo)).astype(np.float32)
+        g = rng.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+        a = (pad, (stride, stride), (dil, dil), dg)
+        y = O.dcn_v2_forward(x, off, mask, w, bias, *a)
+        gi, go, gm, gw, gb = O.dcn_v2_backward(x, off, mask, w, g, *a)
+        out.update({k_ + "_" + nm: v for k_, v in dict(x=x, w=w, bias=bias, off=off, mask=mask, g=g, y=y, gi=gi, go=go,
+                                                       gm=gm, gw=gw, gb=gb,
+                                                       cfg=np.asarray([k, pad[0], pad[1], stride, dil, dg])).items()})
+    # deformable PSRoI pooling: test_pool's shape class (dcn_v2.py:L1470-1508), scaled down
+    R, N, H, W, od, G, P, part, ncls, spp, tstd, scale = 12, 2, 20, 24, 8, 2, 4, 4, 2, 3, 0.2, 0.25
+    x = rng.standard_normal((N, od * G * G, H, W)).astype(np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = rng.integers(0, N, R)
+    x1, y1 = rng.uniform(-12, W / scale, R), rng.uniform(-12, H / scale, R)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, W / scale / 2, R), y1 + rng.uniform(0, H / scale / 2, R)
+    trans = rng.standard_normal((R, 2 * ncls, part, part)).astype(np.float32)
+    g = rng.standard_normal((R, od, P, P)).astype(np.float32)
+    for nm, no_trans in (("plain", True), ("deform", False)):
+        y, cnt = O.deform_psroi_forward(x, rois, trans, no_trans, scale, od, G, P, part, spp, tstd)
+        gi, gt = O.deform_psroi_backward(g, cnt, x, rois, trans, no_trans, scale, od, G, P, part, spp, tstd)
+        out.update({"ps_y_" + nm: y, "ps_cnt_" + nm: cnt, "ps_gi_" + nm: gi, "ps_gt_" + nm: gt})
+    out.update(ps_x=x, ps_rois=rois, ps_trans=trans, ps_g=g,
+               ps_cfg=np.asarray([od, G, P, part, spp], np.int32), ps_f=np.asarray([scale, tstd], np.float32))
+    save("dcn_v2", **out)
+
+
+def gen_convex():
+    rng = np.random.default_rng(500)
+    c = rng.uniform(40, 160, size=(40, 1, 2))
+    ps = (c + rng.normal(0, 14, size=(40, 9, 2))).reshape(40, 18).astype(np.float32)
+    ps[0] = np.tile(ps[0, :2], 9)                                           # degenerate: one point nine times
+    ps[1] = np.stack([np.linspace(10, 90, 9), np.linspace(20, 60, 9)], 1).reshape(18)    # collinear
+    quads = []
+    for _ in range(11):
+        cx, cy, w, h, t = rng.uniform(40, 160), rng.uniform(40, 160), rng.uniform(10, 80), rng.uniform(6, 50), \
+            rng.uniform(-np.pi, np.pi)
+        d = np.asarray([[-.5, -.5], [.5, -.5], [.5, .5], [-.5, .5]]) * [w, h]
+        quads.append((d @ np.asarray([[np.cos(t), np.sin(t)], [-np.sin(t), np.cos(t)]]) + [cx, cy]).reshape(8))
+    quads = np.asarray(quads, np.float32)
+    quads[::3] = quads[::3].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)
+    pts = rng.uniform(0, 50, size=(30, 12, 2)).astype(np.float32)
+    pts[:, -1] = pts[:, 0]
+    masks = (rng.uniform(size=(30, 12)) > 0.3).astype(np.float32)
+    masks[:, 0] = 1
+    save("convex_ops", pointsets=ps, quads=quads, ious=O.convex_iou(ps, quads), boxes=O.min_area_bbox(ps), pts=pts,
+         masks=masks, sort_circular=O.convex_sort(pts, masks, True), sort_open=O.convex_sort(pts, masks, False))
+
+
 if __name__ == "__main__":
     if not O.have_ref():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -178,11 +244,14 @@ if __name__ == "__main__":
         build_ref.build()
     # the restatement-generated fixtures are written only behind the closed-form pins
     import subprocess
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_closed_form_cpu.py"), "-q", "-x"],
-                       cwd=ROOT)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x"] +
+                       [os.path.join(ROOT, "tests", f) for f in ("test_closed_form_cpu.py", "test_dcn_v2_oracle.py",
+                                                                 "test_convex_oracle.py")], cwd=ROOT)
     if r.returncode != 0:
         raise SystemExit("closed-form pins failed: not writing restatement fixtures")
     gen_roi_align()
     gen_iou_nms()
     gen_dcn_arf()
+    gen_dcn_v2()
+    gen_convex()
     print("all checks passed")

@@ -89,3 +89,20 @@ def test_convex_sort_limits():
     with pytest.raises(L.JDetHipError):
         convex_sort(torch.zeros(1, 65, 2).cuda(), torch.ones(1, 65).cuda())
     assert convex_sort(torch.zeros(2, 0, 2).cuda(), torch.ones(2, 0).cuda()).tolist() == [[-1], [-1]]
+
+
+def test_convex_ops_vs_golden(golden):
+    from jdet_amd.ops.convex_sort import convex_sort
+    from jdet_amd.ops.reppoints_convex_iou import reppoints_convex_iou
+    from jdet_amd.ops.reppoints_min_area_bbox import reppoints_min_area_bbox
+    g = golden("convex_ops")
+    ps, q = torch.from_numpy(g["pointsets"]).cuda(), torch.from_numpy(g["quads"]).cuda()
+    got = reppoints_convex_iou(ps, q).cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(g["ious"]))
+    np.testing.assert_allclose(np.nan_to_num(got), np.nan_to_num(g["ious"]), rtol=0, atol=1e-6)
+    box, ref = reppoints_min_area_bbox(ps).cpu().numpy()[2:], g["boxes"][2:]          # rows 0, 1 are degenerate sets
+    area = lambda b: np.linalg.norm(b[:, 0:2] - b[:, 2:4], axis=1) * np.linalg.norm(b[:, 4:6] - b[:, 2:4], axis=1)
+    np.testing.assert_allclose(area(box), area(ref), rtol=1e-4)
+    pts, masks = torch.from_numpy(g["pts"]).cuda(), torch.from_numpy(g["masks"]).cuda()
+    np.testing.assert_array_equal(convex_sort(pts, masks, True).cpu().numpy(), g["sort_circular"])
+    np.testing.assert_array_equal(convex_sort(pts, masks, False).cpu().numpy(), g["sort_open"])

@@ -127,3 +127,28 @@ def test_pooling_modules():
     assert torch.allclose(y, plain(x, rois, off) * 0.5, atol=1e-6)
     assert dcn_v2.DCNPooling(0.25, 7, 32, no_trans=True)(x, rois).shape == (3, 32, 7, 7)
     assert plain(x, rois[:0], off[:0]).shape == (0, 32, 7, 7)
+
+
+def test_dcn_v2_vs_golden(golden):
+    """the committed regression vectors (oracle outputs written behind its closed-form pins)"""
+    from jdet_amd.ops import dcn_v2
+    g = golden("dcn_v2")
+    for nm in "abc":
+        k, ph, pw, stride, dil, dg = [int(v) for v in g["cfg_" + nm]]
+        t = [torch.from_numpy(g[key + "_" + nm]).cuda().requires_grad_(True) for key in ("x", "off", "mask", "w", "bias")]
+        y = dcn_v2.dcn_v2_conv(*t, (stride, stride), (ph, pw), (dil, dil), dg)
+        y.backward(torch.from_numpy(g["g_" + nm]).cuda())
+        _close(y.detach().cpu().numpy(), g["y_" + nm], 2e-5, "y_" + nm)
+        for v, key in zip(t, ("gi", "go", "gm", "gw", "gb")):
+            _close(v.grad.cpu().numpy(), g[key + "_" + nm], 1e-4, key + "_" + nm)
+    od, G, P, part, spp = [int(v) for v in g["ps_cfg"]]
+    scale, tstd = [float(v) for v in g["ps_f"]]
+    for nm, no_trans in (("plain", True), ("deform", False)):
+        xt = torch.from_numpy(g["ps_x"]).cuda().requires_grad_(True)
+        tt = torch.from_numpy(g["ps_trans"]).cuda().requires_grad_(True)
+        y = dcn_v2.dcn_v2_pooling(xt, torch.from_numpy(g["ps_rois"]).cuda(), tt, scale, P, od, no_trans, G, part, spp, tstd)
+        y.backward(torch.from_numpy(g["ps_g"]).cuda())
+        _close(y.detach().cpu().numpy(), g["ps_y_" + nm], 2e-6, "ps_y_" + nm)
+        _close(xt.grad.cpu().numpy(), g["ps_gi_" + nm], 2e-5, "ps_gi_" + nm)
+        if not no_trans:
+            _close(tt.grad.cpu().numpy(), g["ps_gt_" + nm], 1e-4, "ps_gt_" + nm)

@@ -123,3 +123,34 @@ def test_arf_oracle_vs_golden(golden):
     # rotation 0 is the identity permutation
     y = g["y"].reshape(4, 8, 3, 8, 3, 3)
     np.testing.assert_array_equal(y[:, 0], g["w"])
+
+
+def test_dcn_v2_restatement_vs_golden(golden):
+    """regression vectors of the round-3 operators (written by gen_golden.py behind the closed-form pins)"""
+    g = golden("dcn_v2")
+    for nm in "abc":
+        k, ph, pw, stride, dil, dg = [int(v) for v in g["cfg_" + nm]]
+        a = ((ph, pw), (stride, stride), (dil, dil), dg)
+        x, off, mask, w = g["x_" + nm], g["off_" + nm], g["mask_" + nm], g["w_" + nm]
+        np.testing.assert_array_equal(O.dcn_v2_forward(x, off, mask, w, g["bias_" + nm], *a), g["y_" + nm])
+        for got, key in zip(O.dcn_v2_backward(x, off, mask, w, g["g_" + nm], *a), ("gi", "go", "gm", "gw", "gb")):
+            np.testing.assert_array_equal(got, g[key + "_" + nm])
+    od, G, P, part, spp = [int(v) for v in g["ps_cfg"]]
+    scale, tstd = [float(v) for v in g["ps_f"]]
+    for nm, no_trans in (("plain", True), ("deform", False)):
+        y, cnt = O.deform_psroi_forward(g["ps_x"], g["ps_rois"], g["ps_trans"], no_trans, scale, od, G, P, part, spp, tstd)
+        np.testing.assert_array_equal(y, g["ps_y_" + nm])
+        np.testing.assert_array_equal(cnt, g["ps_cnt_" + nm])
+        gi, gt = O.deform_psroi_backward(g["ps_g"], cnt, g["ps_x"], g["ps_rois"], g["ps_trans"], no_trans, scale, od,
+                                         G, P, part, spp, tstd)
+        np.testing.assert_array_equal(gi, g["ps_gi_" + nm])
+        if not no_trans:
+            np.testing.assert_array_equal(gt, g["ps_gt_" + nm])
+
+
+def test_convex_restatement_vs_golden(golden):
+    g = golden("convex_ops")
+    np.testing.assert_array_equal(O.convex_iou(g["pointsets"], g["quads"]), g["ious"])
+    np.testing.assert_array_equal(O.min_area_bbox(g["pointsets"]), g["boxes"])
+    np.testing.assert_array_equal(O.convex_sort(g["pts"], g["masks"], True), g["sort_circular"])
+    np.testing.assert_array_equal(O.convex_sort(g["pts"], g["masks"], False), g["sort_open"])
