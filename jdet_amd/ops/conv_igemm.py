@@ -123,6 +123,8 @@ def bias_act_backward(g, y, relu):
     key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        if len(_BWD_WS) >= 8:          # streams come and go (graph captures): keep the scratch cache bounded
+            _BWD_WS.clear()
         ws = _BWD_WS[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=g.device)
     gb = torch.empty((C,), dtype=torch.float32, device=g.device)
     gp = torch.empty_like(gn) if relu else gn
