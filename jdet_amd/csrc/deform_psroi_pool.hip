@@ -19,7 +19,7 @@
 namespace {
 
 struct PsP {
-  int C, H, W, R, no_trans, output_dim, group, P, part, spp, num_classes, ch_each_class;
+  int N, C, H, W, R, no_trans, output_dim, group, P, part, spp, num_classes, ch_each_class;
   float scale, trans_std;
 };
 
@@ -81,6 +81,11 @@ __global__ __launch_bounds__(256) void psroi_fwd_kernel(const float* __restrict_
                                                        float* __restrict__ out, float* __restrict__ top_count) {
   for (long index = (long)blockIdx.x * 256 + threadIdx.x; index < count; index += (long)gridDim.x * 256) {
     const Bin b = bin_of(p, index, rois, trans);
+    if (b.batch < 0 || b.batch >= p.N) {     // (the reference reads out of bounds here; a bad batch index pools nothing)
+      out[index] = 0.f;
+      top_count[index] = 0.f;
+      continue;
+    }
     const int c = (b.ctop * p.group + b.gh) * p.group + b.gw;
     const float* plane = input + ((size_t)b.batch * p.C + c) * p.H * p.W;
     float sum = 0.f;
@@ -146,7 +151,7 @@ int fill(PsP& p, int N, int C, int H, int W, int R, int no_trans, float spatial_
       part_size <= 0 || sample_per_part <= 0)
     return JDET_E_BADARG;
   if (C != output_dim * group_size * group_size) return JDET_E_BADARG;
-  p.C = C; p.H = H; p.W = W; p.R = R; p.no_trans = no_trans ? 1 : 0; p.output_dim = output_dim; p.group = group_size;
+  p.N = N; p.C = C; p.H = H; p.W = W; p.R = R; p.no_trans = no_trans ? 1 : 0; p.output_dim = output_dim; p.group = group_size;
   p.P = pooled_size; p.part = part_size; p.spp = sample_per_part; p.scale = spatial_scale; p.trans_std = trans_std;
   // L951-952: num_classes = no_trans ? 1 : trans channels / 2; channels_each_class = output_dim / num_classes
   p.num_classes = no_trans ? 1 : trans_channels / 2;

@@ -930,8 +930,8 @@ PsBin ps_bin(long index, const float* rois, const float* trans, int no_trans, fl
 
 }  // namespace
 
-JO_API void jo_deform_psroi_forward(const float* input, const float* rois, const float* trans, int C, int H, int W,
-                                    int R, int no_trans, float spatial_scale, int output_dim, int group_size, int P,
+JO_API void jo_deform_psroi_forward(const float* input, const float* rois, const float* trans, int N, int C, int H,
+                                    int W, int R, int no_trans, float spatial_scale, int output_dim, int group_size, int P,
                                     int part_size, int spp, float trans_std, int trans_channels, float* out,
                                     float* top_count) {
   const int num_classes = no_trans ? 1 : trans_channels / 2;
@@ -942,6 +942,11 @@ JO_API void jo_deform_psroi_forward(const float* input, const float* rois, const
                            trans_std, num_classes, cec);
     float sum = 0;
     int cnt = 0;
+    if (b.batch < 0 || b.batch >= N) {   // (out-of-bounds read in the reference; here: nothing pooled)
+      out[index] = 0.f;
+      top_count[index] = 0;
+      continue;
+    }
     const float* data = input + (size_t)b.batch * C * H * W;
     for (int ih = 0; ih < spp; ih++)
       for (int iw = 0; iw < spp; iw++) {

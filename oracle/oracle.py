@@ -192,7 +192,7 @@ def deform_psroi_forward(x, rois, trans, no_trans, spatial_scale, output_dim, gr
     out = np.zeros((R, output_dim, pooled_size, pooled_size), np.float32)
     cnt = np.zeros_like(out)
     tch = 2 if no_trans else trans.shape[1]
-    lib().jo_deform_psroi_forward(_ptr(x), _ptr(rois), _ptr(trans), *_psroi_args(
+    lib().jo_deform_psroi_forward(_ptr(x), _ptr(rois), _ptr(trans), _i(x.shape[0]), *_psroi_args(
         x, R, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, spp, trans_std, tch),
         _ptr(out), _ptr(cnt))
     return out, cnt
