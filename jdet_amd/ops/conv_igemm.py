@@ -1,15 +1,16 @@
-"""3x3 convolution / deformable convolution forward as one fp32-MFMA implicit GEMM (csrc/conv_igemm.hip).
+"""3x3 convolution / deformable convolution forward as one fp32-MFMA implicit GEMM (csrc/conv_igemm.hip), and the
+one-pass bias / ReLU backward of every conv + bias [+ ReLU] (csrc/frozen_bn.hip: jdet_bias_act_backward).
 
-Replaces, for inference, the `nn.Conv(3x3) [+ ReLU]` of ConvModule (python/jdet/models/utils/modules.py:L91-175) in
-the head towers and the FPN, and the im2col + matmul pair of DeformConv.execute (python/jdet/ops/dcn_v1.py:L412-454):
-no column matrix, bias / ReLU / gap-row mask applied to the accumulators.  The kernel is a forward kernel:
-`conv3x3_bias_act` gives it a backward through the library's data / weight gradient kernels (the ReLU mask comes from
-the saved output), the deformable form is used where no gradient is needed (the training path keeps the column-matrix
-deformable conv, whose weight-gradient GEMM reads the columns).
+Replaces the `nn.Conv(3x3) [+ ReLU]` of ConvModule (python/jdet/models/utils/modules.py:L91-175) in the head towers,
+the FPN and the RPNs, and -- where no gradient is needed -- the im2col + matmul pair of DeformConv.execute
+(python/jdet/ops/dcn_v1.py:L412-454): no column matrix, bias / ReLU / gap-row mask applied to the accumulators.  The
+kernel is a forward kernel: `_ConvBiasAct` gives it a backward through the library's data / weight gradient kernels
+(the ReLU mask and the bias gradient come out of one pass over the incoming gradient); the training path of the
+deformable conv keeps the column matrix, which its weight-gradient GEMM reads.
 
 Measured on MI355X, 256 -> 256 channels, batch 2 (scripts/conv_igemm_timing.py, profiles/r03_conv_igemm.md):
-128^2 map 336 us vs 390 us for library conv + bias + ReLU; 64^2 map 111 vs 127 us; below that the 2304-deep reduction
-per tile makes the tile's own latency the floor (74 us) and the library (split-K) wins, so `preferred()` says no.
+128^2 map 296 us (130.6 TFLOP/s, MFMA busy 80.8 %) vs 394 us for library conv + bias + ReLU; 64^2 map 86-94 vs 126 us;
+32^2 / 16^2 / 8^2 maps 37 / 18 / 16 us vs 55 / 29 / 26 us (K steps split over workgroups through a scratch buffer).
 """
 import os
 
@@ -58,7 +59,8 @@ def conv3x3(x, weight, bias=None, relu=False, offset=None, tile=0):
     return y.permute(0, 3, 1, 2)
 
 
-# fused path only where it measured faster than library conv + bias + ReLU (positions = N*H*W)
+# smallest map (positions = N*H*W) the fused path takes: it measured faster than library conv + bias + ReLU at every
+# size once small maps split their K steps over workgroups; the deformable form only where it beats im2col + GEMM
 MIN_POSITIONS = int(os.environ.get("JDET_CONV_MIN_POS", "1"))
 DEFORM_MIN_POSITIONS = 32768
 ENABLED = os.environ.get("JDET_CONV_IGEMM", "1") == "1"     # A/B switch for measurements
