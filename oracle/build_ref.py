@@ -14,12 +14,13 @@ _v1), rotated NMS (nms_rotated.py ML_NMS_ROTATED_CPU_HEADER, BOX_LENGTH 5 and 6)
 (orn.py ARF_CPU_HEADER).  The only edit is dropping `#include <executor.h>`, a Jittor header the arithmetic never
 uses.
 
-What is NOT built: RoIAlign (x5 dialects) and DeformConv exist only as CUDA kernels in the reference (`__global__`,
-blockIdx, atomicAdd ...).  Compiling them on the host needs stand-ins for the CUDA built-ins, i.e. it is not "the
-reference compiled here": those operators are UNBUILDABLE in this image (round 1 did build them behind such a
-shim; removed).  Their oracle (oracle/jdet_oracle.cpp) is pinned instead by closed forms that involve neither the
-restatement nor any reference build: tests/closed_form.py (affine-map RoIAlign for all five dialects, integer-offset
-DeformConv), tests/test_closed_form_cpu.py.
+What is NOT built here: RoIAlign (x5 dialects), DeformConv and the other CUDA-only operators (`__global__`, blockIdx,
+atomicAdd ...).  Compiling them for the HOST would need stand-ins for the CUDA built-ins, i.e. it would not be "the
+reference compiled here" (round 1 did that behind a shim; removed).  Compiling them for the GPU needs none: the
+kernel dialect is hipcc's own -- oracle/build_ref_hip.py does that, and tests/test_gpu_reference_kernels.py pins the
+restatement (oracle/jdet_oracle.cpp) and the product kernels against those kernels on the device.  On the CPU the
+restatement is additionally held to closed forms that involve neither itself nor any reference build:
+tests/closed_form.py, tests/test_closed_form_cpu.py.
 """
 import ast
 import os

@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Build oracle/_ref/libjdet_ref_hip.so: the reference's OWN GPU kernels, compiled for gfx950.  TEST INFRASTRUCTURE.
+
+The operators SURVEY 8(a) lists as "CUDA only" (the five RoIAligns, DeformConv v1 sampling, feature refinement, the
+RepPoints geometry, convex_sort) have no CPU source in the reference, but their kernel text is plain CUDA C++ --
+`__global__` functions, blockIdx / threadIdx, atomicAdd, <<< >>> launches -- and that dialect is what hipcc compiles
+natively: no stand-in for a CUDA built-in, header, library or tool is written here.  As oracle/build_ref.py does for
+the CPU sources, this recipe reads the kernel text with `ast` from the files WHERE THEY LIE under /root/reference
+(nothing is copied into the repo; the generated .hip lives and dies in a TemporaryDirectory), puts every file's text in
+its own namespace, and appends `extern "C"` entry points that launch the kernels with the grid / block arithmetic of the
+reference's `jt.code` launch snippets (cited per entry point).  The only edit to the kernel text is dropping
+`#include <executor.h>` (a Jittor header none of these kernels uses), as in build_ref.py.
+
+Two builds of the same text: `-ffp-contract=off` (libjdet_ref_hip.so: the operation order of the text, no fused
+multiply-add -- what the CPU restatement oracle/jdet_oracle.cpp is written to match bit for bit) and hipcc's default
+contraction (libjdet_ref_hip_fma.so: what a CUDA toolchain's default `-fmad=true` would do to the same text).
+
+Needs /root/reference and hipcc: runs in the build container (hipcc cross-compiles gfx950 without a GPU); the .so files
+travel to the GPU box with the snapshot (oracle/_ref/ is git-ignored, not gpurun-ignored), where tests/ use them to pin
+both the HIP kernels and the CPU restatement against the reference's kernels running on the same device.
+
+NOT built: dcn_v2.py's kernels (their header pulls cuBLAS and Jittor's executor), nms_poly.py (executor types in the
+kernel text), the kernels of models outside SURVEY 8.
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from build_ref import OPS, OUT_DIR, module_strings  # noqa: E402
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+PRELUDE = r'''
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <climits>
+#include <cfloat>
+#include <math.h>
+#include <stdio.h>
+#include <float.h>
+#include <algorithm>
+#include <vector>
+using std::min; using std::max;
+#define API extern "C" __attribute__((visibility("default")))
+static inline int ref_sync() { return (int)hipDeviceSynchronize(); }
+'''
+
+UNDEF = ("#undef CUDA_1D_KERNEL_LOOP\n#undef CUDA_KERNEL_LOOP\n#undef THREADS_PER_BLOCK\n#undef PI\n#undef maxn\n"
+         "#undef nmax\n#undef CeilDIV\n#undef ROI_ALIGN_VERSION\n")
+
+
+def ns(name, body):
+    body = re.sub(r"#include\s*<executor.h>", "", body).replace("#undef out", "")
+    return "namespace %s {\n%s\n}\n%s" % (name, body, UNDEF)
+
+
+ENTRY = r'''
+// ---- roi_align_rotated.py:L265-283 / L286-307 (and the _v1 twin L311-349): one thread per output element
+#define ROT_ENTRY(NS, NAME)                                                                                        \
+API int NAME##_forward(const float* input, const float* rois, int R, int C, int H, int W, int PH, int PW,          \
+                       float spatial_scale, float sampling_ratio, float* out) {                                    \
+  const int output_size = R * PH * PW * C;                                                                        \
+  if (output_size)                                                                                                 \
+    NS::ROIAlignRotatedForward<<<NS::GET_BLOCKS(output_size), 1024>>>(output_size, input, rois, spatial_scale,    \
+                                                                      sampling_ratio, C, H, W, PH, PW, out);      \
+  return ref_sync();                                                                                               \
+}                                                                                                                  \
+API int NAME##_backward(const float* grad, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,  \
+                        float spatial_scale, float sampling_ratio, float* grad_input) {                            \
+  const int output_size = R * PH * PW * C;                                                                        \
+  hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * C * H * W);                                           \
+  if (output_size)                                                                                                 \
+    NS::ROIAlignBackward<<<NS::GET_BLOCKS(output_size), 1024>>>(output_size, grad, rois, spatial_scale,           \
+                                                                sampling_ratio, C, H, W, PH, PW, grad_input);     \
+  return ref_sync();                                                                                               \
+}
+ROT_ENTRY(ref_rroi, refhip_roi_align_rotated)
+ROT_ENTRY(ref_rroi_v1, refhip_roi_align_rotated_v1)
+
+// ---- riroi_align.py:L404-427 / L440-468: the header's own launchers (C = channels per orientation)
+API int refhip_riroi_align_forward(const float* input, const float* rois, int R, int C, int H, int W, int PH, int PW,
+                                   float spatial_scale, int sample_num, int nO, float* out) {
+  hipMemsetAsync(out, 0, sizeof(float) * (size_t)R * C * nO * PH * PW);
+  if (R) ref_riroi::RiROIAlignForwardLaucher<float>(input, rois, spatial_scale, sample_num, C, H, W, R, PH, PW, nO, out);
+  return ref_sync();
+}
+API int refhip_riroi_align_backward(const float* grad, const float* rois, int R, int N, int C, int H, int W, int PH,
+                                    int PW, float spatial_scale, int sample_num, int nO, float* grad_input) {
+  hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * C * nO * H * W);
+  if (R) ref_riroi::RiROIAlignBackwardLaucher<float>(grad, rois, spatial_scale, sample_num, C, H, W, R, PH, PW, nO,
+                                                     grad_input);
+  return ref_sync();
+}
+
+// ---- roi_align.py:L217-237 / L240-263 (ROI_ALIGN_VERSION 0 and 1; 512 threads per block)
+#define HBB_ENTRY(NS, NAME)                                                                                        \
+API int NAME##_forward(const float* input, const float* rois, int R, int C, int H, int W, int PH, int PW,          \
+                       float spatial_scale, float sampling_ratio, float* out) {                                    \
+  const int output_size = R * PH * PW * C;                                                                        \
+  if (output_size)                                                                                                 \
+    NS::RoIAlignForward<<<(output_size + 511) / 512, 512>>>(output_size, input, C, H, W, PH, PW, rois, out,       \
+                                                            spatial_scale, sampling_ratio);                       \
+  return ref_sync();                                                                                               \
+}                                                                                                                  \
+API int NAME##_backward(const float* grad, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,  \
+                        float spatial_scale, float sampling_ratio, float* grad_input) {                            \
+  const int output_size = R * PH * PW * C;                                                                        \
+  hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * C * H * W);                                           \
+  if (output_size)                                                                                                 \
+    NS::RoIAlignBackwardFeature<<<(output_size + 511) / 512, 512>>>(output_size, grad, R, C, H, W, PH, PW,        \
+                                                                    grad_input, rois, spatial_scale,              \
+                                                                    sampling_ratio);                              \
+  return ref_sync();                                                                                               \
+}
+HBB_ENTRY(ref_hroi0, refhip_roi_align_v0)
+HBB_ENTRY(ref_hroi1, refhip_roi_align_v1)
+
+// ---- dcn_v1.py:L309-338 (im2col), L374-410 (col2im), L340-372 (col2im_coord); parallel_imgs = B
+API int refhip_deform_im2col(const float* im, const float* offset, int B, int C, int H, int W, int kh, int kw,
+                             int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* col) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int num_kernels = C * Ho * Wo * B;
+  hipMemsetAsync(col, 0, sizeof(float) * (size_t)C * kh * kw * B * Ho * Wo);
+  if (num_kernels)
+    ref_dcn::deformable_im2col_gpu_kernel<<<ref_dcn::GET_BLOCKS(num_kernels), ref_dcn::CUDA_NUM_THREADS>>>(
+        num_kernels, im, offset, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, C / dg, B, C, dg, Ho, Wo,
+        col);
+  return ref_sync();
+}
+API int refhip_deform_col2im(const float* col, const float* offset, int B, int C, int H, int W, int kh, int kw,
+                             int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                             float* grad_im) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int num_kernels = C * kh * kw * Ho * Wo * B;
+  hipMemsetAsync(grad_im, 0, sizeof(float) * (size_t)B * C * H * W);
+  if (num_kernels)
+    ref_dcn::deformable_col2im_gpu_kernel<<<ref_dcn::GET_BLOCKS(num_kernels), ref_dcn::CUDA_NUM_THREADS>>>(
+        num_kernels, col, offset, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w, C / dg, B, dg, Ho, Wo,
+        grad_im, B + C + H + W);
+  return ref_sync();
+}
+API int refhip_deform_col2im_coord(const float* col, const float* im, const float* offset, int B, int C, int H, int W,
+                                   int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                   int dil_w, int dg, float* grad_offset) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  const int num_kernels = Ho * Wo * 2 * kh * kw * dg * B;
+  hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)num_kernels);
+  if (num_kernels)
+    ref_dcn::deformable_col2im_coord_gpu_kernel<<<ref_dcn::GET_BLOCKS(num_kernels), ref_dcn::CUDA_NUM_THREADS>>>(
+        num_kernels, col, im, offset, C, H, W, kh, kw, pad_h, pad_w, stride_h, stride_w, dil_h, dil_w,
+        C * kh * kw / dg, B, 2 * kh * kw * dg, dg, Ho, Wo, grad_offset);
+  return ref_sync();
+}
+
+// ---- fr.py:L234-254: features (N, C, H, W), best_bboxes (N, H, W, 5)
+API int refhip_feature_refine_forward(const float* features, const float* boxes, int N, int C, int H, int W,
+                                      float spatial_scale, int points, float* out) {
+  const int output_size = N * C * H * W;
+  if (output_size)
+    ref_fr::feature_refine_forward_kernel<<<ref_fr::GET_BLOCKS(output_size), 1024>>>(output_size, points, features,
+                                                                                     boxes, spatial_scale, C, H, W, out);
+  return ref_sync();
+}
+API int refhip_feature_refine_backward(const float* top_grad, const float* boxes, int N, int C, int H, int W,
+                                       float spatial_scale, int points, float* bottom_grad) {
+  const int output_size = N * C * H * W;
+  hipMemsetAsync(bottom_grad, 0, sizeof(float) * (size_t)output_size);          // jt.zeros_like(top_grad), L245
+  if (output_size)
+    ref_fr::feature_refine_backward_kernel<<<ref_fr::GET_BLOCKS(output_size), 1024>>>(output_size, points, top_grad,
+                                                                                      boxes, spatial_scale, C, H, W,
+                                                                                      bottom_grad);
+  return ref_sync();
+}
+
+// ---- reppoints_convex_iou/convex_iou.py:L7-27, reppoints_min_area_bbox/min_area_bbox.py:L7-20 (512 threads)
+API int refhip_convex_iou(const float* pointsets, int N, const float* polygons, int M, float* ious) {
+  if (N > 0 && M > 0)
+    ref_cvx_iou::convex_iou_kernel<<<(N + 511) / 512, 512>>>(N, M, pointsets, polygons, ious);
+  return ref_sync();
+}
+API int refhip_min_area_bbox(const float* pointsets, int N, float* bboxes) {
+  if (N > 0) ref_cvx_box::minareabbox_kernel<<<(N + 511) / 512, 512>>>(N, pointsets, bboxes);
+  return ref_sync();
+}
+
+// ---- convex_sort.py:L186-192 (the scan kernel; start index and order are tensor programs on the caller's side)
+API int refhip_convex_sort_scan(const float* x, const float* y, const float* m, const int* start_index,
+                                const int* order, int nbs, int npts, int circular, int* convex_index) {
+  const int index_size = circular ? npts + 1 : npts;
+  if (nbs > 0 && npts > 0)
+    ref_cvx_sort::convex_sort_kernel<float><<<(nbs + 511) / 512, 512>>>(nbs, npts, index_size, circular != 0, x, y, m,
+                                                                        start_index, order, convex_index);
+  return ref_sync();
+}
+'''
+
+
+def source():
+    rroi = module_strings(os.path.join(OPS, "roi_align_rotated.py"))["CUDA_HEADER"]
+    rroi1 = module_strings(os.path.join(OPS, "roi_align_rotated_v1.py"))["CUDA_HEADER"]
+    riroi = module_strings(os.path.join(OPS, "riroi_align.py"))["riroi_cuda_head"]
+    hroi = module_strings(os.path.join(OPS, "roi_align.py"))["CUDA_HEADER"]
+    dcn = module_strings(os.path.join(OPS, "dcn_v1.py"))["HEADER"]
+    fr = module_strings(os.path.join(OPS, "fr.py"))["HEADER"]
+    csort = module_strings(os.path.join(OPS, "convex_sort.py"))["CUDA_HEAD"]
+    ciou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_iou_kernel.cu")).read()
+    cbox = open(os.path.join(OPS, "reppoints_min_area_bbox", "min_area_bbox.cu")).read()
+    parts = [PRELUDE, ns("ref_rroi", rroi), ns("ref_rroi_v1", rroi1), ns("ref_riroi", riroi),
+             # roi_align.py:L217-219, L241-243: the version is a #define in front of the header
+             "#define ROI_ALIGN_VERSION 0\n", ns("ref_hroi0", hroi),
+             "#define ROI_ALIGN_VERSION 1\n", ns("ref_hroi1", hroi),
+             ns("ref_dcn", dcn), ns("ref_fr", fr), ns("ref_cvx_sort", csort),
+             ns("ref_cvx_iou", ciou.replace("using namespace std;", "")),
+             ns("ref_cvx_box", cbox), ENTRY]
+    return "\n".join(parts)
+
+
+def build(verbose=True):
+    if not os.path.isdir(OPS):
+        raise SystemExit("reference not present at %s" % OPS)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    src = source()
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "ref_kernels.hip")
+        with open(path, "w") as f:
+            f.write(src)
+        for out, extra in (("libjdet_ref_hip.so", ["-ffp-contract=off"]), ("libjdet_ref_hip_fma.so", [])):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+                   "-w"] + extra + [path, "-o", os.path.join(OUT_DIR, out)]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+            if r.returncode != 0:
+                print(r.stdout[-6000:])
+                raise SystemExit("hipcc failed for %s" % out)
+            if verbose:
+                print("built", os.path.join(OUT_DIR, out))
+    return OUT_DIR
+
+
+if __name__ == "__main__":
+    build()

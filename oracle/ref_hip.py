@@ -1,0 +1,146 @@
+"""ctypes bindings for oracle/_ref/libjdet_ref_hip.so -- the reference's own GPU kernel text compiled for gfx950 by
+oracle/build_ref_hip.py.  TEST INFRASTRUCTURE ONLY (tests/, never jdet_amd): device memory comes from torch tensors,
+every call synchronises the device.  `fma=True` loads the twin built with the compiler's default contraction."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = {False: os.path.join(_HERE, "_ref", "libjdet_ref_hip.so"), True: os.path.join(_HERE, "_ref", "libjdet_ref_hip_fma.so")}
+_libs = {}
+_i, _f, _p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+
+def available():
+    return os.path.exists(_SO[False]) and os.path.exists(_SO[True])
+
+
+def lib(fma=False):
+    if fma not in _libs:
+        if not os.path.exists(_SO[fma]):
+            raise RuntimeError("%s missing: run `python oracle/build_ref_hip.py` in the build container" % _SO[fma])
+        _libs[fma] = ctypes.CDLL(_SO[fma])
+    return _libs[fma]
+
+
+def _t(x):
+    assert x.is_cuda and x.is_contiguous()
+    return _p(x.data_ptr() if x.numel() else 0)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s: hipError %d" % (what, rc))
+
+
+_ROI = {"rot": "refhip_roi_align_rotated", "rot_v1": "refhip_roi_align_rotated_v1", "hbb0": "refhip_roi_align_v0",
+        "hbb1": "refhip_roi_align_v1"}
+
+
+def roi_align_forward(kind, feat, rois, out_hw, spatial_scale, sampling_ratio, n_orient=8, fma=False):
+    """feat (N, C, H, W) NCHW float32 cuda, rois (R, 6 | 5) -> (R, C, PH, PW)"""
+    feat, rois = feat.float().contiguous(), rois.float().contiguous()
+    N, C, H, W = feat.shape
+    R, (PH, PW) = rois.shape[0], out_hw
+    out = torch.zeros((R, C, PH, PW), dtype=torch.float32, device=feat.device)
+    if kind == "riroi":
+        _check(lib(fma).refhip_riroi_align_forward(_t(feat), _t(rois), _i(R), _i(C // n_orient), _i(H), _i(W), _i(PH),
+                                                   _i(PW), _f(spatial_scale), _i(int(sampling_ratio)), _i(n_orient),
+                                                   _t(out)), "riroi forward")
+    else:
+        _check(getattr(lib(fma), _ROI[kind] + "_forward")(_t(feat), _t(rois), _i(R), _i(C), _i(H), _i(W), _i(PH), _i(PW),
+                                                          _f(spatial_scale), _f(float(sampling_ratio)), _t(out)),
+               kind + " forward")
+    return out
+
+
+def roi_align_backward(kind, grad, rois, feat_shape, spatial_scale, sampling_ratio, n_orient=8, fma=False):
+    grad, rois = grad.float().contiguous(), rois.float().contiguous()
+    N, C, H, W = feat_shape
+    R, _, PH, PW = grad.shape
+    gin = torch.empty((N, C, H, W), dtype=torch.float32, device=grad.device)
+    if kind == "riroi":
+        _check(lib(fma).refhip_riroi_align_backward(_t(grad), _t(rois), _i(R), _i(N), _i(C // n_orient), _i(H), _i(W),
+                                                    _i(PH), _i(PW), _f(spatial_scale), _i(int(sampling_ratio)),
+                                                    _i(n_orient), _t(gin)), "riroi backward")
+    else:
+        _check(getattr(lib(fma), _ROI[kind] + "_backward")(_t(grad), _t(rois), _i(R), _i(N), _i(C), _i(H), _i(W), _i(PH),
+                                                           _i(PW), _f(spatial_scale), _f(float(sampling_ratio)),
+                                                           _t(gin)), kind + " backward")
+    return gin
+
+
+def _dcn_args(B, C, H, W, kh, kw, pad, stride, dil, dg):
+    return [_i(v) for v in (B, C, H, W, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], dg)]
+
+
+def _dcn_out(H, W, kh, kw, pad, stride, dil):
+    return ((H + 2 * pad[0] - (dil[0] * (kh - 1) + 1)) // stride[0] + 1,
+            (W + 2 * pad[1] - (dil[1] * (kw - 1) + 1)) // stride[1] + 1)
+
+
+def deform_im2col(im, offset, kh, kw, pad, stride, dil, dg, fma=False):
+    B, C, H, W = im.shape
+    Ho, Wo = _dcn_out(H, W, kh, kw, pad, stride, dil)
+    col = torch.empty((C * kh * kw, B, Ho, Wo), dtype=torch.float32, device=im.device)
+    _check(lib(fma).refhip_deform_im2col(_t(im), _t(offset), *_dcn_args(B, C, H, W, kh, kw, pad, stride, dil, dg),
+                                         _t(col)), "deform_im2col")
+    return col
+
+
+def deform_col2im(col, offset, im_shape, kh, kw, pad, stride, dil, dg, fma=False):
+    B, C, H, W = im_shape
+    gim = torch.empty((B, C, H, W), dtype=torch.float32, device=col.device)
+    _check(lib(fma).refhip_deform_col2im(_t(col), _t(offset), *_dcn_args(B, C, H, W, kh, kw, pad, stride, dil, dg),
+                                         _t(gim)), "deform_col2im")
+    return gim
+
+
+def deform_col2im_coord(col, im, offset, kh, kw, pad, stride, dil, dg, fma=False):
+    B, C, H, W = im.shape
+    goff = torch.empty_like(offset)
+    _check(lib(fma).refhip_deform_col2im_coord(_t(col), _t(im), _t(offset),
+                                               *_dcn_args(B, C, H, W, kh, kw, pad, stride, dil, dg), _t(goff)),
+           "deform_col2im_coord")
+    return goff
+
+
+def feature_refine(features, boxes, spatial_scale, points, grad=None, fma=False):
+    """features (N, C, H, W), boxes (N, H, W, 5) -> refined features; with `grad`: the input gradient instead"""
+    N, C, H, W = features.shape
+    out = torch.empty_like(features)
+    fn = lib(fma).refhip_feature_refine_backward if grad is not None else lib(fma).refhip_feature_refine_forward
+    _check(fn(_t(grad if grad is not None else features), _t(boxes), _i(N), _i(C), _i(H), _i(W), _f(spatial_scale),
+              _i(points), _t(out)), "feature_refine")
+    return out
+
+
+def convex_iou(pointsets, polygons, fma=False):
+    N, M = pointsets.shape[0], polygons.shape[0]
+    out = torch.zeros((N, M), dtype=torch.float32, device=pointsets.device)
+    _check(lib(fma).refhip_convex_iou(_t(pointsets), _i(N), _t(polygons), _i(M), _t(out)), "convex_iou")
+    return out
+
+
+def min_area_bbox(pointsets, fma=False):
+    out = torch.zeros((pointsets.shape[0], 8), dtype=torch.float32, device=pointsets.device)
+    _check(lib(fma).refhip_min_area_bbox(_t(pointsets), _i(pointsets.shape[0]), _t(out)), "min_area_bbox")
+    return out
+
+
+def convex_sort(pts, masks, circular=True, fma=False):
+    """convex_sort_gpu (convex_sort.py:L159-194): the tensor program in torch (first minimum, stable descending sort --
+    Jittor's tie rules are unpinned), the scan by the reference kernel"""
+    nbs, npts = pts.shape[:2]
+    m = masks.float()
+    x, y = pts[:, :, 0].contiguous(), pts[:, :, 1].contiguous()
+    masked_y = m * y + (1 - m) * 10000000
+    start = masked_y.argmin(1, keepdim=True)
+    sx, sy = x.gather(1, start), y.gather(1, start)
+    cosv = (x - sx) / torch.sqrt((x - sx) * (x - sx) + (y - sy) * (y - sy) + 0.000001)
+    order = torch.sort(cosv, dim=1, descending=True, stable=True).indices.int().contiguous()
+    out = torch.full((nbs, npts + (1 if circular else 0)), -1, dtype=torch.int32, device=pts.device)
+    _check(lib(fma).refhip_convex_sort_scan(_t(x), _t(y), _t(m.contiguous()), _t(start.int().contiguous()), _t(order),
+                                            _i(nbs), _i(npts), _i(int(circular)), _t(out)), "convex_sort")
+    return out

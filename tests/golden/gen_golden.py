@@ -10,8 +10,8 @@ Two kinds of expected outputs, said per file:
     against them bit for bit -- that is how those parts of the oracle are pinned.  (`iou_cudasort` in
     box_iou_rotated.npz, the reference's CUDA exchange-sort ordering, is restatement output: CUDA-only source.)
   * roi_align.npz, riroi_align.npz, deform_conv.npz, dcn_v2.npz, convex_ops.npz: the reference has these operators as
-    CUDA kernels only, which
-    cannot be built in this image without stand-ins for the CUDA built-ins (not done: build_ref.py).  The expected
+    CUDA kernels only: nothing to run them on in this container (no GPU; on the GPU box the reference's kernel text,
+    compiled by oracle/build_ref_hip.py, checks both the restatement and the HIP kernels: tests/test_gpu_reference_kernels.py).  The expected
     outputs are those of the restatement oracle/jdet_oracle.cpp, written only AFTER the restatement has passed the
     closed-form pins (tests/closed_form.py: affine-map RoIAlign for all five dialects, integer-offset DeformConv;
     tests/test_dcn_v2_oracle.py, tests/test_convex_oracle.py for the round-3 operators -- none involves the

@@ -1,0 +1,157 @@
+"""GPU: the reference's OWN kernel text, compiled for gfx950 by oracle/build_ref_hip.py (oracle/_ref/libjdet_ref_hip.so),
+run on the same device as the HIP kernels: pins BOTH the product kernels and the CPU restatement (oracle/) by reference
+execution for the operators the reference has as CUDA text only -- the five RoIAligns, DeformConv v1 sampling, feature
+refinement, the RepPoints geometry, convex_sort.
+
+Tolerances (measured: profiles/r03_reference_kernels_parity.txt).  The build with contraction off runs the text's own
+operation order.  The horizontal dialects involve no trigonometry: the restatement and the product's reference-order
+forward equal the reference kernel BIT FOR BIT.  In the rotated dialects the kernel text calls `cos(theta)` on a float,
+which device code resolves to the single-precision routine of the platform's math library (cosf: an ulp or two from the
+correctly rounded value, and not the same function on any two platforms), while the restatement and the product round
+the double-precision cosine -- they agree with EACH OTHER bit for bit (tests/test_gpu_roi_align.py) and with the
+reference kernel to 4e-6 on N(0,1) maps (82-96 % of the elements bit-equal): 1e-5.  Backward results sum float atomics
+in arbitrary order: 3e-5.  The twin built with the compiler's default contraction (what a CUDA toolchain does to the
+same text) stays within 2e-5 of the contraction-free build: the parity claims do not hinge on the flag."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fr_oracle as FO
+from oracle import oracle as O
+from oracle import ref_hip as RH
+from tests import inputs as I
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not RH.available(), reason="oracle/_ref/libjdet_ref_hip.so not built")]
+
+KINDS = [("rot", O.V_ROT), ("rot_v1", O.V_ROT_V1), ("hbb0", O.V_HBB0), ("hbb1", O.V_HBB1), ("riroi", O.V_RI)]
+
+
+def _case(rng, kind, C=16, nO=8):
+    N, H, W, scale = 2, 24, 32, 0.25
+    Ct = C * nO if kind == "riroi" else C
+    feat = rng.standard_normal((N, Ct, H, W)).astype(np.float32)
+    obbs = I.random_obbs(rng, 24, extent=W / scale, wh=(4.0, 90.0))
+    obbs[:, 1] *= H / W
+    rois = np.concatenate([I.rois_from_obbs(obbs, rng.integers(0, N, 24)), I.edge_rois(H, W, scale)], 0)
+    if kind in ("hbb0", "hbb1"):
+        rois = I.obb_to_hbb_rois(rois)
+    return feat, rois.astype(np.float32), scale
+
+
+def _product(variant, feat, rois, hw, scale, s, grad, dev, mode, nO=8):
+    from jdet_amd import _lib as L
+    from tests.test_gpu_roi_align import _layer
+    prev = L.lib().jdet_set_roi_forward_mode(mode)
+    try:
+        x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = _layer(variant, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
+        y.backward(torch.from_numpy(grad).to(dev))
+        return y.detach().cpu().numpy(), x.grad.detach().cpu().contiguous().numpy()
+    finally:
+        L.lib().jdet_set_roi_forward_mode(prev)
+
+
+@pytest.mark.parametrize("kind,variant", KINDS)
+@pytest.mark.parametrize("hw,s", [((7, 7), 2), ((3, 5), 0), ((2, 2), 3)])
+def test_roi_align_against_the_reference_kernels(dev, kind, variant, hw, s):
+    rng = np.random.default_rng(7 + variant + hw[0])
+    feat, rois, scale = _case(rng, kind)
+    grad = rng.standard_normal((rois.shape[0], feat.shape[1]) + hw).astype(np.float32)
+    tf, tr, tg = (torch.from_numpy(v).to(dev) for v in (feat, rois, grad))
+    ref_y = RH.roi_align_forward(kind, tf, tr, hw, scale, s).cpu().numpy()
+    ref_g = RH.roi_align_backward(kind, tg, tr, feat.shape, scale, s).cpu().numpy()
+    trig = kind not in ("hbb0", "hbb1")
+    fwd_tol = 1e-5 if trig else 0.0
+    # 1. the CPU restatement is the reference kernel's arithmetic
+    o_y = O.roi_align_forward(variant, feat, rois, hw, scale, s, 8)
+    o_g = O.roi_align_backward(variant, grad, rois, feat.shape, scale, s, 8)
+    np.testing.assert_allclose(o_y, ref_y, rtol=0, atol=fwd_tol)
+    assert (o_y == ref_y).mean() > 0.75
+    np.testing.assert_allclose(o_g, ref_g, rtol=0, atol=3e-5)
+    # 2. the product kernels: reference-order arithmetic and the default merged-tap arithmetic
+    y1, g1 = _product(variant, feat, rois, hw, scale, s, grad, dev, 1)
+    np.testing.assert_allclose(y1, ref_y, rtol=0, atol=fwd_tol)
+    np.testing.assert_allclose(g1, ref_g, rtol=0, atol=3e-5)
+    y0, _ = _product(variant, feat, rois, hw, scale, s, grad, dev, 0)
+    np.testing.assert_allclose(y0, ref_y, rtol=0, atol=1e-5)
+    # 3. the same text under the compiler's default contraction
+    fma_y = RH.roi_align_forward(kind, tf, tr, hw, scale, s, fma=True).cpu().numpy()
+    np.testing.assert_allclose(fma_y, ref_y, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W,k,pad,stride,dil,dg", [(2, 4, 9, 11, 3, 1, 1, 1, 1), (1, 6, 10, 8, 3, 1, 2, 1, 2),
+                                                          (2, 8, 7, 9, 3, 2, 1, 2, 1)])
+def test_deform_conv_sampling_against_the_reference_kernels(dev, B, C, H, W, k, pad, stride, dil, dg):
+    from jdet_amd.ops import dcn_v1
+    rng = np.random.default_rng(B * 10 + C)
+    a = (k, k, (pad, pad), (stride, stride), (dil, dil), dg)
+    Ho = (H + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (k - 1) + 1)) // stride + 1
+    im = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    off = (rng.standard_normal((B, dg * 2 * k * k, Ho, Wo)) * 2.0).astype(np.float32)
+    off.flat[::7] = np.round(off.flat[::7])
+    tim, toff = torch.from_numpy(im).to(dev), torch.from_numpy(off).to(dev)
+    ref_col = RH.deform_im2col(tim, toff, *a)
+    gcol = torch.from_numpy(rng.standard_normal(tuple(ref_col.shape)).astype(np.float32)).to(dev)
+    ref_gim = RH.deform_col2im(gcol, toff, im.shape, *a).cpu().numpy()
+    ref_goff = RH.deform_col2im_coord(gcol, tim, toff, *a).cpu().numpy()
+    # restatement
+    np.testing.assert_array_equal(O.deform_im2col(im, off, *a), ref_col.cpu().numpy())
+    np.testing.assert_allclose(O.deform_col2im(gcol.cpu().numpy(), off, im.shape, *a), ref_gim, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(O.deform_col2im_coord(gcol.cpu().numpy(), im, off, *a), ref_goff, rtol=0, atol=1e-5)
+    # product (general NCHW path)
+    np.testing.assert_array_equal(dcn_v1.deformable_im2col(tim, toff, *a).cpu().numpy(), ref_col.cpu().numpy())
+    np.testing.assert_allclose(dcn_v1.deformable_col2im(gcol, toff, im.shape, *a).cpu().numpy(), ref_gim, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(dcn_v1.deformable_col2im_coord(gcol, tim, toff, *a).cpu().numpy(), ref_goff, rtol=0,
+                               atol=1e-5)
+
+
+@pytest.mark.parametrize("points", [1, 5])
+def test_feature_refine_against_the_reference_kernels(dev, points):
+    from jdet_amd.ops.fr import FR
+    from tests.test_gpu_fr import _boxes
+    rng = np.random.default_rng(points)
+    N, C, H, W, stride = 2, 32, 12, 10, 8.0
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    boxes = _boxes(rng, N, H, W, stride)
+    grad = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    tf, tb, tg = (torch.from_numpy(v).to(dev) for v in (feat, boxes, grad))
+    ref_y = RH.feature_refine(tf, tb, 1.0 / stride, points).cpu().numpy()
+    ref_g = RH.feature_refine(tf, tb, 1.0 / stride, points, grad=tg).cpu().numpy()
+    tol = 2e-5 * max(1.0, np.abs(ref_y).max())          # float sin / cos of two math libraries move a sample by an ulp
+    np.testing.assert_allclose(FO.feature_refine_forward(feat, boxes, 1.0 / stride, points), ref_y, rtol=0, atol=tol)
+    np.testing.assert_allclose(FO.feature_refine_backward(grad, boxes, 1.0 / stride, points), ref_g, rtol=0, atol=1e-4)
+    x = tf.clone().requires_grad_(True)
+    y = FR(1.0 / stride, points)(x, tb)
+    y.backward(tg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_y, rtol=0, atol=tol)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref_g, rtol=0, atol=1e-4)
+
+
+def test_convex_geometry_against_the_reference_kernels(dev):
+    from jdet_amd.ops.convex_sort import convex_sort
+    from jdet_amd.ops.reppoints_convex_iou import reppoints_convex_iou
+    from jdet_amd.ops.reppoints_min_area_bbox import reppoints_min_area_bbox
+    from tests.test_gpu_convex_ops import _pointsets, _quads
+    rng = np.random.default_rng(21)
+    ps, q = _pointsets(rng, 200), _quads(rng, 13)
+    q[::3] = q[::3].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)
+    tp, tq = torch.from_numpy(ps).to(dev), torch.from_numpy(q).to(dev)
+    ref_iou = RH.convex_iou(tp, tq).cpu().numpy()
+    np.testing.assert_allclose(O.convex_iou(ps, q), ref_iou, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(reppoints_convex_iou(tp, tq).cpu().numpy(), ref_iou, rtol=0, atol=1e-6)
+    ref_box = RH.min_area_bbox(tp).cpu().numpy()
+    area = lambda b: np.linalg.norm(b[:, 0:2] - b[:, 2:4], axis=1) * np.linalg.norm(b[:, 4:6] - b[:, 2:4], axis=1)
+    got = reppoints_min_area_bbox(tp).cpu().numpy()
+    np.testing.assert_allclose(area(got), area(ref_box), rtol=1e-4)
+    assert (np.abs(got - ref_box).max(1) < 2e-3).mean() > 0.97       # equal-area rectangles may pick another edge
+    np.testing.assert_allclose(area(O.min_area_bbox(ps)), area(ref_box), rtol=1e-4)
+    pts = rng.uniform(0, 50, size=(150, 12, 2)).astype(np.float32)
+    pts[:, -1] = pts[:, 0]
+    masks = (rng.uniform(size=(150, 12)) > 0.3).astype(np.float32)
+    masks[:, 0] = 1
+    for circular in (True, False):
+        ref_idx = RH.convex_sort(torch.from_numpy(pts).to(dev), torch.from_numpy(masks).to(dev), circular).cpu().numpy()
+        np.testing.assert_array_equal(convex_sort(torch.from_numpy(pts).to(dev), torch.from_numpy(masks).to(dev),
+                                                  circular).cpu().numpy(), ref_idx)
+        np.testing.assert_array_equal(O.convex_sort(pts, masks, circular), ref_idx)
