@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Build oracle/_ref/libjdet_ref_hip.so: the reference's OWN GPU kernels, compiled for gfx950.  TEST INFRASTRUCTURE.
 
-The operators SURVEY 8(a) lists as "CUDA only" (the five RoIAligns, DeformConv v1 sampling, feature refinement, the
-RepPoints geometry, convex_sort) have no CPU source in the reference, but their kernel text is plain CUDA C++ --
+The operators SURVEY 8(a) lists as "CUDA only" (the five RoIAligns, DeformConv v1 / v2 sampling, deformable PSRoI
+pooling, feature refinement, the RepPoints geometry, convex_sort) have no CPU source in the reference, but their kernel text is plain CUDA C++ --
 `__global__` functions, blockIdx / threadIdx, atomicAdd, <<< >>> launches -- and that dialect is what hipcc compiles
 natively: no stand-in for a CUDA built-in, header, library or tool is written here.  As oracle/build_ref.py does for
 the CPU sources, this recipe reads the kernel text with `ast` from the files WHERE THEY LIE under /root/reference
@@ -19,8 +19,12 @@ Needs /root/reference and hipcc: runs in the build container (hipcc cross-compil
 travel to the GPU box with the snapshot (oracle/_ref/ is git-ignored, not gpurun-ignored), where tests/ use them to pin
 both the HIP kernels and the CPU restatement against the reference's kernels running on the same device.
 
-NOT built: dcn_v2.py's kernels (their header pulls cuBLAS and Jittor's executor), nms_poly.py (executor types in the
-kernel text), the kernels of models outside SURVEY 8.
+dcn_v2.py keeps its kernel text inline in the `jt.code(cuda_header=...)` calls: read from there.  The two pooling headers
+compile as they are; from the convolution's backward header (all three sampling kernels + their launch wrappers) the
+includes of <cuda_runtime.h> / <cublas_v2.h> and the `extern cublasHandle_t cublas_handle;` declaration are dropped as
+well -- the GEMMs that use them live in the launch snippet, not in the kernels.
+
+NOT built: nms_poly.py (executor types in the kernel text), the kernels of models outside SURVEY 8.
 """
 import os
 import re
@@ -202,7 +206,81 @@ API int refhip_convex_sort_scan(const float* x, const float* y, const float* m, 
                                                                         start_index, order, convex_index);
   return ref_sync();
 }
+
+// ---- dcn_v2.py:L711-779: the per-image sampling calls of the backward loop (batch_size = 1; columns (C*kh*kw, Ho*Wo))
+API int refhip_dcn2_im2col(const float* im, const float* offset, const float* mask, int C, int H, int W, int kh, int kw,
+                           int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg, float* col) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  ref_dcn2::modulated_deformable_im2col_cuda(im, offset, mask, 1, C, H, W, Ho, Wo, kh, kw, pad_h, pad_w, stride_h,
+                                             stride_w, dil_h, dil_w, dg, col);
+  return ref_sync();
+}
+API int refhip_dcn2_col2im(const float* col, const float* offset, const float* mask, int C, int H, int W, int kh, int kw,
+                           int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w, int dg,
+                           float* grad_im) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  hipMemsetAsync(grad_im, 0, sizeof(float) * (size_t)C * H * W);
+  ref_dcn2::modulated_deformable_col2im_cuda(col, offset, mask, 1, C, H, W, Ho, Wo, kh, kw, pad_h, pad_w, stride_h,
+                                             stride_w, dil_h, dil_w, dg, grad_im);
+  return ref_sync();
+}
+API int refhip_dcn2_col2im_coord(const float* col, const float* im, const float* offset, const float* mask, int C, int H,
+                                 int W, int kh, int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h,
+                                 int dil_w, int dg, float* grad_offset, float* grad_mask) {
+  const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1;
+  const int Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+  ref_dcn2::modulated_deformable_col2im_coord_cuda(col, im, offset, mask, 1, C, H, W, Ho, Wo, kh, kw, pad_h, pad_w,
+                                                   stride_h, stride_w, dil_h, dil_w, dg, grad_offset, grad_mask);
+  return ref_sync();
+}
+
+// ---- dcn_v2.py:L935-985 / L1118-1175: deformable PSRoI pooling (512 threads, at most 4096 blocks)
+API int refhip_psroi_forward(const float* input, const float* bbox, const float* trans, int C, int H, int W, int R,
+                             int no_trans, float spatial_scale, int output_dim, int group_size, int pooled_size,
+                             int part_size, int sample_per_part, float trans_std, int channels_trans, float* out,
+                             float* top_count) {
+  const long out_size = (long)R * output_dim * pooled_size * pooled_size;
+  const int num_classes = no_trans ? 1 : channels_trans / 2;
+  const int channels_each_class = no_trans ? output_dim : output_dim / num_classes;
+  const long tmp = out_size % 512L == 0 ? out_size / 512L : out_size / 512L + 1L;
+  if (out_size)
+    ref_ps_fwd::DeformablePSROIPoolForwardKernel<<<dim3((unsigned)std::min(tmp, 4096L)), dim3(512)>>>(
+        out_size, input, spatial_scale, C, H, W, pooled_size, pooled_size, bbox, trans, no_trans, trans_std,
+        sample_per_part, output_dim, group_size, part_size, num_classes, channels_each_class, out, top_count);
+  return ref_sync();
+}
+API int refhip_psroi_backward(const float* grad_out, const float* top_count, const float* input, const float* bbox,
+                              const float* trans, int N, int C, int H, int W, int R, int no_trans, float spatial_scale,
+                              int output_dim, int group_size, int pooled_size, int part_size, int sample_per_part,
+                              float trans_std, int channels_trans, float* grad_input, float* grad_trans) {
+  const long out_size = (long)R * output_dim * pooled_size * pooled_size;
+  const int num_classes = no_trans ? 1 : channels_trans / 2;
+  const int channels_each_class = no_trans ? output_dim : output_dim / num_classes;
+  const long tmp = out_size % 512L == 0 ? out_size / 512L : out_size / 512L + 1L;
+  hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)N * C * H * W);
+  if (!no_trans) hipMemsetAsync(grad_trans, 0, sizeof(float) * (size_t)R * channels_trans * part_size * part_size);
+  if (out_size)
+    ref_ps_bwd::DeformablePSROIPoolBackwardAccKernel<<<dim3((unsigned)std::min(tmp, 4096L)), dim3(512)>>>(
+        out_size, grad_out, top_count, R, spatial_scale, C, H, W, pooled_size, pooled_size, output_dim, grad_input,
+        grad_trans, input, bbox, trans, no_trans, trans_std, sample_per_part, group_size, part_size, num_classes,
+        channels_each_class);
+  return ref_sync();
+}
 '''
+
+
+def inline_headers(path):
+    """the `cuda_header=` string constants of a module's jt.code calls, in source order"""
+    import ast
+    out = []
+    for node in ast.walk(ast.parse(open(path).read())):
+        if isinstance(node, ast.Call):
+            for kw in node.keywords:
+                if kw.arg == "cuda_header" and isinstance(kw.value, ast.Constant) and isinstance(kw.value.value, str):
+                    out.append((node.lineno, kw.value.value))
+    return [h for _, h in sorted(out)]
 
 
 def source():
@@ -215,13 +293,23 @@ def source():
     csort = module_strings(os.path.join(OPS, "convex_sort.py"))["CUDA_HEAD"]
     ciou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_iou_kernel.cu")).read()
     cbox = open(os.path.join(OPS, "reppoints_min_area_bbox", "min_area_bbox.cu")).read()
+    d2 = inline_headers(os.path.join(OPS, "dcn_v2.py"))      # conv forward, conv backward, pooling forward, pooling backward
+    assert len(d2) == 4, len(d2)
+    d2_conv = d2[1]
+    for drop in (r"#include\s*<cuda_runtime.h>", r"#include\s*<cublas_v2.h>",
+                 r"namespace jittor \{\s*extern cublasHandle_t cublas_handle;\s*\}\s*// jittor"):
+        d2_conv, n = re.subn(drop, "", d2_conv)
+        assert n == 1, drop
     parts = [PRELUDE, ns("ref_rroi", rroi), ns("ref_rroi_v1", rroi1), ns("ref_riroi", riroi),
              # roi_align.py:L217-219, L241-243: the version is a #define in front of the header
              "#define ROI_ALIGN_VERSION 0\n", ns("ref_hroi0", hroi),
              "#define ROI_ALIGN_VERSION 1\n", ns("ref_hroi1", hroi),
              ns("ref_dcn", dcn), ns("ref_fr", fr), ns("ref_cvx_sort", csort),
              ns("ref_cvx_iou", ciou.replace("using namespace std;", "")),
-             ns("ref_cvx_box", cbox), ENTRY]
+             ns("ref_cvx_box", cbox),
+             ns("ref_dcn2", d2_conv.replace("using namespace std;", "")),
+             ns("ref_ps_fwd", d2[2].replace("using namespace std;", "")),
+             ns("ref_ps_bwd", d2[3].replace("using namespace std;", "")), ENTRY]
     return "\n".join(parts)
 
 

@@ -144,3 +144,60 @@ def convex_sort(pts, masks, circular=True, fma=False):
     _check(lib(fma).refhip_convex_sort_scan(_t(x), _t(y), _t(m.contiguous()), _t(start.int().contiguous()), _t(order),
                                             _i(nbs), _i(npts), _i(int(circular)), _t(out)), "convex_sort")
     return out
+
+
+def _dcn2_args(C, H, W, kh, kw, pad, stride, dil, dg):
+    return [_i(v) for v in (C, H, W, kh, kw, pad[0], pad[1], stride[0], stride[1], dil[0], dil[1], dg)]
+
+
+def dcn2_im2col(im, offset, mask, kh, kw, pad, stride, dil, dg, fma=False):
+    """ONE image: im (C, H, W), offset (dg*2*kk, Ho, Wo), mask (dg*kk, Ho, Wo) -> columns (C*kk, Ho, Wo)"""
+    C, H, W = im.shape
+    Ho, Wo = _dcn_out(H, W, kh, kw, pad, stride, dil)
+    col = torch.empty((C * kh * kw, Ho, Wo), dtype=torch.float32, device=im.device)
+    _check(lib(fma).refhip_dcn2_im2col(_t(im), _t(offset), _t(mask), *_dcn2_args(C, H, W, kh, kw, pad, stride, dil, dg),
+                                       _t(col)), "dcn2_im2col")
+    return col
+
+
+def dcn2_col2im(col, offset, mask, im_shape, kh, kw, pad, stride, dil, dg, fma=False):
+    C, H, W = im_shape
+    gim = torch.empty((C, H, W), dtype=torch.float32, device=col.device)
+    _check(lib(fma).refhip_dcn2_col2im(_t(col), _t(offset), _t(mask), *_dcn2_args(C, H, W, kh, kw, pad, stride, dil, dg),
+                                       _t(gim)), "dcn2_col2im")
+    return gim
+
+
+def dcn2_col2im_coord(col, im, offset, mask, kh, kw, pad, stride, dil, dg, fma=False):
+    C, H, W = im.shape
+    goff, gmask = torch.zeros_like(offset), torch.zeros_like(mask)
+    _check(lib(fma).refhip_dcn2_col2im_coord(_t(col), _t(im), _t(offset), _t(mask),
+                                             *_dcn2_args(C, H, W, kh, kw, pad, stride, dil, dg), _t(goff), _t(gmask)),
+           "dcn2_col2im_coord")
+    return goff, gmask
+
+
+def _ps_args(x, R, no_trans, scale, od, G, P, part, spp, tstd, tch):
+    return [_i(x.shape[1]), _i(x.shape[2]), _i(x.shape[3]), _i(R), _i(int(no_trans)), _f(scale), _i(od), _i(G), _i(P),
+            _i(part), _i(spp), _f(tstd), _i(tch)]
+
+
+def psroi_forward(x, rois, trans, no_trans, scale, od, G, P, part, spp, tstd, fma=False):
+    R = rois.shape[0]
+    out = torch.zeros((R, od, P, P), dtype=torch.float32, device=x.device)
+    cnt = torch.zeros_like(out)
+    tch = 2 if no_trans else trans.shape[1]
+    _check(lib(fma).refhip_psroi_forward(_t(x), _t(rois), _t(trans), *_ps_args(x, R, no_trans, scale, od, G, P, part, spp,
+                                                                                tstd, tch), _t(out), _t(cnt)),
+           "psroi_forward")
+    return out, cnt
+
+
+def psroi_backward(grad, cnt, x, rois, trans, no_trans, scale, od, G, P, part, spp, tstd, fma=False):
+    R = rois.shape[0]
+    gi, gt = torch.empty_like(x), torch.zeros_like(trans)
+    tch = 2 if no_trans else trans.shape[1]
+    _check(lib(fma).refhip_psroi_backward(_t(grad), _t(cnt), _t(x), _t(rois), _t(trans), _i(x.shape[0]),
+                                          *_ps_args(x, R, no_trans, scale, od, G, P, part, spp, tstd, tch), _t(gi),
+                                          _t(gt)), "psroi_backward")
+    return gi, gt

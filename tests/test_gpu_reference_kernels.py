@@ -155,3 +155,71 @@ def test_convex_geometry_against_the_reference_kernels(dev):
         np.testing.assert_array_equal(convex_sort(torch.from_numpy(pts).to(dev), torch.from_numpy(masks).to(dev),
                                                   circular).cpu().numpy(), ref_idx)
         np.testing.assert_array_equal(O.convex_sort(pts, masks, circular), ref_idx)
+
+
+@pytest.mark.parametrize("C,H,W,k,pad,stride,dil,dg", [(8, 9, 11, 3, (1, 1), 1, 1, 2), (6, 10, 8, 3, (2, 2), 2, 2, 3)])
+def test_dcn_v2_sampling_against_the_reference_kernels(dev, C, H, W, k, pad, stride, dil, dg):
+    """the three modulated sampling kernels as the reference's backward loop calls them: one image at a time"""
+    from jdet_amd import _lib as L
+    from jdet_amd.ops import dcn_v2
+    from jdet_amd.ops.dcn_v1 import _geom_args
+    rng = np.random.default_rng(C + H)
+    Ho = (H + 2 * pad[0] - (dil * (k - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad[1] - (dil * (k - 1) + 1)) // stride + 1
+    a = (k, k, pad, (stride, stride), (dil, dil), dg)
+    im = torch.from_numpy(rng.standard_normal((C, H, W)).astype(np.float32)).to(dev)
+    off_np = (rng.standard_normal((dg * 2 * k * k, Ho, Wo)) * 2.0).astype(np.float32)
+    off_np.flat[::7] = np.round(off_np.flat[::7])
+    off = torch.from_numpy(off_np).to(dev)
+    mask = torch.from_numpy(rng.uniform(0, 1, (dg * k * k, Ho, Wo)).astype(np.float32)).to(dev)
+    ref_col = RH.dcn2_im2col(im, off, mask, *a)
+    gcol = torch.from_numpy(rng.standard_normal(tuple(ref_col.shape)).astype(np.float32)).to(dev)
+    ref_gim = RH.dcn2_col2im(gcol, off, mask, (C, H, W), *a)
+    ref_goff, ref_gmask = RH.dcn2_col2im_coord(gcol, im, off, mask, *a)
+    # product kernels on the same single image (B = 1: the two column layouts coincide)
+    col = dcn_v2._im2col(im[None], off[None], mask[None], *a)
+    np.testing.assert_allclose(col.view_as(ref_col).cpu().numpy(), ref_col.cpu().numpy(), rtol=0, atol=1e-6)
+    lib, st = L.lib(), L.stream_ptr(im)
+    geom = _geom_args(1, C, H, W, k, k, pad, (stride, stride), (dil, dil), dg)
+    gim, goff, gmask = torch.empty_like(im), torch.empty_like(off), torch.empty_like(mask)
+    L.check(lib.jdet_modulated_deform_col2im(L.ptr(gcol), L.ptr(off), L.ptr(mask), *geom, L.ptr(gim), st), "col2im")
+    L.check(lib.jdet_modulated_deform_col2im_coord(L.ptr(gcol), L.ptr(im), L.ptr(off), L.ptr(mask), *geom, L.ptr(goff),
+                                                   L.ptr(gmask), st), "coord")
+    np.testing.assert_allclose(gim.cpu().numpy(), ref_gim.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(goff.cpu().numpy(), ref_goff.cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(gmask.cpu().numpy(), ref_gmask.cpu().numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("no_trans", [True, False])
+def test_deform_psroi_pooling_against_the_reference_kernels(dev, no_trans):
+    from jdet_amd.ops import dcn_v2
+    rng = np.random.default_rng(17)
+    R, N, H, W, od, G, P, part, ncls, spp, tstd, scale = 14, 2, 20, 24, 8, 2, 4, 4, 2, 3, 0.2, 0.25
+    x = rng.standard_normal((N, od * G * G, H, W)).astype(np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    rois[:, 0] = rng.integers(0, N, R)
+    x1, y1 = rng.uniform(-12, W / scale, R), rng.uniform(-12, H / scale, R)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3], rois[:, 4] = x1 + rng.uniform(0, W / scale / 2, R), y1 + rng.uniform(0, H / scale / 2, R)
+    trans = rng.standard_normal((R, 2 * ncls, part, part)).astype(np.float32)
+    g = rng.standard_normal((R, od, P, P)).astype(np.float32)
+    tx, tr, tt, tg = (torch.from_numpy(v).to(dev) for v in (x, rois, trans, g))
+    cfg = (no_trans, scale, od, G, P, part, spp, tstd)
+    ref_y, ref_cnt = RH.psroi_forward(tx, tr, tt, *cfg)
+    ref_gi, ref_gt = RH.psroi_backward(tg, ref_cnt, tx, tr, tt, *cfg)
+    # restatement
+    o_y, o_cnt = O.deform_psroi_forward(x, rois, trans, *cfg)
+    np.testing.assert_array_equal(o_cnt, ref_cnt.cpu().numpy())
+    np.testing.assert_allclose(o_y, ref_y.cpu().numpy(), rtol=0, atol=2e-6)
+    o_gi, o_gt = O.deform_psroi_backward(g, o_cnt, x, rois, trans, *cfg)
+    np.testing.assert_allclose(o_gi, ref_gi.cpu().numpy(), rtol=0, atol=2e-5)
+    # product
+    xt, ttt = tx.clone().requires_grad_(True), tt.clone().requires_grad_(True)
+    y = dcn_v2.dcn_v2_pooling(xt, tr, ttt, scale, P, od, no_trans, G, part, spp, tstd)
+    y.backward(tg)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_y.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), ref_gi.cpu().numpy(), rtol=0, atol=2e-5)
+    if not no_trans:
+        scale_t = max(1.0, float(ref_gt.abs().max()))
+        np.testing.assert_allclose(o_gt, ref_gt.cpu().numpy(), rtol=0, atol=1e-4 * scale_t)
+        np.testing.assert_allclose(ttt.grad.cpu().numpy(), ref_gt.cpu().numpy(), rtol=0, atol=1e-4 * scale_t)
