@@ -24,7 +24,10 @@ compile as they are; from the convolution's backward header (all three sampling 
 includes of <cuda_runtime.h> / <cublas_v2.h> and the `extern cublasHandle_t cublas_handle;` declaration are dropped as
 well -- the GEMMs that use them live in the launch snippet, not in the kernels.
 
-NOT built: nms_poly.py (executor types in the kernel text), the kernels of models outside SURVEY 8.
+nms_poly.py: the mask kernel is built; the greedy scan over the mask is host code inside the launch snippet (which also
+uses Jittor's allocator) and is restated in the entry point, statement by statement (L207-229).
+
+NOT built: the kernels of models outside SURVEY 8.
 """
 import os
 import re
@@ -51,6 +54,7 @@ PRELUDE = r'''
 #include <float.h>
 #include <algorithm>
 #include <vector>
+#include <iostream>
 using std::min; using std::max;
 #define API extern "C" __attribute__((visibility("default")))
 static inline int ref_sync() { return (int)hipDeviceSynchronize(); }
@@ -268,6 +272,33 @@ API int refhip_psroi_backward(const float* grad_out, const float* top_count, con
         channels_each_class);
   return ref_sync();
 }
+
+// ---- nms_poly.py:L187-232: polys_sorted (n, 9) on the device, already in descending score order; keep: n host bytes
+API int refhip_poly_nms(const float* polys_sorted, int n, float thr, unsigned char* keep) {
+  memset(keep, 0, n);
+  if (n <= 0) return 0;
+  const int tpb = ref_pnms::threadsPerBlock;
+  const int col_blocks = (n + tpb - 1) / tpb;
+  const size_t bytes = (size_t)n * col_blocks * sizeof(unsigned long long);
+  unsigned long long* mask_d = nullptr;
+  if (hipMalloc((void**)&mask_d, bytes) != hipSuccess) return -1;
+  hipMemset(mask_d, 0, bytes);
+  ref_pnms::poly_nms_kernel<<<dim3(col_blocks, col_blocks), dim3(tpb), 0>>>(n, thr, polys_sorted, mask_d);
+  int rc = ref_sync();
+  std::vector<unsigned long long> mask((size_t)n * col_blocks), remv(col_blocks, 0ull);
+  hipMemcpy(mask.data(), mask_d, bytes, hipMemcpyDeviceToHost);
+  hipFree(mask_d);
+  for (int i = 0; i < n; i++) {
+    int nblock = i / tpb;
+    int inblock = i % tpb;
+    if (!(remv[nblock] & (1ULL << inblock))) {
+      keep[i] = 1;
+      unsigned long long* p = mask.data() + (size_t)i * col_blocks;
+      for (int j = nblock; j < col_blocks; j++) remv[j] |= p[j];
+    }
+  }
+  return rc;
+}
 '''
 
 
@@ -293,6 +324,7 @@ def source():
     csort = module_strings(os.path.join(OPS, "convex_sort.py"))["CUDA_HEAD"]
     ciou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_iou_kernel.cu")).read()
     cbox = open(os.path.join(OPS, "reppoints_min_area_bbox", "min_area_bbox.cu")).read()
+    pnms = module_strings(os.path.join(OPS, "nms_poly.py"))["HEADER"]
     d2 = inline_headers(os.path.join(OPS, "dcn_v2.py"))      # conv forward, conv backward, pooling forward, pooling backward
     assert len(d2) == 4, len(d2)
     d2_conv = d2[1]
@@ -309,7 +341,8 @@ def source():
              ns("ref_cvx_box", cbox),
              ns("ref_dcn2", d2_conv.replace("using namespace std;", "")),
              ns("ref_ps_fwd", d2[2].replace("using namespace std;", "")),
-             ns("ref_ps_bwd", d2[3].replace("using namespace std;", "")), ENTRY]
+             ns("ref_ps_bwd", d2[3].replace("using namespace std;", "")),
+             "#undef THCCeilDiv\n#undef DIVUP\n", ns("ref_pnms", pnms), ENTRY]
     return "\n".join(parts)
 
 

@@ -201,3 +201,15 @@ def psroi_backward(grad, cnt, x, rois, trans, no_trans, scale, od, G, P, part, s
                                           *_ps_args(x, R, no_trans, scale, od, G, P, part, spp, tstd, tch), _t(gi),
                                           _t(gt)), "psroi_backward")
     return gi, gt
+
+
+def poly_nms(boxes, thr, fma=False):
+    """nms_poly.py:L187-232: boxes (n, 9) [8 coordinates, score] on the device -> kept indices in descending-score order
+    (stable sort: Jittor's tie rule is unpinned)"""
+    import numpy as np
+    n = boxes.shape[0]
+    order = torch.argsort(boxes[:, 8], descending=True, stable=True)
+    srt = boxes[order].float().contiguous()
+    keep = np.zeros((max(n, 1),), np.uint8)
+    _check(lib(fma).refhip_poly_nms(_t(srt), _i(n), _f(thr), keep.ctypes.data_as(_p)), "poly_nms")
+    return order[torch.from_numpy(keep[:n].astype(bool)).to(order.device)]

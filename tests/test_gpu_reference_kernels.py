@@ -223,3 +223,31 @@ def test_deform_psroi_pooling_against_the_reference_kernels(dev, no_trans):
         scale_t = max(1.0, float(ref_gt.abs().max()))
         np.testing.assert_allclose(o_gt, ref_gt.cpu().numpy(), rtol=0, atol=1e-4 * scale_t)
         np.testing.assert_allclose(ttt.grad.cpu().numpy(), ref_gt.cpu().numpy(), rtol=0, atol=1e-4 * scale_t)
+
+
+def test_poly_nms_against_the_reference_kernel(dev):
+    """nms_poly.py's mask kernel (float arithmetic, eps sign tests) + its greedy scan against the product's polygon NMS
+    and the float64 restatement: the same polygons survive, in the same order (no pair within 1e-3 of the threshold)"""
+    import math
+    from jdet_amd.ops.nms_poly import poly_nms
+    from oracle import poly_oracle as PO
+    rng = np.random.default_rng(5)
+    base = np.array([0, 0, 30, 0, 30, 12, 0, 12], np.float64).reshape(4, 2)
+    polys = []
+    for _ in range(300):
+        ang = rng.uniform(-0.5, 0.5)
+        c, s = math.cos(ang), math.sin(ang)
+        p = base @ np.array([[c, s], [-s, c]]) + rng.uniform(0, 120, 2)
+        p[rng.integers(0, 4)] += rng.uniform(-2, 2, 2)
+        polys.append(p.reshape(8))
+    polys = np.stack(polys)
+    scores = rng.uniform(0, 1, 300)
+    thr = 0.25
+    iou = PO.poly_iou_matrix(polys, polys, 0)
+    ok = (np.abs(iou - thr) > 1e-3).all(1)                      # drop polygons with a borderline partner
+    polys, scores = polys[ok], scores[ok]
+    boxes = torch.from_numpy(np.concatenate([polys, scores[:, None]], 1).astype(np.float32)).to(dev)
+    ref = RH.poly_nms(boxes, thr).cpu().numpy().tolist()
+    assert 20 < len(ref) < len(polys)
+    assert poly_nms(boxes, thr).cpu().numpy().tolist() == ref
+    assert PO.poly_nms(polys, scores.astype(np.float32), thr) == ref
