@@ -16,9 +16,14 @@
 // host-compiled (oracle/build_ref.py -> oracle/_ref/, used by
 // tests/golden/gen_golden.py).  Compile with -ffp-contract=off.
 //
-// Pinning status: pinned against (a) the reference's known-answer literals
-// (box_iou_rotated.py:L513-514, nms_rotated.py:L599-603) and (b) golden vectors
-// produced by the host-compiled reference kernel text (tests/golden/*.npz).
+// Pinning status: (a) the reference's known-answer literals (box_iou_rotated.py:L513-514, nms_rotated.py:L599-603);
+// (b) golden vectors produced by the reference's true CPU sources compiled where they lie (oracle/build_ref.py ->
+// tests/golden/*.npz: rotated IoU, rotated NMS, ARF), bit for bit; (c) for the operators the reference has as GPU
+// kernel text only (RoIAlign x5, DeformConv v1 / v2 sampling, PSRoI pooling, feature refinement, RepPoints geometry,
+// convex_sort, polygon NMS): the reference's own kernels compiled for gfx950 (oracle/build_ref_hip.py) and run on the
+// device next to this restatement (tests/test_gpu_reference_kernels.py: bit-equal where no trigonometry is involved,
+// <= 4e-6 where the kernel text's cos(float) resolves to the device's cosf); (d) closed forms that involve neither this
+// file nor any reference build (tests/closed_form.py, tests/test_dcn_v2_oracle.py, tests/test_convex_oracle.py).
 
 #include <algorithm>
 #include <cmath>
