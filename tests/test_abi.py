@@ -200,3 +200,23 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_feature_refine_backward(N, N, 1, 8, 4, 4, 0.125, 5, N, N, 0, N) == -1
     assert lib.jdet_poly_iou(N, 2, 7, N, 2, 8, 0, N, N) == -1                                          # stride < 8
     assert lib.jdet_nms_poly(N, 4, 9, N, 0.1, 0, N, N, 0, N) == -1                                     # n_labels < 1
+
+
+def test_reference_kernel_build_exports_its_entry_points():
+    """oracle/_ref/libjdet_ref_hip.so (the reference's GPU kernel text compiled for gfx950, oracle/build_ref_hip.py) loads
+    without a device and carries every entry point oracle/ref_hip.py binds; skipped where it was not built"""
+    import re
+
+    import pytest
+    from oracle import ref_hip as RH
+    if not RH.available():
+        pytest.skip("oracle/_ref/libjdet_ref_hip.so not built (needs /root/reference)")
+    names = set(re.findall(r"refhip_[a-z0-9_]+", open(RH.__file__).read()))
+    names |= {n + sfx for n in ("refhip_roi_align_rotated", "refhip_roi_align_rotated_v1", "refhip_roi_align_v0",
+                                "refhip_roi_align_v1") for sfx in ("_forward", "_backward")}
+    names -= {"refhip_roi_align_rotated", "refhip_roi_align_rotated_v1", "refhip_roi_align_v0", "refhip_roi_align_v1"}
+    for fma in (False, True):
+        lib = RH.lib(fma)
+        missing = [n for n in sorted(names) if not hasattr(lib, n)]
+        assert not missing, missing
+    assert len(names) >= 20
