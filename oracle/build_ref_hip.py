@@ -299,6 +299,50 @@ API int refhip_poly_nms(const float* polys_sorted, int n, float thr, unsigned ch
   }
   return rc;
 }
+
+// ---- box_iou_rotated.py:L464-485 (and the _v1 twin): 32 x 16 threads per block
+#define IOU_CU_ENTRY(NS, NAME)                                                                          \
+API int NAME(const float* b1, int n1, const float* b2, int n2, float* ious) {                          \
+  if (n1 > 0 && n2 > 0) {                                                                               \
+    dim3 blocks((n1 + NS::BLOCK_DIM_X - 1) / NS::BLOCK_DIM_X, (n2 + NS::BLOCK_DIM_Y - 1) / NS::BLOCK_DIM_Y); \
+    dim3 threads(NS::BLOCK_DIM_X, NS::BLOCK_DIM_Y);                                                     \
+    NS::box_iou_rotated_cuda_kernel<float><<<blocks, threads, 0>>>(n1, n2, b1, b2, ious);              \
+  }                                                                                                     \
+  return ref_sync();                                                                                    \
+}
+IOU_CU_ENTRY(ref_iou_cu, refhip_box_iou_rotated)
+IOU_CU_ENTRY(ref_iou1_cu, refhip_box_iou_rotated_v1)
+
+// ---- nms_rotated.py:L450-493 (ML_NMS_ROTATED_CUDA_SRC): dets_sorted (n, BOX_LENGTH) on the device in visiting order;
+// keep_sorted: n host bytes, position i = the i-th visited box (the snippet writes keep[order[i]])
+#define NMS_CU_ENTRY(NS, NAME, BL)                                                                      \
+API int NAME(const float* dets_sorted, int n, float iou_threshold, unsigned char* keep_sorted) {       \
+  memset(keep_sorted, 0, n);                                                                            \
+  if (n <= 0) return 0;                                                                                 \
+  const int tpb = NS::threadsPerBlock;                                                                  \
+  const int col_blocks = (n + tpb - 1) / tpb;                                                           \
+  const size_t bytes = (size_t)n * col_blocks * sizeof(unsigned long long);                             \
+  unsigned long long* mask_d = nullptr;                                                                 \
+  if (hipMalloc((void**)&mask_d, bytes) != hipSuccess) return -1;                                       \
+  hipMemset(mask_d, 0, bytes);                                                                          \
+  NS::nms_rotated_cuda_kernel<float><<<dim3(col_blocks, col_blocks), dim3(tpb), 0>>>(n, iou_threshold, \
+                                                                                     dets_sorted, mask_d); \
+  int rc = ref_sync();                                                                                  \
+  std::vector<unsigned long long> mask((size_t)n * col_blocks), remv(col_blocks, 0ull);                 \
+  hipMemcpy(mask.data(), mask_d, bytes, hipMemcpyDeviceToHost);                                         \
+  hipFree(mask_d);                                                                                      \
+  for (int i = 0; i < n; i++) {                                                                         \
+    int nblock = i / tpb, inblock = i % tpb;                                                            \
+    if (!(remv[nblock] & (1ULL << inblock))) {                                                          \
+      keep_sorted[i] = 1;                                                                               \
+      unsigned long long* p = mask.data() + (size_t)i * col_blocks;                                     \
+      for (int j = nblock; j < col_blocks; j++) remv[j] |= p[j];                                        \
+    }                                                                                                   \
+  }                                                                                                     \
+  return rc;                                                                                            \
+}
+NMS_CU_ENTRY(ref_nms5_cu, refhip_nms_rotated5, 5)
+NMS_CU_ENTRY(ref_nms6_cu, refhip_nms_rotated6, 6)
 '''
 
 
@@ -325,6 +369,10 @@ def source():
     ciou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_iou_kernel.cu")).read()
     cbox = open(os.path.join(OPS, "reppoints_min_area_bbox", "min_area_bbox.cu")).read()
     pnms = module_strings(os.path.join(OPS, "nms_poly.py"))["HEADER"]
+    iou_cu = module_strings(os.path.join(OPS, "box_iou_rotated.py"))["IOU_ROTATED_CUDA_HEADER"]
+    iou1_cu = module_strings(os.path.join(OPS, "box_iou_rotated_v1.py"))["IOU_ROTATED_CUDA_HEADER"]
+    nms_cu = module_strings(os.path.join(OPS, "nms_rotated.py"))["ML_NMS_ROTATED_CUDA_HEADER"]
+    und = "#undef HOST_DEVICE\n#undef HOST_DEVICE_INLINE\n#undef CeilDIV\n#undef BOX_LENGTH\n"
     d2 = inline_headers(os.path.join(OPS, "dcn_v2.py"))      # conv forward, conv backward, pooling forward, pooling backward
     assert len(d2) == 4, len(d2)
     d2_conv = d2[1]
@@ -342,7 +390,11 @@ def source():
              ns("ref_dcn2", d2_conv.replace("using namespace std;", "")),
              ns("ref_ps_fwd", d2[2].replace("using namespace std;", "")),
              ns("ref_ps_bwd", d2[3].replace("using namespace std;", "")),
-             "#undef THCCeilDiv\n#undef DIVUP\n", ns("ref_pnms", pnms), ENTRY]
+             "#undef THCCeilDiv\n#undef DIVUP\n", ns("ref_pnms", pnms),
+             # the CUDA variants of rotated IoU / NMS (exchange-sort hull ordering, `>` suppression rule)
+             ns("ref_iou_cu", iou_cu), und, ns("ref_iou1_cu", iou1_cu), und,
+             "#define BOX_LENGTH 5\n", ns("ref_nms5_cu", nms_cu), und,
+             "#define BOX_LENGTH 6\n", ns("ref_nms6_cu", nms_cu), und, ENTRY]
     return "\n".join(parts)
 
 
@@ -356,8 +408,10 @@ def build(verbose=True):
         with open(path, "w") as f:
             f.write(src)
         for out, extra in (("libjdet_ref_hip.so", ["-ffp-contract=off"]), ("libjdet_ref_hip_fma.so", [])):
+            # -DNDEBUG: the IoU text asserts inside __host__ __device__ functions; re-including <cassert> inside a
+            # namespace would bind them to the host's __assert_fail
             cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-                   "-w"] + extra + [path, "-o", os.path.join(OUT_DIR, out)]
+                   "-w", "-DNDEBUG"] + extra + [path, "-o", os.path.join(OUT_DIR, out)]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
             if r.returncode != 0:
                 print(r.stdout[-6000:])

@@ -213,3 +213,26 @@ def poly_nms(boxes, thr, fma=False):
     keep = np.zeros((max(n, 1),), np.uint8)
     _check(lib(fma).refhip_poly_nms(_t(srt), _i(n), _f(thr), keep.ctypes.data_as(_p)), "poly_nms")
     return order[torch.from_numpy(keep[:n].astype(bool)).to(order.device)]
+
+
+def box_iou_rotated(b1, b2, version=0, fma=False):
+    """the CUDA variant of the rotated IoU (exchange-sort hull ordering, device trigonometry): (n1, 5), (n2, 5) -> (n1, n2)"""
+    b1, b2 = b1.float().contiguous(), b2.float().contiguous()
+    out = torch.zeros((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    fn = lib(fma).refhip_box_iou_rotated_v1 if version else lib(fma).refhip_box_iou_rotated
+    _check(fn(_t(b1), _i(b1.shape[0]), _t(b2), _i(b2.shape[0]), _t(out)), "box_iou_rotated")
+    return out
+
+
+def nms_rotated(dets, order, thr, fma=False):
+    """the CUDA rotated NMS (suppress at iou > thr): dets (n, 5 | 6) device, order (n,) visiting order -> bool keep mask
+    over original indices"""
+    import numpy as np
+    n, bl = dets.shape
+    srt = dets[order.long()].float().contiguous()
+    keep = np.zeros((max(n, 1),), np.uint8)
+    fn = lib(fma).refhip_nms_rotated5 if bl == 5 else lib(fma).refhip_nms_rotated6
+    _check(fn(_t(srt), _i(n), _f(thr), keep.ctypes.data_as(_p)), "nms_rotated")
+    mask = torch.zeros((n,), dtype=torch.bool, device=dets.device)
+    mask[order.long()[torch.from_numpy(keep[:n].astype(bool)).to(dets.device)]] = True
+    return mask

@@ -251,3 +251,43 @@ def test_poly_nms_against_the_reference_kernel(dev):
     assert 20 < len(ref) < len(polys)
     assert poly_nms(boxes, thr).cpu().numpy().tolist() == ref
     assert PO.poly_nms(polys, scores.astype(np.float32), thr) == ref
+
+
+_UNVALIDATED = pytest.mark.xfail(strict=False, reason="written after the round's GPU budget was spent: its first run on a "
+                                 "device is the round-end run (an XPASS there is the validation)")
+
+
+@_UNVALIDATED
+@pytest.mark.parametrize("version", [0, 1])
+def test_rotated_iou_cuda_variant_against_the_reference_kernel(dev, version):
+    """the CUDA text of the rotated IoU (hull ordered by an exchange sort, device cosf / sinf) against the product in
+    its `sort_mode = 1` and the restatement's: IoU of well-conditioned random boxes to 1e-4, mean 1e-6"""
+    from tests.test_gpu_iou_nms import _iou
+    rng = np.random.default_rng(31 + version)
+    b1, b2 = I.random_obbs(rng, 300, extent=300.0, wh=(10.0, 120.0)), I.random_obbs(rng, 280, extent=300.0, wh=(10.0, 120.0))
+    ref = RH.box_iou_rotated(torch.from_numpy(b1).to(dev), torch.from_numpy(b2).to(dev), version).cpu().numpy()
+    assert (ref > 0.05).mean() > 0.02
+    for got in (_iou(b1, b2, dev, version, 1), O.box_iou_rotated(b1, b2, version=version, sort_mode=1)):
+        d = np.abs(got.astype(np.float64) - ref)
+        assert d.max() < 1e-4 and d.mean() < 1e-6, (d.max(), d.mean())
+
+
+@_UNVALIDATED
+@pytest.mark.parametrize("box_len", [5, 6])
+def test_rotated_nms_cuda_variant_against_the_reference_kernel(dev, box_len):
+    """nms_rotated.py's CUDA kernel (`iou > thr`) + the scan of its launch snippet against the product's "cuda" rule"""
+    from jdet_amd.ops.nms_rotated import nms_rotated_keep_mask
+    rng = np.random.default_rng(41 + box_len)
+    boxes = I.clustered_obbs(rng, 600, 12, 300.0)
+    scores = rng.uniform(0, 1, 600).astype(np.float32)
+    thr = 0.3
+    iou = O.box_iou_rotated(boxes, boxes, sort_mode=1)
+    ok = (np.abs(iou - thr) > 1e-3).all(1)                     # no decision within reach of the threshold
+    boxes, scores = boxes[ok], scores[ok]
+    dets = boxes if box_len == 5 else np.concatenate([boxes, rng.integers(0, 3, (boxes.shape[0], 1)).astype(np.float32)], 1)
+    td = torch.from_numpy(dets.astype(np.float32)).to(dev)
+    order = torch.argsort(torch.from_numpy(scores).to(dev), descending=True, stable=True)
+    ref = RH.nms_rotated(td, order, thr).cpu().numpy()
+    got = nms_rotated_keep_mask(td, order, thr, rule="cuda").cpu().numpy()
+    assert 10 < ref.sum() < len(ref)
+    np.testing.assert_array_equal(got, ref)
