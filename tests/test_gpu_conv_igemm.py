@@ -3,7 +3,6 @@ deformable form, against the column-matrix path (jdet_deform_im2col_nhwc + GEMM)
 
 Tolerance: fp32 products and fp32 accumulation over K = 9 * Cin terms in a different order than the reference GEMM:
 |err| <= 2e-5 * sqrt(K) * max|x| * max|w| is generous (observed ~1e-6 relative to the output scale)."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
