@@ -1,5 +1,7 @@
-"""usage (GPU box): python scripts/refk_diag.py -- how far the CPU restatement and the product kernels sit from the
-reference's own RoIAlign kernels (oracle/_ref/libjdet_ref_hip.so), per dialect: max abs difference and bit-equal share"""
+"""usage (GPU box): python scripts/refk_diag.py [--time] -- how far the CPU restatement and the product kernels sit from the
+reference's own RoIAlign kernels (oracle/_ref/libjdet_ref_hip.so), per dialect: max abs difference and bit-equal share.
+--time: the reference's rotated RoIAlign kernels against the product's on the north-star workload (1 x 256 x 256 x 256 map,
+2000 RoIs, 7 x 7 bins, 2 x 2 samples) on the same device -- wall time per call incl. the reference wrapper's device sync."""
 import sys
 
 import numpy as np
@@ -11,6 +13,35 @@ from oracle import ref_hip as RH        # noqa: E402
 from tests.test_gpu_reference_kernels import KINDS, _case, _product   # noqa: E402
 
 dev = torch.device("cuda:0")
+
+if "--time" in sys.argv:
+    import time
+    from tests import inputs as I
+    from tests.test_gpu_roi_align import _layer
+    rng = np.random.default_rng(1000)
+    feat = torch.randn((1, 256, 256, 256), device=dev)
+    rois = torch.from_numpy(I.rois_from_obbs(I.random_obbs(rng, 2000), np.zeros(2000))).to(dev)
+    grad = torch.randn((2000, 256, 7, 7), device=dev)
+    fcl = feat.contiguous(memory_format=torch.channels_last)
+
+    def wall(fn, n=20):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e6
+
+    layer = _layer(O.V_ROT, (7, 7), 0.25, 2)
+    print("forward : reference kernel %.1f us, product %.1f us" % (
+        wall(lambda: RH.roi_align_forward("rot", feat, rois, (7, 7), 0.25, 2)), wall(lambda: layer(fcl, rois))))
+    x = fcl.clone().requires_grad_(True)
+    y = layer(x, rois)
+    print("backward: reference kernel %.1f us, product %.1f us (autograd call)" % (
+        wall(lambda: RH.roi_align_backward("rot", grad, rois, feat.shape, 0.25, 2)),
+        wall(lambda: torch.autograd.grad(y, x, grad, retain_graph=True))))
+    sys.exit(0)
 
 
 def d(a, b):
