@@ -107,9 +107,26 @@ def make_step(workload, d):
             return (step, nbytes / 1e9, "GB", nbytes,
                     "EXPERIMENTAL roi_order_kernel + roi_plan_kernel<ROTATED> + roi_pool_kernel (channels-last output)",
                     "f32")
-        cl = path == "roi_cl"   # default product path: RoI-stationary kernels, channels-last result
-        out = torch.empty((R, 256, 7, 7), device=feat.device,
-                          memory_format=torch.channels_last if cl else torch.contiguous_format)
+        if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = schedule / records + channel-sliced kernel
+            out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
+            op = out.data_ptr()
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+            wp = ws.data_ptr()
+            lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
+
+            def step():
+                # schedule + per-RoI records are recomputed every step: RoIs arrive in arbitrary order
+                L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op, wp, wsb,
+                                                      L.stream_ptr(feat)), "fwd_cl")
+            d["out"] = out
+            legacy = os.environ.get("JDET_ROI_FWD_LEGACY", "0") == "1" or os.environ.get("JDET_ROI_FWD_MODE", "0") == "1"
+            return (step, nbytes / 1e9, "GB", nbytes,
+                    "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out> (legacy)" if legacy
+                    else "roi_prep_kernel<ROTATED> + roi_align_fwd_sliced_kernel<ROTATED> (channels-last out)", "f32")
+        # path "roi": the RoI-stationary kernels with the reference's (R,C,7,7)-contiguous result
+        cl = False
+        out = torch.empty((R, 256, 7, 7), device=feat.device)
         obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)
         op = out.data_ptr()
         o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
@@ -117,19 +134,14 @@ def make_step(workload, d):
         lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
 
         def step():
-            # the XCD-aware schedule is recomputed every step: RoIs arrive in arbitrary order
             st = L.stream_ptr(feat)
             if use_order:
                 L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
-            if cl:
-                L.check(lib.jdet_roi_align_forward_cl_roi(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
-                                                          o0 if use_order else None, op, st), "fwd_cl_roi")
-            else:
-                L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
-                                                   o0 if use_order else None, op, st), "fwd")
+            L.check(lib.jdet_roi_align_forward(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
+                                               o0 if use_order else None, op, st), "fwd")
         d["out"] = out
-        return (step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,%s>"
-                % ("channels-last out" if cl else "(R,C,7,7) out"), "f32")
+        return (step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,(R,C,7,7) out>",
+                "f32")
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]

@@ -192,72 +192,50 @@ __global__ __launch_bounds__(1024) void bias_act_bwd_kernel(const v4f* __restric
     for (int t = threadIdx.x; t < (int)blockDim.x; t += cpt)
 #pragma unroll
       for (int k = 0; k < 4; k++) acc[k] += s_red[(size_t)t * 4 + k];
-    float* out = partial + (size_t)blockIdx.x * 2 * cpt * 4;      // row layout of frozen_bn_finish_kernel (dbeta half)
+    float* out = partial + (size_t)blockIdx.x * 2 * cpt * 4;      // row layout of sums_finish_kernel (dbeta half)
 #pragma unroll
     for (int k = 0; k < 4; k++) out[threadIdx.x * 4 + k] = acc[k];
   }
 }
 
-// second stage of the per-channel sums: workgroup = 32 channels x 8 row groups, 4 independent loads in flight per
-// lane, LDS combine in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void frozen_bn_finish_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float s_b[8][32], s_g[8][32];
-  const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + lane;
-  float sb[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    int b = rg;
-    for (; b + 24 < nblocks; b += 32) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        sb[u] += partial[(size_t)(b + 8 * u) * 2 * C + c];
-        if (dgamma) sg[u] += partial[(size_t)(b + 8 * u) * 2 * C + C + c];
-      }
-    }
-    for (; b < nblocks; b += 8) {
-      sb[0] += partial[(size_t)b * 2 * C + c];
-      if (dgamma) sg[0] += partial[(size_t)b * 2 * C + C + c];
-    }
-  }
-  s_b[rg][lane] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
-  s_g[rg][lane] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
-  __syncthreads();
-  if (rg == 0 && c < C) {
-    float tb = 0.f, tg = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      tb += s_b[r][lane];
-      tg += s_g[r][lane];
-    }
-    if (dbeta) dbeta[c] = tb;
-    if (dgamma) dgamma[c] = tg;
-  }
-}
-
-// the bias path's second stage: the same fixed-order sum with 32 channels x 32 row groups per workgroup and every
-// row of a thread in flight at once (nblocks <= 256 -> 8 rows per thread): the 256-thread version above needed 24 us
-// for 512 rows of 256 channels behind an 8-workgroup grid
-__global__ __launch_bounds__(1024) void bias_finish_kernel(const float* __restrict__ partial, int nblocks, int C,
-                                                          float* __restrict__ dbeta) {
+// Second stage of the per-channel sums (BN: dbeta + dgamma; conv bias: dbeta only): workgroup = 32 channels x 32 row
+// groups, every partial row of a thread in flight at once (nblocks <= 256 -> 8 rows per thread), fixed-order LDS
+// combine (deterministic).  History: the first version (256 threads, 8 row groups, 512 partial rows) took 14.5 us per
+// BN layer -- 74 launches = 1.07 ms of the S2ANet step (profiles/r03_s2anet_train_steady_state_kernels.txt) -- behind
+// an 8-workgroup grid on a 256-CU chip; the first stages now write at most 256 rows from 1024-thread workgroups.
+template <bool GAMMA>
+__global__ __launch_bounds__(1024) void sums_finish_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float s_b[32][33];
+  __shared__ float s_g[GAMMA ? 32 : 1][33];
   const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + lane;
-  float v[8];
+  float v[8], w[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) {
     const int b = rg + 32 * u;
-    v[u] = (c < C && b < nblocks) ? partial[(size_t)b * 2 * C + c] : 0.f;
+    const bool ok = c < C && b < nblocks;
+    v[u] = ok ? partial[(size_t)b * 2 * C + c] : 0.f;
+    w[u] = (GAMMA && ok) ? partial[(size_t)b * 2 * C + C + c] : 0.f;
   }
   float acc = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-  for (int b = rg + 256; b < nblocks; b += 32) acc += (c < C) ? partial[(size_t)b * 2 * C + c] : 0.f;
+  float accg = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+  for (int b = rg + 256; b < nblocks; b += 32) {
+    acc += (c < C) ? partial[(size_t)b * 2 * C + c] : 0.f;
+    if (GAMMA) accg += (c < C) ? partial[(size_t)b * 2 * C + C + c] : 0.f;
+  }
   s_b[rg][lane] = acc;
+  if (GAMMA) s_g[rg][lane] = accg;
   __syncthreads();
   if (rg == 0 && c < C) {
-    float t = 0.f;
+    float t = 0.f, tg = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; r++) t += s_b[r][lane];
-    dbeta[c] = t;
+    for (int r = 0; r < 32; r++) {
+      t += s_b[r][lane];
+      if (GAMMA) tg += s_g[r][lane];
+    }
+    if (dbeta) dbeta[c] = t;
+    if (GAMMA && dgamma) dgamma[c] = tg;
   }
 }
 
@@ -343,6 +321,13 @@ JDET_API int jdet_frozen_bn_act_backward(const float* grad_y_nhwc, const float* 
   v4f* dx = (v4f*)grad_x_nhwc;
   v4f* dr = (v4f*)grad_residual_nhwc;
   float* part = (float*)workspace;
+  if (affine && 1024 % g.cpt == 0) {
+    // affine pass: 1024-thread workgroups (a multiple of the channel-quad count, as the LDS combine needs) and at
+    // most 256 of them, so that the second stage has every partial row of a thread in flight at once
+    g.block = 1024;
+    long want = (long)((n4 + (size_t)g.block * 4 - 1) / ((size_t)g.block * 4));
+    g.grid = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  }
   const size_t lds = affine ? sizeof(float) * 8 * (size_t)g.block : 0;
 #define JDET_BN_BWD(RELU, RES, AFF)                                                                            \
   hipLaunchKernelGGL((frozen_bn_bwd_kernel<RELU, RES, AFF>), dim3(g.grid), dim3(g.block), lds, st, dy, y, x, dx, dr, \
@@ -361,7 +346,7 @@ JDET_API int jdet_frozen_bn_act_backward(const float* grad_y_nhwc, const float* 
 #undef JDET_BN_BWD
   e = jdet_launch_status();
   if (e || !affine) return e;
-  hipLaunchKernelGGL(frozen_bn_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part, g.grid, C, grad_weight,
+  hipLaunchKernelGGL((sums_finish_kernel<true>), dim3((C + 31) / 32), dim3(1024), 0, st, part, g.grid, C, grad_weight,
                      grad_bias);
   return jdet_launch_status();
 }
@@ -381,7 +366,7 @@ JDET_API int jdet_bias_act_backward(const float* grad_y_nhwc, const float* y_nhw
   if (!workspace || workspace_bytes < jdet_frozen_bn_act_backward_workspace(P, C)) return JDET_E_WORKSPACE;
   // 1024-thread workgroups (a multiple of the channel-quad count, as the LDS combine needs) and at most 256 of them:
   // a quarter of the partial rows of the BN kernels' geometry for the second stage to read
-  if (g.cpt <= 256) g.block = 1024;
+  if (1024 % g.cpt == 0) g.block = 1024;
   const size_t n4 = (size_t)P * g.cpt;
   long want = (long)((n4 + (size_t)g.block * 4 - 1) / ((size_t)g.block * 4));
   g.grid = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
@@ -394,6 +379,7 @@ JDET_API int jdet_bias_act_backward(const float* grad_y_nhwc, const float* y_nhw
     hipLaunchKernelGGL((bias_act_bwd_kernel<false>), dim3(g.grid), dim3(g.block), lds, st, (const v4f*)grad_y_nhwc,
                        (const v4f*)nullptr, (v4f*)nullptr, g.cpt, n4, part);
   if ((e = jdet_launch_status())) return e;
-  hipLaunchKernelGGL(bias_finish_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, g.grid, C, grad_bias);
+  hipLaunchKernelGGL((sums_finish_kernel<false>), dim3((C + 31) / 32), dim3(1024), 0, st, part, g.grid, C,
+                     (float*)nullptr, grad_bias);
   return jdet_launch_status();
 }

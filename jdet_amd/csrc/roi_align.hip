@@ -107,6 +107,8 @@ __device__ __forceinline__ void acc_sample(float (&acc)[4], const RoiGeom& g, in
   }
 }
 
+#include "roi_align_sliced.h"   // channel-sliced forward (product path of the sampling-2 dialects)
+
 // ---- vector fast path: C % 4 == 0, map < 2 GiB per image; RiRoI with 4 or 8 orientation planes -------------
 // Lane owns 4 consecutive channels.  Taps are fetched with buffer_load_dwordx4 whose per-tap
 // pixel byte offset is an SGPR (soffset) -- no per-load 64-bit VALU address arithmetic -- and the
@@ -997,6 +999,47 @@ int launch_bwd(const float* gout, const float* rois, float* gin, int R, int C, i
   return jdet_launch_status();
 }
 
+
+// ---- channel-sliced forward (roi_align_sliced.h) ----
+bool sliced_ok(int variant, int R, int N, int C, int H, int W, int PH, int PW, int sample_num, int nO) {
+  static const int legacy = env_int("JDET_ROI_FWD_LEGACY", 0);   // profiling: the RoI-stationary kernels of rounds 1-3
+  if (legacy || g_fwd_reference_order || sample_num != 2) return false;
+  const long nbins = (long)PH * PW;
+  if (nbins < jdet_roi_sliced::kItemsPerWave || C % jdet_roi_sliced::kSliceC != 0) return false;
+  if ((size_t)N * H * W * C * 4 >= (1ull << 31) || (long)R * nbins >= (1L << 30)) return false;
+  if (variant == JDET_ROI_RIROI && nO != 4 && nO != 8) return false;
+  return true;
+}
+
+template <int VARIANT, int NO>
+int launch_sliced(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W, int PH, int PW,
+                  float scale, int nO, void* ws, hipStream_t st) {
+  using namespace jdet_roi_sliced;
+  int* hdr = (int*)ws;
+  RoiRec* recs = (RoiRec*)((char*)ws + kHdrBytes);
+  hipLaunchKernelGGL((roi_prep_kernel<VARIANT>), dim3(1), dim3(kPrepThreads), 0, st, rois, R, scale, N, H, W, PH, PW,
+                     nO, hdr, recs);
+  const int nslices = C / kSliceC;
+  const long items = (long)R * PH * PW;
+  const unsigned blocks = (unsigned)(nslices * ((items + 4 * kItemsPerWave - 1) / (4 * kItemsPerWave)));
+#define JDET_SL(B_, S_)                                                                                          \
+  hipLaunchKernelGGL((roi_align_fwd_sliced_kernel<VARIANT, NO, B_, S_>), dim3(blocks), dim3(256), 0, st, feat, hdr, \
+                     recs, out, R, N, C, H, W, PH, PW, nslices)
+  if constexpr (VARIANT == JDET_ROI_ROTATED && NO == 0) {   // tuning knobs (profiling runs) on the benchmarked dialect only
+    static const int batch = env_int("JDET_ROI_SLICED_BATCH", 8), store = env_int("JDET_ROI_SLICED_STORE", 0);
+    if (batch == 4 && store == 0) JDET_SL(4, 0);
+    else if (batch == 16 && store == 0) JDET_SL(16, 0);
+    else if (batch == 8 && store == 1) JDET_SL(8, 1);
+    else if (batch == 8 && store == 2) JDET_SL(8, 2);
+    else if (batch == 16 && store == 1) JDET_SL(16, 1);
+    else JDET_SL(8, 0);
+  } else {
+    JDET_SL(8, 0);
+  }
+#undef JDET_SL
+  return jdet_launch_status();
+}
+
 int check_common(int variant, const void* a, const void* b, const void* c, int N, int C, int H,
                  int W, int R, int PH, int PW, int n_orient) {
   if (variant < 0 || variant > 4) return JDET_E_BADARG;
@@ -1085,6 +1128,51 @@ JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N
     default:
       return launch_fwd<JDET_ROI_HBB_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true);
   }
+}
+
+// Product forward with a channels-last result: the channel-sliced kernels (roi_align_sliced.h) where they apply
+// (sampling 2, PH*PW >= 16, C % 32 == 0, default arithmetic mode), otherwise the RoI-stationary kernels above under the
+// XCD-aware spatial order.  The schedule / per-RoI records live in the caller's workspace.
+JDET_API size_t jdet_roi_align_forward_cl_workspace(int R) {
+  return (size_t)jdet_roi_sliced::kHdrBytes + sizeof(jdet_roi_sliced::RoiRec) * (size_t)(R > 0 ? R : 1);
+}
+
+JDET_API int jdet_roi_align_forward_cl(int variant, const float* feat, int N, int C, int H, int W, const float* rois,
+                                       int R, int PH, int PW, float spatial_scale, int sample_num, int n_orient,
+                                       float* out_cl, void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
+  int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, n_orient);
+  if (e) return e;
+  if (C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
+  if (variant == JDET_ROI_RIROI && n_orient != 4 && n_orient != 8) return JDET_E_UNSUPPORTED;
+  if (R == 0) return JDET_OK;
+  if (!workspace || workspace_bytes < jdet_roi_align_forward_cl_workspace(R)) return JDET_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  if (sliced_ok(variant, R, N, C, H, W, PH, PW, sample_num, n_orient)) {
+    switch (variant) {
+      case JDET_ROI_ROTATED:
+        return launch_sliced<JDET_ROI_ROTATED, 0>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 1, workspace, st);
+      case JDET_ROI_ROTATED_V1:
+        return launch_sliced<JDET_ROI_ROTATED_V1, 0>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 1, workspace, st);
+      case JDET_ROI_RIROI:
+        if (n_orient == 8)
+          return launch_sliced<JDET_ROI_ROTATED, 8>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 8, workspace, st);
+        return launch_sliced<JDET_ROI_ROTATED, 4>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 4, workspace, st);
+      case JDET_ROI_HBB_V0:
+        return launch_sliced<JDET_ROI_HBB_V0, 0>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 1, workspace, st);
+      default:
+        return launch_sliced<JDET_ROI_HBB_V1, 0>(feat, rois, out_cl, R, N, C, H, W, PH, PW, spatial_scale, 1, workspace, st);
+    }
+  }
+  const int32_t* order = nullptr;
+  if (R >= 64) {   // below that the map traffic is too small for the schedule to matter
+    int32_t* o = (int32_t*)workspace;
+    const int cols = (variant == JDET_ROI_HBB_V0 || variant == JDET_ROI_HBB_V1) ? 5 : 6;
+    e = jdet_roi_spatial_order(rois, R, cols, spatial_scale, N, H, W, o, o + R, stream);
+    if (e) return e;
+    order = o;
+  }
+  return jdet_roi_align_forward_cl_roi(variant, feat, N, C, H, W, rois, R, PH, PW, spatial_scale, sample_num, n_orient,
+                                       order, out_cl, stream);
 }
 
 // Atomic-scatter backward (all dialects, any sampling).  The exported jdet_roi_align_backward

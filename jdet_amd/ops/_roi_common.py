@@ -116,6 +116,21 @@ def spatial_order(rois_c, spatial_scale, N, H, W):
     return buf[0]
 
 
+def forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num, n_orient):
+    """Product forward into a channels-last `out` (jdet_roi_align_forward_cl): the channel-sliced kernels where they
+    apply, otherwise the RoI-stationary ones under the XCD-aware order.  RoIs with a negative batch index are skipped
+    (their rows of `out` stay as they are)."""
+    N, C, H, W = feat.shape
+    R = rois_c.shape[0]
+    if R == 0:
+        return
+    wsb = L.lib().jdet_roi_align_forward_cl_workspace(R)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+    L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
+                                              spatial_scale, sample_num, n_orient, L.ptr(out), L.ptr(ws), wsb,
+                                              L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+
+
 class RoIAlignFunction(torch.autograd.Function):
     """forward(input (N,C,H,W), rois (R,6|5)) -> (R,C,PH,PW); grad only w.r.t. input
     (reference: `return input_grad, None`, roi_align_rotated.py:L308)."""
@@ -134,11 +149,8 @@ class RoIAlignFunction(torch.autograd.Function):
         if _roi_cl_ok(variant, C, H, W, n_orient):
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device,
                               memory_format=torch.channels_last)
-            order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
-            L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                                          float(spatial_scale), int(sample_num), int(n_orient),
-                                                          L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
-                    "jdet_roi_align_forward_cl_roi")
+            order = None
+            forward_cl(variant, feat, rois_c, out, PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
         else:
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
@@ -188,10 +200,7 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             r_i = rois_c.clone()
             r_i[:, 0] = torch.where(lvl == i, rois_c[:, 0], torch.full_like(rois_c[:, 0], -1.0))
             if R and roi_cl:
-                L.check(L.lib().jdet_roi_align_forward_cl_roi(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
-                                                              float(scales[i]), int(sample_num), int(n_orient), None,
-                                                              L.ptr(out), L.stream_ptr(fm)),
-                        "jdet_roi_align_forward_cl_roi")
+                forward_cl(variant, fm, r_i, out, PH, PW, float(scales[i]), int(sample_num), int(n_orient))
             elif R:
                 L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
                                                        float(scales[i]), int(sample_num), int(n_orient), None,

@@ -269,3 +269,92 @@ def test_spatial_order_is_a_permutation(dev, R, N):
         d_sched = np.linalg.norm(c[8:] - c[:-8], axis=1).mean()
         d_rand = np.linalg.norm(rois[8:, 1:3] - rois[:-8, 1:3], axis=1).mean()
         assert d_sched < 0.25 * d_rand
+
+
+def _fwd_cl_both(variant, x, rois, hw, scale, nO, rois_legacy=None):
+    """(channel-sliced product path, RoI-stationary kernels of rounds 1-3) on the same inputs, merged-tap arithmetic.
+    Output buffers start as NaN so that rows a kernel skips (masked RoIs) stay recognisable."""
+    if rois_legacy is None:
+        rois_legacy = rois
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    N, C, H, W = x.shape
+    R = rois.shape[0]
+    outs = []
+    for sliced in (True, False):
+        out = torch.full((R, C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
+        if sliced:
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
+            L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0], hw[1],
+                                                  scale, 2, nO, out.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(x)),
+                    "fwd_cl")
+        else:
+            L.check(lib.jdet_roi_align_forward_cl_roi(variant, x.data_ptr(), N, C, H, W, rois_legacy.data_ptr(), R, hw[0],
+                                                      hw[1], scale, 2, nO, None, out.data_ptr(), L.stream_ptr(x)),
+                    "fwd_cl_roi")
+        outs.append(out)
+    torch.cuda.synchronize()
+    return outs
+
+
+@pytest.mark.parametrize("variant,nO,C", [(O.V_ROT, 1, 256), (O.V_ROT, 1, 96), (O.V_ROT_V1, 1, 64), (O.V_HBB0, 1, 32),
+                                          (O.V_HBB1, 1, 128), (O.V_RI, 8, 64), (O.V_RI, 4, 32)])
+@pytest.mark.parametrize("hw", [(7, 7), (4, 4), (5, 9)])
+def test_sliced_forward_equals_roi_stationary_kernels(dev, variant, nO, C, hw):
+    """jdet_roi_align_forward_cl (channel-sliced: Morton-sorted records + 8-lane groups per item) runs the same
+    geometry functions, the same tap merge and the same fma chain as the RoI-stationary merged-tap kernel: bit-equal.
+    Covers several images, masked RoIs (negative batch index: rows untouched), RoIs hanging over the map border, a RoI
+    of an image that does not exist (zeros), R not a multiple of anything, slices counts 1 / 2 / 3 / 4 / 8."""
+    from jdet_amd import _lib as L
+    if fwd_mode_is_reference():
+        pytest.skip("merged-tap arithmetic only")
+    rng = np.random.default_rng(100 + variant * 7 + C + hw[0])
+    N, H, W, scale = 3, 40, 56, 0.25
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    R = 203
+    rois = np.concatenate([I.rois_from_obbs(I.random_obbs(rng, R, extent=W / scale, wh=(4.0, 200.0)),
+                                            rng.integers(0, N, R)), I.edge_rois(H, W, scale)], 0)
+    rois[rng.random(rois.shape[0]) < 0.2, 0] = -1.0        # masked
+    rois[5, 0] = 7.0                                        # no such image
+    if variant in (O.V_HBB0, O.V_HBB1):
+        rois = I.obb_to_hbb_rois(rois)
+    x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.from_numpy(rois).to(dev)
+    rois_l = rois.copy()
+    rois_l[5, 0] = -1.0      # (the RoI-stationary kernel would read image 7 of 3 through its per-image descriptor)
+    a, b = _fwd_cl_both(variant, x, r, hw, scale, nO, torch.from_numpy(rois_l).to(dev))
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    masked = rois[:, 0] < 0
+    assert np.isnan(a[masked]).all() and np.isnan(b[masked]).all()
+    assert not np.isnan(a[~masked]).any()
+    assert np.array_equal(a[5], np.zeros_like(a[5]))
+    keep = ~masked
+    keep[5] = False
+    assert np.array_equal(a[keep], b[keep])
+    ref = O.roi_align_forward(variant, feat, rois[keep], hw, scale, 2, nO) if variant == O.V_RI else \
+        O.roi_align_forward(variant, feat, rois[keep], hw, scale, 2)
+    np.testing.assert_allclose(a[keep], ref, rtol=0, atol=FWD_MERGED_ATOL)
+
+
+def fwd_mode_is_reference():
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    m = lib.jdet_set_roi_forward_mode(0)
+    lib.jdet_set_roi_forward_mode(m)
+    return m == 1
+
+
+def test_sliced_forward_north_star_equals_roi_stationary(dev):
+    """the roofline shape: 1 x 256 x 256 x 256 map, 2000 RoIs, 7 x 7: sliced == RoI-stationary bit for bit, and a
+    second call on a dirty workspace gives the same result (the workspace carries no state between calls)"""
+    if fwd_mode_is_reference():
+        pytest.skip("merged-tap arithmetic only")
+    rng = np.random.default_rng(1)
+    R = 2000
+    rois = torch.from_numpy(I.rois_from_obbs(I.random_obbs(rng, R), np.zeros(R))).to(dev)
+    x = torch.randn(1, 256, 256, 256, device=dev).contiguous(memory_format=torch.channels_last)
+    a, b = _fwd_cl_both(O.V_ROT, x, rois, (7, 7), 0.25, 1)
+    assert torch.equal(a, b)
+    a2, _ = _fwd_cl_both(O.V_ROT, x, rois, (7, 7), 0.25, 1)
+    assert torch.equal(a, a2)
