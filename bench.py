@@ -107,23 +107,28 @@ def make_step(workload, d):
             return (step, nbytes / 1e9, "GB", nbytes,
                     "EXPERIMENTAL roi_order_kernel + roi_plan_kernel<ROTATED> + roi_pool_kernel (channels-last output)",
                     "f32")
-        if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = schedule / records + channel-sliced kernel
+        if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = XCD-aware schedule + RoI-stationary kernel
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R)
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
             wp = ws.data_ptr()
             lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
+            if os.environ.get("JDET_ROI_SLICED_PLANAR", "0") == "1":
+                # EXPERIMENT (L2 channel spread): the map as [slice][pixel][32 channels]; same values, other addresses
+                planar = feat.permute(0, 2, 3, 1).reshape(256 * 256, 8, 32).permute(1, 0, 2).contiguous()
+                d["planar"] = planar
+                fp = planar.data_ptr()
 
             def step():
                 # schedule + per-RoI records are recomputed every step: RoIs arrive in arbitrary order
                 L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op, wp, wsb,
                                                       L.stream_ptr(feat)), "fwd_cl")
             d["out"] = out
-            legacy = os.environ.get("JDET_ROI_FWD_LEGACY", "0") == "1" or os.environ.get("JDET_ROI_FWD_MODE", "0") == "1"
+            sliced = os.environ.get("JDET_ROI_FWD_SLICED", "0") == "1" or os.environ.get("JDET_ROI_FWD_MODE", "0") == "2"
             return (step, nbytes / 1e9, "GB", nbytes,
-                    "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out> (legacy)" if legacy
-                    else "roi_prep_kernel<ROTATED> + roi_align_fwd_sliced_kernel<ROTATED> (channels-last out)", "f32")
+                    "EXPERIMENT roi_sort_plan_kernel<ROTATED> + roi_pool_sliced_kernel (channels-last out)" if sliced
+                    else "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out>", "f32")
         # path "roi": the RoI-stationary kernels with the reference's (R,C,7,7)-contiguous result
         cl = False
         out = torch.empty((R, 256, 7, 7), device=feat.device)
@@ -465,6 +470,9 @@ def main():
         d = make_inputs(a.workload, a.rois, 1000 + rank, dev)
         step, units, unit_name, nbytes, kname, dtype = make_step(a.workload, d)
         t, dev_ms = timed(step, a.steps, a.warmup, dist, dev)
+        if os.environ.get("JDET_BENCH_CHECKSUM", "0") == "1" and torch.is_tensor(d.get("out")):
+            o = d["out"].double()     # A/B runs of one workload must agree: printed to stderr, not part of the line
+            print("checksum %s sum %.9e abs %.9e" % (a.workload, float(o.sum()), float(o.abs().sum())), file=sys.stderr)
         if rank == 0:
             line = {
                 "metric": ("rotated RoIAlign forward algorithmic GB/s (1024x1024 tile, %d RoIs)" % a.rois

@@ -82,16 +82,19 @@ int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, in
                                   const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
                                   int n_orient, const int32_t* order, float* out_cl, jdet_stream_t stream);
 
-/* Product forward with the channels-last result out_cl (R, PH, PW, C); same call sites as jdet_roi_align_forward
- * (roi_align_rotated.py:L265-283, roi_align_rotated_v1.py:L308-326, riroi_align.py:L425-427, roi_align.py:L217-237).
- * Where sample_num == 2, PH*PW >= 16, C % 32 == 0, the map is under 2 GiB and the arithmetic mode is 0, the
- * CHANNEL-SLICED kernels run: one launch sorts the RoIs by the Morton code of their centre and writes a 64-byte
- * geometry record per RoI (double-precision trig once per RoI), the second gives every XCD one 32-channel slice of
- * every RoI (workgroup b -> slice b % (C/32)), so a pixel is one 128-byte line in exactly one XCD's L2.  Otherwise the
- * kernels of jdet_roi_align_forward_cl_roi run under jdet_roi_spatial_order.  Same values either way (merged-tap
- * arithmetic).  workspace: jdet_roi_align_forward_cl_workspace(R) bytes, any content, 16-byte aligned.
+/* Forward with the channels-last result out_cl (R, PH, PW, C) and the schedule computed inside; same call sites as
+ * jdet_roi_align_forward (roi_align_rotated.py:L265-283, roi_align_rotated_v1.py:L308-326, riroi_align.py:L425-427,
+ * roi_align.py:L217-237).  Default: jdet_roi_spatial_order (R >= 64) + the kernels of jdet_roi_align_forward_cl_roi.
+ * In forward mode 2 (jdet_set_roi_forward_mode), where sample_num == 2, PH*PW >= 16, C % 32 == 0 and the map is under
+ * 2 GiB, the CHANNEL-SLICED kernels run instead: one launch sorts the RoIs by the Morton code of their centre (block 0)
+ * and writes the PLAN (other blocks): per (RoI, bin) the merged tap list of its 4 samples, (byte offset, weight) pairs,
+ * geometry with double-precision trig once per RoI; the second gives every XCD one 32-channel slice of every RoI
+ * (workgroup b -> slice b % (C/32); a group of 8 lanes = one (RoI, bin) x 32 channels), so a pixel is one 128-byte
+ * line in exactly one XCD's L2.  Same values either way (merged-tap arithmetic).
+ * workspace: jdet_roi_align_forward_cl_workspace(R, PH, PW) bytes (schedule + plan: ~ 136 bytes per (RoI, bin)), any
+ * content, 256-byte aligned.
  * RoIs with a negative batch index are skipped as in jdet_roi_align_forward. */
-size_t jdet_roi_align_forward_cl_workspace(int R);
+size_t jdet_roi_align_forward_cl_workspace(int R, int PH, int PW);
 int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W, const float* rois,
                               int R, int PH, int PW, float spatial_scale, int sample_num, int n_orient,
                               float* out_cl, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
@@ -100,7 +103,9 @@ int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C,
  *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);
  *                equals the reference up to fp32 re-association of the bilinear weights.
  *   1          : the reference's operation order (roi_align_rotated.py:L70-118) -- bit-identical to the
- *                CPU oracle; used by the parity tests. */
+ *                CPU oracle; used by the parity tests.
+ *   2          : mode 0's arithmetic through the channel-sliced kernels of jdet_roi_align_forward_cl where they apply
+ *                (bit-equal to mode 0; measured slower at the north-star point, profiles/r04_roi_fwd_notes.md). */
 int jdet_set_roi_forward_mode(int mode);
 
 /* XCD-aware spatial schedule for the RoIAlign kernels (no reference counterpart: the reference

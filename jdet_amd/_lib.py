@@ -23,7 +23,7 @@ SIGNATURES = {
     "jdet_nhwc_to_nchw": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "jdet_roi_align_forward": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
     "jdet_roi_align_forward_cl_roi": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
-    "jdet_roi_align_forward_cl_workspace": (_sz, [_i]),
+    "jdet_roi_align_forward_cl_workspace": (_sz, [_i, _i, _i]),
     "jdet_roi_align_forward_cl": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_cl": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _i, _p]),
     "jdet_roi_align_backward_clean_bytes": (_sz, [_i] * 9),

@@ -108,7 +108,7 @@ void conv3x3_igemm_kernel(ConvArgs a) {
       py[p] = rem / a.W;
       px[p] = rem - py[p] * a.W;
     }
-    wv[p] = n0 + row < a.Cout ? (unsigned)(((n0 + row) * 9 * a.Cin + lchunk * 4) * 4) : kOob;
+    wv[p] = n0 + row < a.Cout ? ((unsigned)((n0 + row) * 9 * a.Cin + lchunk * 4)) * 4u : kOob;
     st_off[p] = swz_bytes<BK>(row, lchunk);
   }
   const int all_steps = 9 * (a.Cin / BK);   // (host: BK = 32 only when Cin % 32 == 0)
@@ -132,7 +132,7 @@ void conv3x3_igemm_kernel(ConvArgs a) {
       if (!DEFORM) {
         const int yy = py[p] + r - 1, xx = px[p] + s - 1;
         if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-          av[p][0] = (unsigned)((((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4) * 4);
+          av[p][0] = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;   // element index < 2^30: the byte offset is formed unsigned
       } else {
         // dcn_v1.py:L132-166 (deformable_im2col): h_im = h_in + i*dil + offset_h, zero outside (-1, H) x (-1, W),
         // corners outside the image contribute 0 (dmcn_im2col_bilinear L25-56)
@@ -148,7 +148,7 @@ void conv3x3_igemm_kernel(ConvArgs a) {
           for (int k = 0; k < 4; k++) {
             aw[p][k] = wt[k];
             if (cy[k] >= 0 && cy[k] < a.H && cx[k] >= 0 && cx[k] < a.W)
-              av[p][k] = (unsigned)((((img[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin + lchunk * 4) * 4);
+              av[p][k] = ((unsigned)(((img[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin + lchunk * 4)) * 4u;
           }
         }
       }
@@ -370,6 +370,8 @@ JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W
   if (tile == 0 && !big) {
     const int ks = ksplit_for(M, Cin, Cout, offset != nullptr);
     if (ks > 1 && workspace && workspace_bytes >= sizeof(float) * (size_t)ks * M * Cout) {
+      // the finish kernel moves float4s: y, bias and the scratch must be 16-byte aligned as well (views at odd offsets)
+      if ((((uintptr_t)y_nhwc) | ((uintptr_t)bias) | ((uintptr_t)workspace)) & 15 || Cout % 4 != 0) goto unsplit;
       a.partial = (float*)workspace;
       a.ksplit = ks;
       int e = k32 ? launch<64, 32, 1>(a, st) : launch<64, 16, 1>(a, st);
@@ -382,6 +384,7 @@ JDET_API int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W
       return jdet_launch_status();
     }
   }
+unsplit:
   if (big) return k32 ? (split ? launch<128, 32, 2>(a, st) : launch<128, 32, 1>(a, st)) : launch<128, 16, 1>(a, st);
   return k32 ? (split ? launch<64, 32, 2>(a, st) : launch<64, 32, 1>(a, st)) : launch<64, 16, 1>(a, st);
 }

@@ -869,7 +869,8 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// 0 = merged taps (default), 1 = reference operation order (bit-identical to the CPU oracle)
+// 0 = merged taps (default), 1 = reference operation order (bit-identical to the CPU oracle),
+// 2 = merged taps through the channel-sliced kernels where they apply (roi_align_sliced.h; measured, not default)
 int g_fwd_reference_order = 0;
 
 template <int VARIANT>
@@ -885,7 +886,7 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
   if (VARIANT == JDET_ROI_RIROI && big_ok && (nO == 4 || nO == 8)) {
     // orientation planes mixed in registers.  Default: merged-tap kernel + one mix per bin; reference-order mode
     // (or sampling other than 2x2): the per-sample kernel, bit-identical to the scalar one.
-    const bool merged = sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && (out_cl || lds >= 8 * 2048);
+    const bool merged = sample_num == 2 && g_fwd_reference_order != 1 && nbins <= 64 && (out_cl || lds >= 8 * 2048);
     const size_t lds_m = out_cl ? 8 * 2048 : lds, lds_v = out_cl ? 16 : lds;
 #define JDET_RI(NO_)                                                                                              \
   do {                                                                                                            \
@@ -911,7 +912,7 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
     if (!vec) return JDET_E_UNSUPPORTED;
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     // (the merged kernel keeps its per-wave tap lists in the first 2 KiB / wave of the dynamic LDS block)
-    if (sample_num == 2 && !g_fwd_reference_order && nbins <= 64) {
+    if (sample_num == 2 && g_fwd_reference_order != 1 && nbins <= 64) {
       // The LDS request caps the workgroups per CU at 4 (36 KiB each; the tap lists need 16): one workgroup fewer
       // in flight per CU leaves the time where it is (59.4 vs 60.9 us at the north-star point) and cuts the reads
       // beyond the L2 by 14 % (1.34 M vs 1.55 M 128-byte requests, profiles/r03_roi_pool_notes.md) -- fewer RoIs
@@ -926,7 +927,7 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
                          W, PH, PW, scale, sample_num, order);
     return jdet_launch_status();
   }
-  if (vec && sample_num == 2 && !g_fwd_reference_order && nbins <= 64 && lds >= 8 * 2048) {
+  if (vec && sample_num == 2 && g_fwd_reference_order != 1 && nbins <= 64 && lds >= 8 * 2048) {
     constexpr int V = VARIANT == JDET_ROI_RIROI ? JDET_ROI_ROTATED : VARIANT;
     static const int nw = env_int("JDET_ROI_FWD_WAVES", 4);
     static const int abl = env_int("JDET_ROI_ABLATE", 0);  // profiling builds only
@@ -1002,8 +1003,10 @@ int launch_bwd(const float* gout, const float* rois, float* gin, int R, int C, i
 
 // ---- channel-sliced forward (roi_align_sliced.h) ----
 bool sliced_ok(int variant, int R, int N, int C, int H, int W, int PH, int PW, int sample_num, int nO) {
-  static const int legacy = env_int("JDET_ROI_FWD_LEGACY", 0);   // profiling: the RoI-stationary kernels of rounds 1-3
-  if (legacy || g_fwd_reference_order || sample_num != 2) return false;
+  // jdet_set_roi_forward_mode(2) (or JDET_ROI_FWD_SLICED=1 for profiling runs) selects the channel-sliced kernels.
+  // They are NOT the default: measured slower than the RoI-stationary kernels (profiles/r04_roi_fwd_notes.md).
+  static const int sliced_env = env_int("JDET_ROI_FWD_SLICED", 0);
+  if (!(g_fwd_reference_order == 2 || (sliced_env && g_fwd_reference_order == 0)) || sample_num != 2) return false;
   const long nbins = (long)PH * PW;
   if (nbins < jdet_roi_sliced::kItemsPerWave || C % jdet_roi_sliced::kSliceC != 0) return false;
   if ((size_t)N * H * W * C * 4 >= (1ull << 31) || (long)R * nbins >= (1L << 30)) return false;
@@ -1015,26 +1018,35 @@ template <int VARIANT, int NO>
 int launch_sliced(const float* feat, const float* rois, float* out, int R, int N, int C, int H, int W, int PH, int PW,
                   float scale, int nO, void* ws, hipStream_t st) {
   using namespace jdet_roi_sliced;
-  int* hdr = (int*)ws;
-  RoiRec* recs = (RoiRec*)((char*)ws + kHdrBytes);
-  hipLaunchKernelGGL((roi_prep_kernel<VARIANT>), dim3(1), dim3(kPrepThreads), 0, st, rois, R, scale, N, H, W, PH, PW,
-                     nO, hdr, recs);
+  const int nbins = PH * PW;
+  const PlanWs w = plan_carve(ws, R, nbins);
+  // EXPERIMENT (profiling): JDET_ROI_SLICED_PLANAR=1 reads `feat` as [slice][pixel][32 channels] (every slice one
+  // contiguous plane) instead of NHWC -- the caller must pass a map permuted that way
+  static const int planar = env_int("JDET_ROI_SLICED_PLANAR", 0);
+  const int pix_bytes = planar ? kSliceC * 4 : C * 4;
+  const unsigned slice_stride = planar ? (unsigned)((size_t)N * H * W * kSliceC * 4) : (unsigned)(kSliceC * 4);
+  hipLaunchKernelGGL((roi_sort_plan_kernel<VARIANT>), dim3(1 + (R + 3) / 4), dim3(1024), 0, st, rois, R, scale, N,
+                     pix_bytes, H, W, PH, PW, nO, w.hdr, w.order, w.rrec, w.ent);
   const int nslices = C / kSliceC;
-  const long items = (long)R * PH * PW;
-  const unsigned blocks = (unsigned)(nslices * ((items + 4 * kItemsPerWave - 1) / (4 * kItemsPerWave)));
-#define JDET_SL(B_, S_)                                                                                          \
-  hipLaunchKernelGGL((roi_align_fwd_sliced_kernel<VARIANT, NO, B_, S_>), dim3(blocks), dim3(256), 0, st, feat, hdr, \
-                     recs, out, R, N, C, H, W, PH, PW, nslices)
-  if constexpr (VARIANT == JDET_ROI_ROTATED && NO == 0) {   // tuning knobs (profiling runs) on the benchmarked dialect only
-    static const int batch = env_int("JDET_ROI_SLICED_BATCH", 8), store = env_int("JDET_ROI_SLICED_STORE", 0);
-    if (batch == 4 && store == 0) JDET_SL(4, 0);
-    else if (batch == 16 && store == 0) JDET_SL(16, 0);
-    else if (batch == 8 && store == 1) JDET_SL(8, 1);
-    else if (batch == 8 && store == 2) JDET_SL(8, 2);
-    else if (batch == 16 && store == 1) JDET_SL(16, 1);
-    else JDET_SL(8, 0);
+  const long items = (long)R * nbins;
+#define JDET_SL(B_, P_, NW_)                                                                                          \
+  hipLaunchKernelGGL((roi_pool_sliced_kernel<NO, B_, P_, NW_>),                                                       \
+                     dim3((unsigned)(nslices * ((items + NW_ * kItemsPerWave - 1) / (NW_ * kItemsPerWave)))),         \
+                     dim3(NW_ * 64), 0, st, feat, w.order, w.rrec, w.ent, out, R, N, C, H * W, nbins, nslices, slice_stride)
+  if constexpr (NO == 0) {   // tuning knobs (profiling runs)
+    static const int batch = env_int("JDET_ROI_SLICED_BATCH", 8), pred = env_int("JDET_ROI_SLICED_PRED", 0),
+                     nw = env_int("JDET_ROI_SLICED_WAVES", 4);
+    if (nw == 16 && batch == 4 && pred == 1) JDET_SL(4, 1, 16);
+    else if (nw == 16) JDET_SL(8, 0, 16);
+    else if (nw == 8 && batch == 4 && pred == 1) JDET_SL(4, 1, 8);
+    else if (nw == 1 && batch == 4 && pred == 1) JDET_SL(4, 1, 1);
+    else if (batch == 4 && pred == 0) JDET_SL(4, 0, 4);
+    else if (batch == 16 && pred == 0) JDET_SL(16, 0, 4);
+    else if (batch == 4 && pred == 1) JDET_SL(4, 1, 4);
+    else if (batch == 8 && pred == 1) JDET_SL(8, 1, 4);
+    else JDET_SL(8, 0, 4);
   } else {
-    JDET_SL(8, 0);
+    JDET_SL(8, 0, 4);
   }
 #undef JDET_SL
   return jdet_launch_status();
@@ -1067,7 +1079,7 @@ JDET_API int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float
 
 JDET_API int jdet_set_roi_forward_mode(int mode) {
   const int prev = g_fwd_reference_order;
-  if (mode == 0 || mode == 1) g_fwd_reference_order = mode;
+  if (mode == 0 || mode == 1 || mode == 2) g_fwd_reference_order = mode;
   return prev;
 }
 
@@ -1133,8 +1145,9 @@ JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N
 // Product forward with a channels-last result: the channel-sliced kernels (roi_align_sliced.h) where they apply
 // (sampling 2, PH*PW >= 16, C % 32 == 0, default arithmetic mode), otherwise the RoI-stationary kernels above under the
 // XCD-aware spatial order.  The schedule / per-RoI records live in the caller's workspace.
-JDET_API size_t jdet_roi_align_forward_cl_workspace(int R) {
-  return (size_t)jdet_roi_sliced::kHdrBytes + sizeof(jdet_roi_sliced::RoiRec) * (size_t)(R > 0 ? R : 1);
+JDET_API size_t jdet_roi_align_forward_cl_workspace(int R, int PH, int PW) {
+  if (R <= 0 || PH <= 0 || PW <= 0) return 256;
+  return jdet_roi_sliced::plan_carve(nullptr, R, (long)PH * PW).bytes;
 }
 
 JDET_API int jdet_roi_align_forward_cl(int variant, const float* feat, int N, int C, int H, int W, const float* rois,
@@ -1145,7 +1158,7 @@ JDET_API int jdet_roi_align_forward_cl(int variant, const float* feat, int N, in
   if (C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
   if (variant == JDET_ROI_RIROI && n_orient != 4 && n_orient != 8) return JDET_E_UNSUPPORTED;
   if (R == 0) return JDET_OK;
-  if (!workspace || workspace_bytes < jdet_roi_align_forward_cl_workspace(R)) return JDET_E_WORKSPACE;
+  if (!workspace || workspace_bytes < jdet_roi_align_forward_cl_workspace(R, PH, PW)) return JDET_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   if (sliced_ok(variant, R, N, C, H, W, PH, PW, sample_num, n_orient)) {
     switch (variant) {

@@ -44,7 +44,23 @@ def collate_batch(batch):
     Samples left un-normalised for the device (`Normalize(on_device=True)`: uint8 (h,w,3)) are collated as
     (N,Hmax,Wmax,3) uint8; each target then carries its image's extent in the canvas (`canvas_hw`)."""
     images, targets = zip(*batch)
-    if images[0].dtype == np.uint8 and images[0].ndim == 3 and images[0].shape[-1] == 3:
+    u8 = [im.dtype == np.uint8 and im.ndim == 3 and im.shape[-1] == 3 for im in images]
+    if any(u8) and not all(u8):
+        # a batch that mixes device-normalised (uint8 HWC) and host-normalised (float CHW) samples -- `Normalize(
+        # on_device=True)` falls back per sample when an earlier transform left floats: finish the uint8 ones on the
+        # host, so that the batch has ONE layout (deciding it from images[0] would collate the others wrongly)
+        images, targets = list(images), [dict(t) for t in targets]
+        for i, im in enumerate(images):
+            if u8[i]:
+                t = targets[i]
+                arr = im.transpose((2, 0, 1)).astype(np.float32)
+                if t.get("to_bgr"):
+                    arr = arr[::-1]
+                images[i] = ((arr - np.asarray(t["mean"], np.float32).reshape(-1, 1, 1)) /
+                             np.asarray(t["std"], np.float32).reshape(-1, 1, 1)).astype(np.float32)
+                t.pop("normalize_on_device", None)
+        u8 = [False] * len(images)
+    if all(u8):
         hmax = max(im.shape[0] for im in images)
         wmax = max(im.shape[1] for im in images)
         out = np.zeros((len(images), hmax, wmax, 3), dtype=np.uint8)

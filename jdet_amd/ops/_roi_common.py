@@ -66,7 +66,13 @@ _BWD_WS_MAX = 16   # (device, stream, map size) triples kept: an FPN has 4-5 map
 def _kept_backward_workspace(dev, map_shape, nbytes):
     """Workspace of the channels-last backward, kept per (device, stream, map size): zero-filled once; the call hands
     its counters back zeroed (`workspace_clean` contract of jdet_roi_align_backward_cl), so no memset launch per
-    step.  One buffer per map size: the zeroed region's length depends on it."""
+    step.  One buffer per map size: the zeroed region's length depends on it.
+    Under HIP-graph capture nothing is kept: the buffer is allocated (and zero-filled by a captured kernel) per call
+    from the capturing graph's own pool, so its address lives exactly as long as the graph that baked it in -- a
+    cache entry created during one capture could otherwise be evicted (or re-used by the next capture on the same
+    capture stream) while replays of the first graph still write to it."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((nbytes,), dtype=torch.uint8, device=dev), None
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tuple(map_shape))
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -96,7 +102,8 @@ def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_o
                                                        ws.numel(), 1, L.stream_ptr(g_out)),
                     "jdet_roi_align_backward_cl")
         except Exception:
-            _BWD_WS.pop(key, None)      # state unknown after a failed call: start from a fresh zeroed buffer
+            if key is not None:
+                _BWD_WS.pop(key, None)      # state unknown after a failed call: start from a fresh zeroed buffer
             raise
         return grad_in
     ws = torch.empty((wsb,), dtype=torch.uint8, device=g_out.device) if wsb else None
@@ -124,7 +131,7 @@ def forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num, n_
     R = rois_c.shape[0]
     if R == 0:
         return
-    wsb = L.lib().jdet_roi_align_forward_cl_workspace(R)
+    wsb = L.lib().jdet_roi_align_forward_cl_workspace(R, PH, PW)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
     L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
                                               spatial_scale, sample_num, n_orient, L.ptr(out), L.ptr(ws), wsb,

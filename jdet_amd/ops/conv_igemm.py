@@ -122,12 +122,17 @@ def bias_act_backward(g, y, relu):
     gn = L.f32c(g.permute(0, 2, 3, 1))
     P = N * H * W
     nbytes = L.lib().jdet_frozen_bn_act_backward_workspace(P, C)
-    key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
-    ws = _BWD_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        if len(_BWD_WS) >= 8:          # streams come and go (graph captures): keep the scratch cache bounded
-            _BWD_WS.clear()
-        ws = _BWD_WS[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=g.device)
+    if torch.cuda.is_current_stream_capturing():
+        # the address is baked into the graph: scratch from the capturing graph's own pool, never from (or into) the
+        # cache -- an evicted cache entry would leave replays writing partial sums to freed memory
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=g.device)
+    else:
+        key = (g.device.index, torch.cuda.current_stream(g.device).cuda_stream)
+        ws = _BWD_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            while len(_BWD_WS) >= 8:       # streams come and go: keep the scratch cache bounded (oldest entry out)
+                _BWD_WS.pop(next(iter(_BWD_WS)))
+            ws = _BWD_WS[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=g.device)
     gb = torch.empty((C,), dtype=torch.float32, device=g.device)
     gp = torch.empty_like(gn) if relu else gn
     yn = L.f32c(y.permute(0, 2, 3, 1)) if relu else None

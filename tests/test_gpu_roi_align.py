@@ -284,11 +284,15 @@ def _fwd_cl_both(variant, x, rois, hw, scale, nO, rois_legacy=None):
     for sliced in (True, False):
         out = torch.full((R, C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
         if sliced:
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R)
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R, hw[0], hw[1])
             ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
-            L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0], hw[1],
-                                                  scale, 2, nO, out.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(x)),
-                    "fwd_cl")
+            prev = lib.jdet_set_roi_forward_mode(2)        # the channel-sliced kernels (not the default path)
+            try:
+                L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0],
+                                                      hw[1], scale, 2, nO, out.data_ptr(), ws.data_ptr(), wsb,
+                                                      L.stream_ptr(x)), "fwd_cl")
+            finally:
+                lib.jdet_set_roi_forward_mode(prev)
         else:
             L.check(lib.jdet_roi_align_forward_cl_roi(variant, x.data_ptr(), N, C, H, W, rois_legacy.data_ptr(), R, hw[0],
                                                       hw[1], scale, 2, nO, None, out.data_ptr(), L.stream_ptr(x)),
@@ -302,7 +306,7 @@ def _fwd_cl_both(variant, x, rois, hw, scale, nO, rois_legacy=None):
                                           (O.V_HBB1, 1, 128), (O.V_RI, 8, 64), (O.V_RI, 4, 32)])
 @pytest.mark.parametrize("hw", [(7, 7), (4, 4), (5, 9)])
 def test_sliced_forward_equals_roi_stationary_kernels(dev, variant, nO, C, hw):
-    """jdet_roi_align_forward_cl (channel-sliced: Morton-sorted records + 8-lane groups per item) runs the same
+    """jdet_roi_align_forward_cl in forward mode 2 (channel-sliced: plan + 8-lane groups per item) runs the same
     geometry functions, the same tap merge and the same fma chain as the RoI-stationary merged-tap kernel: bit-equal.
     Covers several images, masked RoIs (negative batch index: rows untouched), RoIs hanging over the map border, a RoI
     of an image that does not exist (zeros), R not a multiple of anything, slices counts 1 / 2 / 3 / 4 / 8."""
