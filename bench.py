@@ -54,7 +54,7 @@ def make_inputs(workload, R, seed, dev):
     from tests import inputs as I
     rng = np.random.default_rng(seed)
     d = {}
-    if workload.startswith("roi_align"):
+    if workload.startswith("roi_align") or workload == "riroi_align":
         g = torch.Generator(device="cpu").manual_seed(seed)
         feat = torch.randn((1, 256, 256, 256), generator=g)
         d["feat_np"] = None
@@ -147,6 +147,22 @@ def make_step(workload, d):
         d["out"] = out
         return (step, nbytes / 1e9, "GB", nbytes, "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,(R,C,7,7) out>",
                 "f32")
+    if workload == "riroi_align":
+        # RiRoIAlign forward (riroi_align.py:L70-173) at the north-star shape: 256 planes = 32 channels x 8 orientations
+        feat, rois = d["feat"], d["rois"]
+        R = rois.shape[0]
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
+        wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+        fp, rp, op, wp = feat.data_ptr(), rois.data_ptr(), out.data_ptr(), ws.data_ptr()
+
+        def step():
+            L.check(lib.jdet_roi_align_forward_cl(2, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 8, op, wp, wsb,
+                                                  L.stream_ptr(feat)), "riroi_fwd_cl")
+        d["out"] = out
+        return (step, nbytes / 1e9, "GB", nbytes,
+                "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out,nO=8>", "f32")
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]

@@ -94,6 +94,38 @@ __device__ __forceinline__ void ri_dispatch(float (&acc)[4], const float (&val)[
   }
 }
 
+// The same mix with `ind` as a run-time value (wave-uniform or per lane), for the kernels that mix ONCE per finished bin:
+// every plane lookup is a 4-way select on (index & 3) plus, for nO == 8, a select between the lane's own registers and
+// its pair lane's (the two lanes of a pair hold planes 0-3 / 4-7 of a group).  No register arrays indexed at run time:
+// the switch of ri_dispatch above costs 8 template instances whose plane arrays end up in scratch (RiRoIAlign ran
+// 92 us against 59 us for the plain dialect at the north-star point).
+__device__ __forceinline__ float ri_sel4(const float (&v)[4], int i) {
+  const float lo = (i & 1) ? v[1] : v[0], hi = (i & 1) ? v[3] : v[2];
+  return (i & 2) ? hi : lo;
+}
+
+template <int NO>
+__device__ __forceinline__ void ri_mix(float (&out)[4], const float (&val)[4], int lane, int ind, float r_var,
+                                       float l_var) {
+  if (NO == 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      out[k] = 0.f + (r_var * ri_sel4(val, (k - ind) & 3) + l_var * ri_sel4(val, (k - ind + 1) & 3));
+  } else {
+    const int odd = lane & 1;
+    float other[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) other[k] = __shfl_xor(val[k], 1, 64);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {          // this lane's output plane o = 4 * odd + k; source planes (o - ind), (o - ind + 1) mod 8
+      const int ta = (4 * odd + k - ind) & 7, tb = (4 * odd + k - ind + 1) & 7;
+      const float va = ((ta >> 2) == odd) ? ri_sel4(val, ta & 3) : ri_sel4(other, ta & 3);
+      const float vb = ((tb >> 2) == odd) ? ri_sel4(val, tb & 3) : ri_sel4(other, tb & 3);
+      out[k] = 0.f + (r_var * va + l_var * vb);
+    }
+  }
+}
+
 // one sample into the lane's 4 accumulators; NO == 0: plain RoIAlign, NO == 4 / 8: RiRoIAlign with that many planes
 template <int NO>
 __device__ __forceinline__ void acc_sample(float (&acc)[4], const RoiGeom& g, int lane, float w1, float w2, float w3,
@@ -440,8 +472,8 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
       }
     if constexpr (NO != 0) {
       const float val[4] = {acc.x, acc.y, acc.z, acc.w};
-      float mixed[4] = {0.f, 0.f, 0.f, 0.f};
-      ri_dispatch<NO>(mixed, val, lane, ri_ind, ri_r, ri_l);
+      float mixed[4];
+      ri_mix<NO>(mixed, val, lane, ri_ind, ri_r, ri_l);
       acc = v4f{mixed[0], mixed[1], mixed[2], mixed[3]};
     }
     if (lane_ok) {

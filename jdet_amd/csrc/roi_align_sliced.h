@@ -23,7 +23,7 @@
 //                          per tap per group), every group walks ITS item's list, BATCH loads in flight; one 128-byte
 //                          store per group into the channels-last row.
 // The plan costs 8 B per merged tap (7 MB at the north-star point), read once per XCD.
-// (Included by roi_align.hip inside its unnamed namespace, after ri_dispatch<>.)
+// (Included by roi_align.hip inside its unnamed namespace, after ri_mix<>.)
 #pragma once
 #include "roi_geom.h"
 
@@ -367,9 +367,8 @@ __global__ __launch_bounds__(NW * 64) void roi_pool_sliced_kernel(
     if constexpr (NO != 0) {
       const float4 rr = rrec[it_ok ? r : rA];
       const float val[4] = {acc.x, acc.y, acc.z, acc.w};
-      float mixed[4] = {0.f, 0.f, 0.f, 0.f};
-      // per-group orientation constants: the switch on `ind` diverges between the (<= 2) RoIs of a wave at most
-      ri_dispatch<NO>(mixed, val, lane, __float_as_int(rr.x), rr.z, rr.y);
+      float mixed[4];
+      ri_mix<NO>(mixed, val, lane, __float_as_int(rr.x), rr.z, rr.y);     // per-group orientation constants
       acc = v4f{mixed[0], mixed[1], mixed[2], mixed[3]};
     }
     if (it_ok)
