@@ -364,11 +364,13 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
 
 // counts[] hold the row lengths, segment g of recs its seg_n[g] kept taps, counts[nkeys] (ticket) is zero.
 // On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
+// scan == false: the producer has scanned the counters itself (offsets[] global, tile_base[] zero, [ntiles] = total)
 inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
-                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
+                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st, bool scan = true) {
   const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
-                     w.tile_sum, w.tile_base, w.counts + nkeys);
+  if (scan)
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
+                       w.tile_sum, w.tile_base, w.counts + nkeys);
   hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
                      w.offsets, w.tile_base, w.entries);
   const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
@@ -379,169 +381,5 @@ inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, lon
   return jdet_launch_status();
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// 4 x 4 pixel patches (round 4).  Entry counts at the RoIAlign bench (2000 RoIs, 7 x 7 x 4 samples, 256 x 256 map):
-// (bin, pixel) 881 k, (bin, 2x2 patch) 425 k, (bin, 4x4 patch) 241 k -- every entry is one 1 KiB source-row load in the
-// gather, and the gather follows its L1 accesses / L2 requests (profiles/r04_roi_fwd_notes.md), so the wider patch
-// nearly halves it.  An entry carries the 16 weights of the patch's pixels; the gather wave owns one patch
-// (16 accumulators x 4 channels per lane) and its entries are WAVE-UNIFORM, so they arrive through scalar loads and
-// feed the fmas as SGPR operands -- no readlane traffic.
-// ---------------------------------------------------------------------------------------------------------------
-struct Rec4 {        // producer record: 80 bytes
-  int key, pos, src, pad;
-  float w[16];
-};
-static_assert(sizeof(Rec4) == 80, "five 16-byte chunks");
-
-struct Patch4Ws {
-  int* counts;      // nkeys row counters, [nkeys] = scan ticket
-  int* offsets;
-  int* tile_sum;
-  int* tile_base;
-  int* seg_n;       // records per producer segment
-  Rec4* recs;
-  int* esrc;        // gather entries, structure of arrays: source row ...
-  float* ew;        // ... and the 16 weights (64-byte aligned: one s_load_dwordx16 per entry)
-  size_t bytes;
-};
-
-inline Patch4Ws patch4_carve(void* ws, long nkeys, long nsegs, long seg_cap) {
-  const long max_recs = nsegs * seg_cap;
-  Patch4Ws w;
-  char* p = (char*)ws;
-  size_t off = 0;
-  const long ntiles = (nkeys + kScanTile - 1) / kScanTile;
-  w.counts = (int*)(p + off);    off += align256(sizeof(int) * (nkeys + 1));
-  w.offsets = (int*)(p + off);   off += align256(sizeof(int) * (nkeys + 1));
-  w.tile_sum = (int*)(p + off);  off += align256(sizeof(int) * (ntiles + 1));
-  w.tile_base = (int*)(p + off); off += align256(sizeof(int) * (ntiles + 1));
-  w.seg_n = (int*)(p + off);     off += align256(sizeof(int) * nsegs);
-  w.recs = (Rec4*)(p + off);     off += align256(sizeof(Rec4) * max_recs);
-  w.esrc = (int*)(p + off);      off += align256(sizeof(int) * (max_recs + 64));
-  w.ew = (float*)(p + off);      off += align256(sizeof(float) * 16 * max_recs);
-  w.bytes = off;
-  return w;
-}
-
-static __global__ __launch_bounds__(256) void csr_fill_patch4_kernel(const Rec4* __restrict__ recs,
-                                                                     const int* __restrict__ seg_n, int seg_cap,
-                                                                     const int* __restrict__ offsets,
-                                                                     const int* __restrict__ tile_base,
-                                                                     int* __restrict__ esrc, float* __restrict__ ew) {
-  const int n = seg_n[blockIdx.x];
-  const Rec4* __restrict__ seg = recs + (size_t)blockIdx.x * seg_cap;
-  // 4 threads per record: each moves one 16-byte chunk of the weights; chunk 0's thread also stores the source row
-  for (int t = threadIdx.x; t < n * 4; t += 256) {
-    const int e = t >> 2, c = t & 3;
-    const int4 head = reinterpret_cast<const int4*>(seg + e)[0];        // key, pos, src
-    const int dst = row_begin(offsets, tile_base, head.x) + head.y;
-    reinterpret_cast<int4*>(ew + (size_t)dst * 16)[c] = reinterpret_cast<const int4*>(seg + e)[1 + c];
-    if (c == 0) esrc[dst] = head.z;
-  }
-}
-
-// One wave per 4 x 4 patch; lane owns 4 consecutive channels of a 256-channel chunk; 16 accumulators.
-// Workgroup = 2 x 2 patches (an 8 x 8 pixel tile); stripes of 4 tile rows (32 pixel rows) go round-robin to the XCDs.
-// keys = images x ceil(img_h/4) x ceil(img_w/4).  Source rows of 64 entries arrive in one coalesced load and are
-// handed round by readlane; UNROLL row loads are issued back to back; the weights of an entry are wave-uniform: one
-// scalar load of 64 bytes, used by the fmas as SGPR operands.
-template <int UNROLL>
-static __global__ __launch_bounds__(256) void csr_gather_patch4_kernel(const float* __restrict__ gT,
-                                                               const int* __restrict__ offsets,
-                                                               const int* __restrict__ tile_base, int ntiles,
-                                                               const int* __restrict__ esrc,
-                                                               const float* __restrict__ ew, int nkeys,
-                                                               int C, int n_img, int img_h, int img_w,
-                                                               int* __restrict__ counts, float* __restrict__ grad_in) {
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int php = (img_h + 3) >> 2, pwp = (img_w + 3) >> 2;
-  const int bw = (pwp + 1) >> 1;                               // workgroups per row of patches
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int stripe = xcd + 8 * (j / (4 * bw));                 // 4 workgroup rows = 8 patch rows per stripe
-  const int local = j % (4 * bw);
-  const int prow = __builtin_amdgcn_readfirstlane((stripe * 4 + local / bw) * 2 + (wave >> 1));   // over all images stacked
-  const int pcol = __builtin_amdgcn_readfirstlane((local % bw) * 2 + (wave & 1));
-  if (prow >= n_img * php || pcol >= pwp) return;
-  const int p = prow * pwp + pcol;
-  const int img = prow / php, py = prow - img * php;
-  const int beg = __builtin_amdgcn_readfirstlane(row_begin(offsets, tile_base, p));
-  const int end = __builtin_amdgcn_readfirstlane(p + 1 < nkeys ? row_begin(offsets, tile_base, p + 1)
-                                                               : tile_base[ntiles]);
-  if (lane == 0) counts[p] = 0;
-  const int y0 = py * 4, x0 = pcol * 4;
-  float* __restrict__ out0 = grad_in + ((size_t)(img * img_h + y0) * img_w + x0) * C;
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + lane * 4;
-    const bool ok = c < C;                       // C % 4 == 0 on this path
-    const float* __restrict__ col = gT + (ok ? c : 0);
-    v4f acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = v4f{0.f, 0.f, 0.f, 0.f};
-    for (int base = beg; base < end; base += 64) {
-      const int n = min(64, end - base);
-      const int my_src = esrc[base + (lane < n ? lane : 0)];
-      int i = 0;
-      for (; i + UNROLL <= n; i += UNROLL) {
-        v4f v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++)
-          v[u] = *reinterpret_cast<const v4f*>(col + (size_t)__builtin_amdgcn_readlane(my_src, i + u) * C);
-        // all UNROLL row loads are in flight before the first is consumed (left alone, the scheduler issues them one
-        // at a time, each behind a full wait)
-        static_assert(UNROLL == 4, "the fence below names four rows");
-        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          const float* __restrict__ w = ew + (size_t)(base + i + u) * 16;      // wave-uniform: scalar loads
-#pragma unroll
-          for (int q = 0; q < 16; q++) {
-            const float wq = w[q];
-            acc[q].x = __builtin_fmaf(wq, v[u].x, acc[q].x);
-            acc[q].y = __builtin_fmaf(wq, v[u].y, acc[q].y);
-            acc[q].z = __builtin_fmaf(wq, v[u].z, acc[q].z);
-            acc[q].w = __builtin_fmaf(wq, v[u].w, acc[q].w);
-          }
-        }
-      }
-      for (; i < n; i++) {
-        const v4f v = *reinterpret_cast<const v4f*>(col + (size_t)__builtin_amdgcn_readlane(my_src, i) * C);
-        const float* __restrict__ w = ew + (size_t)(base + i) * 16;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-          const float wq = w[q];
-          acc[q].x = __builtin_fmaf(wq, v.x, acc[q].x);
-          acc[q].y = __builtin_fmaf(wq, v.y, acc[q].y);
-          acc[q].z = __builtin_fmaf(wq, v.z, acc[q].z);
-          acc[q].w = __builtin_fmaf(wq, v.w, acc[q].w);
-        }
-      }
-    }
-    if (ok) {
-#pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int dy = q >> 2, dx = q & 3;
-        if (y0 + dy < img_h && x0 + dx < img_w)
-          *reinterpret_cast<v4f*>(out0 + ((size_t)dy * img_w + dx) * C + c) = acc[q];
-      }
-    }
-  }
-}
-
-inline int patch4_finish_and_gather(const Patch4Ws& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
-                                    float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
-  const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
-  hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
-                     w.tile_sum, w.tile_base, w.counts + nkeys);
-  hipLaunchKernelGGL(csr_fill_patch4_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
-                     w.offsets, w.tile_base, w.esrc, w.ew);
-  const int php = (img_h + 3) / 4, pwp = (img_w + 3) / 4, bw = (pwp + 1) / 2;
-  const int wg_rows = (n_img * php + 1) / 2, stripes = (wg_rows + 3) / 4;
-  const unsigned blocks = 8u * (unsigned)((stripes + 7) / 8) * 4u * (unsigned)bw;
-  hipLaunchKernelGGL((csr_gather_patch4_kernel<4>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
-                     ntiles, w.esrc, w.ew, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
-  return jdet_launch_status();
-}
 
 }  // namespace jdet_csr

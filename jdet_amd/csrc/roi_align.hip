@@ -25,6 +25,8 @@
 //     global_atomic_add_f32 into the NHWC gradient (lane-contiguous 256 B per instruction).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "roi_geom.h"
 
 namespace {
@@ -121,6 +123,31 @@ __device__ __forceinline__ void ri_mix(float (&out)[4], const float (&val)[4], i
       const int ta = (4 * odd + k - ind) & 7, tb = (4 * odd + k - ind + 1) & 7;
       const float va = ((ta >> 2) == odd) ? ri_sel4(val, ta & 3) : ri_sel4(other, ta & 3);
       const float vb = ((tb >> 2) == odd) ? ri_sel4(val, tb & 3) : ri_sel4(other, tb & 3);
+      out[k] = 0.f + (r_var * va + l_var * vb);
+    }
+  }
+}
+
+// ... and with `ind` as a template argument (the caller switches on the wave-uniform value ONCE, around its whole bin
+// loop): every plane lookup is a static register pick.  Lane parity drops out: output plane 4 odd + k reads plane
+// (4 odd + t) mod 8 with t = (k - IND) mod 8, i.e. component t & 3 of the lane itself when t < 4, of its pair lane
+// otherwise.
+template <int NO, int IND>
+__device__ __forceinline__ void ri_mix_static(float (&out)[4], const float (&val)[4], float r_var, float l_var) {
+  if (NO == 4) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = 0.f + (r_var * val[(k - IND + 4) & 3] + l_var * val[(k - IND + 5) & 3]);
+  } else {
+    float other[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) other[k] = __shfl_xor(val[k], 1, 64);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int ta = (k - IND + 8) & 7, tb = (k - IND + 9) & 7;
+      const float va = ta < 4 ? val[ta & 3] : other[ta & 3];
+      const float vb = tb < 4 ? val[tb & 3] : other[tb & 3];
       out[k] = 0.f + (r_var * va + l_var * vb);
     }
   }
@@ -446,6 +473,10 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
   auto tap = [&](int soff) -> v4f {
     return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
   };
+  // (RiRoIAlign: the bin loop is instantiated once per orientation shift and entered through one switch on the
+  //  wave-uniform `ind`, so that the mix inside is pure register renaming)
+  auto bins = [&](auto ind_c) {
+  constexpr int IND = decltype(ind_c)::value;
   for (int kb = 0; kb < nb; kb++) {
     const int bin = wave + NW * kb;
     const int l0 = kb * 4;
@@ -473,7 +504,7 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
     if constexpr (NO != 0) {
       const float val[4] = {acc.x, acc.y, acc.z, acc.w};
       float mixed[4];
-      ri_mix<NO>(mixed, val, lane, ri_ind, ri_r, ri_l);
+      ri_mix_static<NO, IND>(mixed, val, ri_r, ri_l);
       acc = v4f{mixed[0], mixed[1], mixed[2], mixed[3]};
     }
     if (lane_ok) {
@@ -485,6 +516,21 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
         s_out[(lane * 4 + 2) * nbins + bin] = acc.z;
         s_out[(lane * 4 + 3) * nbins + bin] = acc.w;
       }
+    }
+  }
+  };
+  if constexpr (NO == 0) {
+    bins(std::integral_constant<int, 0>{});
+  } else {
+    switch (ri_ind) {   // wave-uniform
+      case 0: bins(std::integral_constant<int, 0>{}); break;
+      case 1: bins(std::integral_constant<int, 1>{}); break;
+      case 2: bins(std::integral_constant<int, 2>{}); break;
+      case 3: bins(std::integral_constant<int, 3>{}); break;
+      case 4: bins(std::integral_constant<int, 4 % (NO ? NO : 1)>{}); break;
+      case 5: bins(std::integral_constant<int, 5 % (NO ? NO : 1)>{}); break;
+      case 6: bins(std::integral_constant<int, 6 % (NO ? NO : 1)>{}); break;
+      default: bins(std::integral_constant<int, 7 % (NO ? NO : 1)>{}); break;
     }
   }
   if (OUT_CL) return;

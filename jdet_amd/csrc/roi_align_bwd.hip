@@ -41,14 +41,24 @@ long patch_keys(int N, int H, int W) { return (long)N * ((H + 1) / 2) * ((W + 1)
 // the entries of its bin that share a patch (the 4 samples of a bin are 4 consecutive lanes), counts the survivors in
 // their patch's row (integer atomic, the return value is the place in the row) and writes them, compacted through an
 // LDS counter, into the RoI's own record segment (no global cursor: the fill launch walks the segments).
-template <int VARIANT>
+// Round 4: (i) a lane's (up to four) row-counter atomics are issued back to back and waited for once -- chained, each
+// behind the previous one's record store, they made the kernel a 4-deep latency chain of device-scope round trips
+// (19.9 us); the records of a wave are placed with one LDS atomic per wave (ballot prefix) instead of one per entry.
+// (ii) SCAN_HERE: the workgroup that finishes last (ticket = the row counters' spare word) scans the counters itself
+// -- the separate scan launch (5.8 us + a kernel boundary) disappears for maps of up to 16 Ki patches
+// (JDET_ROI_BWD_FOLD_SCAN=0 keeps the separate launch: A/B).
+constexpr int kFoldedScanMaxKeys = 16384;   // 256 threads x 64 counters
+
+template <int VARIANT, bool SCAN_HERE>
 __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __restrict__ rois, int H, int W, int PH,
                                                             int PW, float spatial_scale, int sample_num,
                                                             TapRec* __restrict__ recs, int* __restrict__ seg_n,
-                                                            int* __restrict__ counts) {
+                                                            int* __restrict__ counts, int nkeys,
+                                                            int* __restrict__ offsets, int* __restrict__ tile_base) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
   __shared__ RoiGeom s_geom;
-  __shared__ int s_n;
+  __shared__ int s_n, s_last;
+  __shared__ int s_scan[4];
   const int r = blockIdx.x;
   if (threadIdx.x == 0) {
     s_geom = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
@@ -117,149 +127,85 @@ __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __rest
     }
     const int src_row = r * nbins + bin;
     TapRec* __restrict__ seg = recs + (size_t)r * S * 4;
+    bool keep[4];
+    int pos[4], mine = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const bool keep = valid && first[k] &&
-                        (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
-      if (keep) {
-        const int pos = atomicAdd(&counts[key[k]], 1);
-        const int local = atomicAdd(&s_n, 1);
-        int4* dst = reinterpret_cast<int4*>(seg + local);
-        dst[0] = make_int4(key[k], pos, src_row, __float_as_int(wv[k][0]));
-        dst[1] = make_int4(__float_as_int(wv[k][1]), __float_as_int(wv[k][2]), __float_as_int(wv[k][3]), 0);
-      }
+      keep[k] = valid && first[k] && (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
+      mine += keep[k] ? 1 : 0;
     }
+    // the row-counter atomics of the lane: independent, all in flight together
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      pos[k] = keep[k] ? __hip_atomic_fetch_add(&counts[key[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    // places in the RoI's segment: exclusive prefix over the wave's lanes, one LDS atomic per wave
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    int wave_base = 0;
+    if (lane == 0 && wave_total > 0) wave_base = atomicAdd(&s_n, wave_total);
+    wave_base = __shfl(wave_base, 0, 64);
+    int local = wave_base + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (keep[k]) {
+        int4* dst = reinterpret_cast<int4*>(seg + local);
+        dst[0] = make_int4(key[k], pos[k], src_row, __float_as_int(wv[k][0]));
+        dst[1] = make_int4(__float_as_int(wv[k][1]), __float_as_int(wv[k][2]), __float_as_int(wv[k][3]), 0);
+        local++;
+      }
   }
   __syncthreads();
   if (threadIdx.x == 0) seg_n[r] = s_n;
-}
+  if (!SCAN_HERE) return;
 
-// ---- 4 x 4 pixel patches (csr_gather.h, round 4) -------------------------------------------------------------------
-long patch4_keys(int N, int H, int W) { return (long)N * ((H + 3) / 4) * ((W + 3) / 4); }
-
-// One workgroup per RoI.  A lane = one (bin, sample), a lane quad = one bin; the 16 taps of a bin fall into a few
-// 4 x 4 patches.  Taps are grouped by patch inside the quad (the group id = the tap index of its first occurrence,
-// found with the quad-shuffle compare pattern of the forward's tap merge); the first tap of a group takes a slot of an
-// LDS table (key, source row, 16 weights), every tap adds its weight into its group's slot (ds_add_f32), and the slots
-// leave as 80-byte records.  One integer atomicAdd per (bin, patch) entry on the patch's row counter, all of a lane's
-// atomics independent of each other (the 2 x 2 kernel above chains up to four returning atomics per lane: 19.7 us).
-// A RoI with more groups than kSlots emits the surplus taps as single-weight entries (correct, just not merged).
-constexpr int kSlots = 448;
-
-template <int VARIANT>
-__global__ __launch_bounds__(256) void bwd_patch4_taps_kernel(const float* __restrict__ rois, int H, int W, int PH,
-                                                             int PW, float spatial_scale, int sample_num,
-                                                             Rec4* __restrict__ recs, int* __restrict__ seg_n,
-                                                             int* __restrict__ counts) {
-  constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
-  __shared__ RoiGeom s_geom;
-  __shared__ int s_nslots, s_nrec;
-  __shared__ __attribute__((aligned(16))) float s_w[kSlots][16];
-  __shared__ int s_key[kSlots], s_src[kSlots];
-  __shared__ unsigned short s_slotmap[64][16];
-  const int r = blockIdx.x;
+  // ---- the last workgroup scans the row counters (exclusive, global) into offsets[]; tile_base[] = 0, [ntiles] = total
+  int* ticket = counts + nkeys;
   if (threadIdx.x == 0) {
-    s_geom = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
-    s_nslots = 0;
-    s_nrec = 0;
+    // No fence: every counter atomic of this workgroup has RETURNED (its value went into a record before the barrier
+    // above), i.e. it is performed at device scope; the records themselves are read by the next launch, not by the
+    // scanning workgroup.  (A release here writes back the XCD's whole L2 once per workgroup: measured 170 us.)
+    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
   }
   __syncthreads();
-  const RoiGeom g = s_geom;
-  const int nbins = PH * PW, S = nbins * 4;       // sample_num == 2 on this path: a lane quad is a bin
-  const int php = (H + 3) >> 2, pwp = (W + 3) >> 2;
-  const int kbase = g.batch * php * pwp;
-  const int lane = threadIdx.x & 63, q = lane & 3, qbase = lane & ~3;
-  const int bin_local = threadIdx.x >> 2;
-  Rec4* __restrict__ seg = recs + (size_t)r * S * 4;
-  constexpr unsigned short kOvf = 0xffff;
-  for (int s0 = 0; s0 < S; s0 += 256) {
-    const bool active = s0 + (int)threadIdx.x < S;
-    const int s = active ? s0 + threadIdx.x : S - 1;
-    const int bin = s >> 2, rr = s & 3;
-    const SamplePos sp = sample_pos<VARIANT>(g, bin / PW, bin % PW, rr >> 1, rr & 1, H, W);
-    const int valid = active && sp.valid && g.batch >= 0;     // batch < 0: masked RoI
-    const float hy = (float)(1. - (double)sp.ly), hx = (float)(1. - (double)sp.lx);   // as make_sample
-    const float w0[4] = {(hy * hx) / g.count, (hy * sp.lx) / g.count, (sp.ly * hx) / g.count,
-                         (sp.ly * sp.lx) / g.count};
-    const int ys[4] = {sp.y_low, sp.y_low, sp.y_high, sp.y_high};
-    const int xs[4] = {sp.x_low, sp.x_high, sp.x_low, sp.x_high};
-    int key[4], pix[4], gid[4];
+  if (!s_last) return;
+  // thread t owns counters [64 t, 64 t + 64): all 64 loads in flight at once (ONE round trip -- chunk by chunk the
+  // scan was 16 dependent device-scope round trips, 35 us), thread-local prefix, one block scan of the thread totals
+  const int wave = threadIdx.x >> 6;
+  const int k0 = 64 * (int)threadIdx.x;
+  int v[64];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      key[k] = valid ? kbase + (ys[k] >> 2) * pwp + (xs[k] >> 2) : -1 - (4 * q + k);   // invalid taps: keys nobody shares
-      pix[k] = (ys[k] & 3) * 4 + (xs[k] & 3);
-      gid[k] = 4 * q + k;
-    }
-    // group id = smallest tap index (4 * sample + tap) of the bin with the same patch
+  for (int i = 0; i < 64; i++)   // other workgroups' atomics: agent-scope loads (served beyond this CU's L1)
+    v[i] = k0 + i < nkeys ? __hip_atomic_load(&counts[k0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  int sum = 0;
 #pragma unroll
-    for (int k = 1; k < 4; k++)
+  for (int i = 0; i < 64; i++) sum += v[i];
+  int inc = sum;
 #pragma unroll
-      for (int j = 0; j < k; j++) gid[k] = key[j] == key[k] ? min(gid[k], gid[j]) : gid[k];
-#pragma unroll
-    for (int d = 1; d < 4; d++) {
-      const int sq = (q + d) & 3, src = qbase | sq;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int ok = __shfl(key[j], src, 64);
-#pragma unroll
-        for (int k = 0; k < 4; k++) gid[k] = ok == key[k] ? min(gid[k], 4 * sq + j) : gid[k];
-      }
-    }
-    // first taps take a slot; the quad's slot map lives in LDS (a wave's LDS operations retire in order)
-    const int src_row = r * nbins + bin;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (valid && gid[k] == 4 * q + k) {
-        const int slot = atomicAdd(&s_nslots, 1);
-        if (slot < kSlots) {
-          float4* z = reinterpret_cast<float4*>(&s_w[slot][0]);
-          z[0] = z[1] = z[2] = z[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          s_key[slot] = key[k];
-          s_src[slot] = src_row;
-        }
-        s_slotmap[bin_local][4 * q + k] = slot < kSlots ? (unsigned short)slot : kOvf;
-      }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (valid) {
-        const unsigned short slot = s_slotmap[bin_local][gid[k]];
-        if (slot != kOvf) {
-          atomicAdd(&s_w[slot][pix[k]], w0[k]);
-        } else if (w0[k] != 0.f) {      // table full: the tap leaves as an entry of its own
-          const int pos = atomicAdd(&counts[key[k]], 1);
-          const int at = kSlots + atomicAdd(&s_nrec, 1);
-          int4* dst = reinterpret_cast<int4*>(seg + at);
-          dst[0] = make_int4(key[k], pos, src_row, 0);
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((pix[k] >> 2) == c) {
-              const int i = pix[k] & 3;
-              v = make_float4(i == 0 ? w0[k] : 0.f, i == 1 ? w0[k] : 0.f, i == 2 ? w0[k] : 0.f, i == 3 ? w0[k] : 0.f);
-            }
-            reinterpret_cast<float4*>(seg + at)[1 + c] = v;
-          }
-        }
-      }
-    __builtin_amdgcn_wave_barrier();   // the slot map rows of this wave are rewritten by the next pass
+  for (int off = 1; off < 64; off <<= 1) {
+    const int u = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += u;
   }
+  if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
-  const int n = min(s_nslots, kSlots), novf = s_nrec;
-  // records [0, n): the table's slots; [kSlots, kSlots + novf): overflow taps.  Pack the overflow down behind the slots.
-  for (int slot = threadIdx.x; slot < n; slot += 256) {
-    const int k = s_key[slot];
-    const int pos = atomicAdd(&counts[k], 1);
-    int4* dst = reinterpret_cast<int4*>(seg + slot);
-    dst[0] = make_int4(k, pos, s_src[slot], 0);
-    const float4* wsrc = reinterpret_cast<const float4*>(&s_w[slot][0]);
+  int base = inc - sum;
+  for (int w = 0; w < wave; w++) base += s_scan[w];
+  const int carry = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
 #pragma unroll
-    for (int c = 0; c < 4; c++) reinterpret_cast<float4*>(seg + slot)[1 + c] = wsrc[c];
+  for (int i = 0; i < 64; i++) {
+    if (k0 + i < nkeys) offsets[k0 + i] = base;
+    base += v[i];
   }
-  if (novf > 0 && n < kSlots) {
-    // (cannot happen: overflow only starts once all kSlots are taken) -- kept for clarity of the layout
+  const int ntiles = (nkeys + kScanTile - 1) / kScanTile;
+  for (int t = threadIdx.x; t < ntiles; t += 256) tile_base[t] = 0;
+  if (threadIdx.x == 0) {
+    tile_base[ntiles] = carry;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this workspace
   }
-  if (threadIdx.x == 0) seg_n[r] = n < kSlots ? n : kSlots + novf;
 }
 
 // (R, C, nbins) -> (R, nbins, C), 32x32 LDS tiles
@@ -313,8 +259,14 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
     int he = jdet_zero_async(w.counts, patch_zero_bytes(nkeys), st);
     if (he) return he;
   }
-  hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
-                     sample_num, w.recs, w.seg_n, w.counts);
+  static const bool fold = [] { const char* v = getenv("JDET_ROI_BWD_FOLD_SCAN"); return !v || atoi(v) != 0; }();
+  const bool scan_here = fold && nkeys <= kFoldedScanMaxKeys;
+  if (scan_here)
+    hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT, true>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
+                       sample_num, w.recs, w.seg_n, w.counts, (int)nkeys, w.offsets, w.tile_base);
+  else
+    hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT, false>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
+                       sample_num, w.recs, w.seg_n, w.counts, (int)nkeys, w.offsets, w.tile_base);
   const float* rows = grad_out;   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
   if (!grad_out_cl) {
     dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
@@ -327,42 +279,7 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
                        rois, n_groups, nbins, C / n_orient, n_orient);
     rows = gT;
   }
-  return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st);
-}
-
-template <int VARIANT>
-int run_gather4(const float* grad_out, const float* rois, int R, int N, int C, int H, int W, int PH, int PW,
-                float scale, int sample_num, float* grad_in, void* ws, bool grad_out_cl, bool ws_clean,
-                hipStream_t st, int n_orient = 0) {
-  const int nbins = PH * PW, spb = sample_num * sample_num;
-  const long nkeys = patch4_keys(N, H, W), seg_cap = (long)nbins * spb * 4;
-  Patch4Ws w = patch4_carve(ws, nkeys, R, seg_cap);
-  float* gT = (float*)((char*)ws + w.bytes);
-  if (!ws_clean) {
-    int he = jdet_zero_async(w.counts, patch_zero_bytes(nkeys), st);
-    if (he) return he;
-  }
-  hipLaunchKernelGGL((bwd_patch4_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
-                     sample_num, w.recs, w.seg_n, w.counts);
-  const float* rows = grad_out;
-  if (!grad_out_cl) {
-    dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
-    hipLaunchKernelGGL(bwd_transpose_kernel, tg, dim3(256), 0, st, grad_out, gT, C, nbins);
-    rows = gT;
-  }
-  if (n_orient > 1) {
-    const long n_groups = (long)R * nbins * (C / n_orient);
-    hipLaunchKernelGGL(riroi_mix_rows_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, rows, gT,
-                       rois, n_groups, nbins, C / n_orient, n_orient);
-    rows = gT;
-  }
-  return patch4_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st);
-}
-
-// 4 x 4 patches where the producer kernel applies (2 x 2 sampling); JDET_ROI_BWD_PATCH=2 keeps the 2 x 2 path (A/B)
-bool use_patch4(int sample_num) {
-  static const int patch = [] { const char* v = getenv("JDET_ROI_BWD_PATCH"); return v ? atoi(v) : 4; }();
-  return sample_num == 2 && patch == 4;
+  return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st, !scan_here);
 }
 
 }  // namespace
@@ -382,10 +299,8 @@ static bool gather_ok(int variant, int R, int N, int C, int H, int W, int PH, in
 JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                                  int sample_num) {
   if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
-  const long seg_cap = (long)PH * PW * sample_num * sample_num * 4;
-  const size_t a = patch_carve(nullptr, patch_keys(N, H, W), R, seg_cap).bytes;
-  const size_t b = patch4_carve(nullptr, patch4_keys(N, H, W), R, seg_cap).bytes;
-  return (a > b ? a : b) + align256(sizeof(float) * (size_t)R * PH * PW * C);
+  return patch_carve(nullptr, patch_keys(N, H, W), R, (long)PH * PW * sample_num * sample_num * 4).bytes +
+         align256(sizeof(float) * (size_t)R * PH * PW * C);
 }
 
 // Bytes at the start of the workspace that the gather path needs zero on entry and leaves zero on return (the row
@@ -399,12 +314,9 @@ JDET_API size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, i
 static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,
                            int PH, int PW, float spatial_scale, int sample_num, float* grad_in, void* workspace,
                            bool grad_out_cl, bool ws_clean, hipStream_t st, int n_orient = 1) {
-#define JDET_RUN(V_, NO_)                                                                                          \
-  (use_patch4(sample_num)                                                                                          \
-       ? run_gather4<V_>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace,     \
-                         grad_out_cl, ws_clean, st, NO_)                                                           \
-       : run_gather<V_>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace,      \
-                        grad_out_cl, ws_clean, st, NO_))
+#define JDET_RUN(V_, NO_)                                                                                     \
+  run_gather<V_>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, \
+                 ws_clean, st, NO_)
   switch (variant) {
     case JDET_ROI_RIROI:   // rotated geometry; the orientation mix is applied to the gradient rows first
       if (n_orient < 1 || n_orient > 16 || C % n_orient != 0) return JDET_E_UNSUPPORTED;

@@ -6,6 +6,8 @@ orientation-pooled map), initialisation, target dict keys and the loss bookkeepi
 reference; the device work underneath is this repo's HIP path: DeformConv sampling, ARF gather,
 rotated IoU, fused max-IoU assignment, fused delta codec, rotated NMS.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -86,7 +88,7 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
                                   for b in self.anchor_base_sizes]
         self.base_anchors = dict()   # anchor cache, keyed by (level, featmap size, device)
         # levels of at most this many positions run their conv towers as ONE packed tensor (see LevelPack)
-        self.pack_max_positions = 1024
+        self.pack_max_positions = int(os.environ.get("JDET_PACK_MAX_POS", "1024"))
         self._init_layers()
 
     def _init_layers(self):

@@ -178,10 +178,19 @@ class Runner:
                 update()
         st["g1"] = g1
         if not single:
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                update()
-            st["g2"] = g2
+            mode = os.environ.get("JDET_GRAPH_UPDATE", "shared")     # diagnosis switch (scripts/ddp_graph_diag.py)
+            if mode == "eager":
+                st["g2"] = None
+                st["update"] = update
+            else:
+                g2 = torch.cuda.CUDAGraph()
+                if mode == "own":
+                    with torch.cuda.graph(g2):
+                        update()
+                else:
+                    with torch.cuda.graph(g2, pool=g1.pool()):
+                        update()
+                st["g2"] = g2
         return st
 
     def _graph_step(self, images, targets):
@@ -219,7 +228,10 @@ class Runner:
         st["g1"].replay()
         if self.world_size > 1:
             self._allreduce_flat(st["flat"])
-            st["g2"].replay()
+            if st["g2"] is not None:
+                st["g2"].replay()
+            else:
+                st["update"]()
         if self.scheduler is not None:
             self.scheduler.step(self.iter, self.epoch, by_epoch=True)
         self.iter += 1

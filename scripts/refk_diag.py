@@ -7,7 +7,8 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O          # noqa: E402
 from oracle import ref_hip as RH        # noqa: E402
 from tests.test_gpu_reference_kernels import KINDS, _case, _product   # noqa: E402
