@@ -364,13 +364,11 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
 
 // counts[] hold the row lengths, segment g of recs its seg_n[g] kept taps, counts[nkeys] (ticket) is zero.
 // On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
-// scan == false: the producer has scanned the counters itself (offsets[] global, tile_base[] zero, [ntiles] = total)
 inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
-                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st, bool scan = true) {
+                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
   const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
-  if (scan)
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
-                       w.tile_sum, w.tile_base, w.counts + nkeys);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
+                     w.tile_sum, w.tile_base, w.counts + nkeys);
   hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
                      w.offsets, w.tile_base, w.entries);
   const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
@@ -380,6 +378,5 @@ inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, lon
                      ntiles, w.entries, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
   return jdet_launch_status();
 }
-
 
 }  // namespace jdet_csr

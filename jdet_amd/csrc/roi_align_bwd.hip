@@ -24,8 +24,6 @@
 // order-nondeterministic in the last bits as the reference's atomics; values agree to fp32 tolerance.
 // RiRoIAlign runs the same gather on orientation-mixed gradient rows (riroi_mix_rows_kernel); adaptive sampling
 // (sample_num <= 0, unbounded samples per bin) keeps the atomic path.
-#include <stdlib.h>
-
 #include "csr_gather.h"
 #include "roi_geom.h"
 
@@ -41,24 +39,14 @@ long patch_keys(int N, int H, int W) { return (long)N * ((H + 1) / 2) * ((W + 1)
 // the entries of its bin that share a patch (the 4 samples of a bin are 4 consecutive lanes), counts the survivors in
 // their patch's row (integer atomic, the return value is the place in the row) and writes them, compacted through an
 // LDS counter, into the RoI's own record segment (no global cursor: the fill launch walks the segments).
-// Round 4: (i) a lane's (up to four) row-counter atomics are issued back to back and waited for once -- chained, each
-// behind the previous one's record store, they made the kernel a 4-deep latency chain of device-scope round trips
-// (19.9 us); the records of a wave are placed with one LDS atomic per wave (ballot prefix) instead of one per entry.
-// (ii) SCAN_HERE: the workgroup that finishes last (ticket = the row counters' spare word) scans the counters itself
-// -- the separate scan launch (5.8 us + a kernel boundary) disappears for maps of up to 16 Ki patches
-// (JDET_ROI_BWD_FOLD_SCAN=0 keeps the separate launch: A/B).
-constexpr int kFoldedScanMaxKeys = 16384;   // 256 threads x 64 counters
-
-template <int VARIANT, bool SCAN_HERE>
+template <int VARIANT>
 __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __restrict__ rois, int H, int W, int PH,
                                                             int PW, float spatial_scale, int sample_num,
                                                             TapRec* __restrict__ recs, int* __restrict__ seg_n,
-                                                            int* __restrict__ counts, int nkeys,
-                                                            int* __restrict__ offsets, int* __restrict__ tile_base) {
+                                                            int* __restrict__ counts) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
   __shared__ RoiGeom s_geom;
-  __shared__ int s_n, s_last;
-  __shared__ int s_scan[4];
+  __shared__ int s_n;
   const int r = blockIdx.x;
   if (threadIdx.x == 0) {
     s_geom = roi_geom<VARIANT>(rois + (size_t)r * ROI_COLS, spatial_scale, sample_num, PH, PW, 1, true);
@@ -127,85 +115,21 @@ __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __rest
     }
     const int src_row = r * nbins + bin;
     TapRec* __restrict__ seg = recs + (size_t)r * S * 4;
-    bool keep[4];
-    int pos[4], mine = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      keep[k] = valid && first[k] && (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
-      mine += keep[k] ? 1 : 0;
-    }
-    // the row-counter atomics of the lane: independent, all in flight together
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      pos[k] = keep[k] ? __hip_atomic_fetch_add(&counts[key[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    // places in the RoI's segment: exclusive prefix over the wave's lanes, one LDS atomic per wave
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    const int wave_total = __shfl(incl, 63, 64);
-    int wave_base = 0;
-    if (lane == 0 && wave_total > 0) wave_base = atomicAdd(&s_n, wave_total);
-    wave_base = __shfl(wave_base, 0, 64);
-    int local = wave_base + incl - mine;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (keep[k]) {
+      const bool keep = valid && first[k] &&
+                        (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
+      if (keep) {
+        const int pos = atomicAdd(&counts[key[k]], 1);
+        const int local = atomicAdd(&s_n, 1);
         int4* dst = reinterpret_cast<int4*>(seg + local);
-        dst[0] = make_int4(key[k], pos[k], src_row, __float_as_int(wv[k][0]));
+        dst[0] = make_int4(key[k], pos, src_row, __float_as_int(wv[k][0]));
         dst[1] = make_int4(__float_as_int(wv[k][1]), __float_as_int(wv[k][2]), __float_as_int(wv[k][3]), 0);
-        local++;
       }
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) seg_n[r] = s_n;
-  if (!SCAN_HERE) return;
-
-  // ---- the last workgroup scans the row counters (exclusive, global) into offsets[]; tile_base[] = 0, [ntiles] = total
-  int* ticket = counts + nkeys;
-  if (threadIdx.x == 0) {
-    // No fence: every counter atomic of this workgroup has RETURNED (its value went into a record before the barrier
-    // above), i.e. it is performed at device scope; the records themselves are read by the next launch, not by the
-    // scanning workgroup.  (A release here writes back the XCD's whole L2 once per workgroup: measured 170 us.)
-    s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  // thread t owns counters [64 t, 64 t + 64): all 64 loads in flight at once (ONE round trip -- chunk by chunk the
-  // scan was 16 dependent device-scope round trips, 35 us), thread-local prefix, one block scan of the thread totals
-  const int wave = threadIdx.x >> 6;
-  const int k0 = 64 * (int)threadIdx.x;
-  int v[64];
-#pragma unroll
-  for (int i = 0; i < 64; i++)   // other workgroups' atomics: agent-scope loads (served beyond this CU's L1)
-    v[i] = k0 + i < nkeys ? __hip_atomic_load(&counts[k0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  int sum = 0;
-#pragma unroll
-  for (int i = 0; i < 64; i++) sum += v[i];
-  int inc = sum;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int u = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += u;
-  }
-  if (lane == 63) s_scan[wave] = inc;
-  __syncthreads();
-  int base = inc - sum;
-  for (int w = 0; w < wave; w++) base += s_scan[w];
-  const int carry = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-#pragma unroll
-  for (int i = 0; i < 64; i++) {
-    if (k0 + i < nkeys) offsets[k0 + i] = base;
-    base += v[i];
-  }
-  const int ntiles = (nkeys + kScanTile - 1) / kScanTile;
-  for (int t = threadIdx.x; t < ntiles; t += 256) tile_base[t] = 0;
-  if (threadIdx.x == 0) {
-    tile_base[ntiles] = carry;
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this workspace
-  }
 }
 
 // (R, C, nbins) -> (R, nbins, C), 32x32 LDS tiles
@@ -259,14 +183,8 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
     int he = jdet_zero_async(w.counts, patch_zero_bytes(nkeys), st);
     if (he) return he;
   }
-  static const bool fold = [] { const char* v = getenv("JDET_ROI_BWD_FOLD_SCAN"); return !v || atoi(v) != 0; }();
-  const bool scan_here = fold && nkeys <= kFoldedScanMaxKeys;
-  if (scan_here)
-    hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT, true>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
-                       sample_num, w.recs, w.seg_n, w.counts, (int)nkeys, w.offsets, w.tile_base);
-  else
-    hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT, false>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
-                       sample_num, w.recs, w.seg_n, w.counts, (int)nkeys, w.offsets, w.tile_base);
+  hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
+                     sample_num, w.recs, w.seg_n, w.counts);
   const float* rows = grad_out;   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
   if (!grad_out_cl) {
     dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
@@ -279,7 +197,7 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
                        rois, n_groups, nbins, C / n_orient, n_orient);
     rows = gT;
   }
-  return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st, !scan_here);
+  return patch_finish_and_gather(w, nkeys, R, seg_cap, rows, C, grad_in, N, H, W, st);
 }
 
 }  // namespace
@@ -314,19 +232,19 @@ JDET_API size_t jdet_roi_align_backward_clean_bytes(int variant, int R, int N, i
 static int backward_gather(int variant, const float* grad_out, const float* rois, int R, int N, int C, int H, int W,
                            int PH, int PW, float spatial_scale, int sample_num, float* grad_in, void* workspace,
                            bool grad_out_cl, bool ws_clean, hipStream_t st, int n_orient = 1) {
-#define JDET_RUN(V_, NO_)                                                                                     \
-  run_gather<V_>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, \
-                 ws_clean, st, NO_)
   switch (variant) {
     case JDET_ROI_RIROI:   // rotated geometry; the orientation mix is applied to the gradient rows first
       if (n_orient < 1 || n_orient > 16 || C % n_orient != 0) return JDET_E_UNSUPPORTED;
-      return JDET_RUN(JDET_ROI_ROTATED, n_orient);
-    case JDET_ROI_ROTATED: return JDET_RUN(JDET_ROI_ROTATED, 0);
-    case JDET_ROI_ROTATED_V1: return JDET_RUN(JDET_ROI_ROTATED_V1, 0);
-    case JDET_ROI_HBB_V0: return JDET_RUN(JDET_ROI_HBB_V0, 0);
-    default: return JDET_RUN(JDET_ROI_HBB_V1, 0);
+      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st, n_orient);
+    case JDET_ROI_ROTATED:
+      return run_gather<JDET_ROI_ROTATED>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
+    case JDET_ROI_ROTATED_V1:
+      return run_gather<JDET_ROI_ROTATED_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
+    case JDET_ROI_HBB_V0:
+      return run_gather<JDET_ROI_HBB_V0>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
+    default:
+      return run_gather<JDET_ROI_HBB_V1>(grad_out, rois, R, N, C, H, W, PH, PW, spatial_scale, sample_num, grad_in, workspace, grad_out_cl, ws_clean, st);
   }
-#undef JDET_RUN
 }
 
 JDET_API int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,

@@ -83,6 +83,15 @@ class Runner:
         self.scheduler = build_from_cfg(dict(sch_cfg), SCHEDULERS, optimizer=self.optimizer) if sch_cfg else None
         use_ddp = self.world_size > 1 if ddp is None else ddp
         self.train_model = self.model
+        if self.use_graph and self.world_size > 1 and os.environ.get("JDET_TRAIN_GRAPH_MULTI", "0") != "1":
+            # Multi-rank HIP-graph steps are refused (round 4): with two ranks the replayed step
+            # intermittently produced a garbage weight gradient for ONE backbone convolution (the library's split-K
+            # weight-gradient path; every kernel of this repo, the update graph and the all-reduce hand-over were
+            # cleared by scripts/ddp_graph_diag.py / graph_replay_diag.py).  Eager DDP (bucketed, overlapped) is the
+            # multi-rank path; JDET_TRAIN_GRAPH_MULTI=1 re-enables the graph step for diagnosis.
+            if self.rank == 0:
+                print("jdet_amd.Runner: HIP-graph mode is single-rank only; %d ranks -> eager DDP steps" % self.world_size)
+            self.use_graph = False
         if self.use_graph and self.device.type == "cuda":
             use_ddp = False    # graph mode all-reduces one flat gradient buffer itself
             if self.world_size > 1:

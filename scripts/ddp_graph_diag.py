@@ -29,7 +29,8 @@ def _hash(t):
 
 def worker(rank, world, port, name, steps):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      JDET_TRAIN_GRAPH_MULTI="1")     # the Runner refuses multi-rank graph steps otherwise
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import jdet_amd.models  # noqa: F401
     from jdet_amd.config.named import ORCNN_CFG, S2ANET_CFG

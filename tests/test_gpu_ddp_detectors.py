@@ -4,8 +4,8 @@ tiles, gradients averaged over ranks before the update).  Asserted per config:
   * DDP eager: parameters bit-identical across ranks after every step, and equal to a single process that averages
     the two ranks' gradients by hand (the definition of the all-reduce) -- NOT to the loss of the concatenated batch:
     the detection losses are normalised per rank (sum over the rank's images of max(#pos, 1)), as in the reference;
-  * HIP-graph mode (flat gradient buffer, one all-reduce between two replays): bit-identical across ranks after its
-    eager warm-up and after captured steps.
+  * a HIP-graph request under world_size 2 falls back to eager DDP steps (graph mode is single-rank only): replicas
+    bit-identical through every step.
 RCCL with more than one rank needs more than one GPU; the driver's 8-GPU run covers it."""
 import os
 import sys
@@ -122,19 +122,15 @@ def test_two_ranks_ddp_eager(dev, tmp_path, name):
         assert float((da - db).norm()) <= (first if step == 1 else later) * float(db.norm()), (name, step, float((da - db).norm() / db.norm()))
 
 
-@pytest.mark.parametrize("name", [
-    "s2anet",
-    # OPEN (round 3): Oriented R-CNN in HIP-graph mode with TWO PROCESSES SHARING ONE DEVICE diverges at a replay in
-    # about one run in three (both ranks take a garbage-sized update; host-staged, fully synchronous all-reduce and a
-    # host-side comparison do not change it; one process per device replays == eager,
-    # tests/test_gpu_oriented_rcnn.py).  Not a production set-up (one process per GPU; graph mode is off by default),
-    # kept visible here instead of being dropped.
-    pytest.param("orcnn", marks=pytest.mark.xfail(strict=False, reason="intermittent divergence, two processes on one device")),
-])
-def test_two_ranks_graph_mode(dev, tmp_path, name):
+@pytest.mark.parametrize("name", ["s2anet", "orcnn"])
+def test_two_ranks_graph_request_runs_eager_ddp(dev, tmp_path, name):
+    """Runner(graph=True) under world_size 2: HIP-graph steps are single-rank only (with two ranks a replay
+    intermittently carried a garbage weight gradient out of the library's split-K path for one backbone convolution --
+    localised by scripts/ddp_graph_diag.py, not a kernel of this repo), so the request falls back to eager DDP steps.
+    The replicas must stay bit-identical through every step, as in the eager test."""
     port = 25000 + os.getpid() % 2000 + (7 if name == "orcnn" else 0)
     out = str(tmp_path / "g.pt")
     mp.spawn(_worker, args=(2, port, name, True, out), nprocs=2, join=True)
     got = torch.load(out)
     assert len(got) == STEPS + 4 and all(torch.isfinite(h).all() for h in got)
-    assert not torch.equal(got[3], got[-1])            # captured steps moved the parameters
+    assert not torch.equal(got[3], got[-1])            # the steps moved the parameters
