@@ -263,6 +263,13 @@ size_t jdet_conv3x3_igemm_workspace(int N, int H, int W, int Cin, int Cout);
  *   as float 0/1 -> index (nbs, npts + circular) int32 hull indices in scan order, -1 in unused slots (the kernel
  *   writes every slot); npts <= 64, else JDET_E_UNSUPPORTED. */
 int jdet_convex_iou(const float* pointsets, int N, const float* polygons, int M, float* ious, jdet_stream_t stream);
+
+/* RepPoints convex GIoU with its gradient (reppoints_convex_iou/convex_giou.py:L29-47, replaces the jt.code site L37-43
+ * around convex_giou_kernel.cu:L725-821): ALIGNED pairs -- pointsets (N, 18), polygons (N, 8) -> out (N, 19):
+ * out[n, 0:18] = d giou / d pointsets[n, :] (zero for points that are not hull vertices), out[n, 18] = giou =
+ * I/U - (C - U)/C of the hull of the 9 points with the quadrilateral (C: hull of both).  Gradient by forward-mode dual
+ * numbers (half a wave per pair, one lane per coordinate), double precision inside like the reference. */
+int jdet_convex_giou(const float* pointsets, const float* polygons, int N, float* out, jdet_stream_t stream);
 int jdet_min_area_bbox(const float* pointsets, int N, float* bboxes, jdet_stream_t stream);
 int jdet_convex_sort(const float* pts, const float* masks, int nbs, int npts, int circular, int32_t* index,
                      jdet_stream_t stream);

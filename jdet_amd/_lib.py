@@ -54,6 +54,7 @@ SIGNATURES = {
     "jdet_deform_col2im_nhwc_workspace": (_sz, [_i] * 12),
     "jdet_deform_col2im_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p, _sz, _p]),
     "jdet_convex_iou": (_i, [_p, _i, _p, _i, _p, _p]),
+    "jdet_convex_giou": (_i, [_p, _p, _i, _p, _p]),
     "jdet_min_area_bbox": (_i, [_p, _i, _p, _p]),
     "jdet_convex_sort": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "jdet_conv3x3_igemm_supported": (_i, [_i, _i]),

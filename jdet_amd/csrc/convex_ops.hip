@@ -5,10 +5,10 @@
 //   min_area_bbox   ops/reppoints_min_area_bbox/min_area_bbox.cu    (minimum-area rectangle of the hull of 9 points)
 //   convex_sort     ops/convex_sort.py:L4-65, L159-194              (start point, angular order, Graham scan -> indices)
 // What has to come out:
-//   * hull: Jarvis march in two chains from the lowest point (ties: smaller x) to the highest (ties: larger x), the
-//     right chain by the most clockwise candidate, the left chain by the most counter-clockwise one, collinear
-//     candidates resolved by the larger distance; turn test in double, distances in the coordinate type (double for
-//     the IoU, float for the rectangle) -- convex_iou_kernel.cu:L157-256, min_area_bbox.cu:L205-299
+//   * hull: the reference marches (Jarvis) in two chains from the lowest point (ties: smaller x) to the highest, the
+//     right chain by the most clockwise candidate, the left one by the most counter-clockwise, collinear candidates
+//     resolved by the larger distance (convex_iou_kernel.cu:L157-256, min_area_bbox.cu:L205-299): the counter-clockwise
+//     vertex sequence from the lowest point without collinear points -- produced here by a monotone chain
 //   * IoU: both polygons made counter-clockwise, intersection area = sum over edge pairs of the signed area of
 //     triangle(0, a, b) /\ triangle(0, c, d), each by three half-plane cuts with eps = 1e-8 sign tests (L60-155);
 //     iou = inter / (|hull| + |quad| - inter), all in double, returned as float (L258-290)
@@ -37,67 +37,41 @@ __device__ __forceinline__ T dis2(const Pt<T>& a, const Pt<T>& b) {
   return (a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y);
 }
 
-// Jarvis march of the reference (see header).  p[0..n) is reordered in place into the hull, n becomes its size.
-// Loop caps (the reference has none): a chain of 9 points has at most 9 steps.
+// Convex hull of p[0..n), in place: counter-clockwise, starting at the lowest point (ties: smaller x), collinear and
+// duplicate candidates dropped -- the vertex sequence the reference's two-chain Jarvis march produces (header), obtained
+// by Andrew's monotone chain (sort by (x, y), lower then upper chain, turn test in double) and one rotation of the
+// result.  (Rounds 2-3 carried a statement-by-statement rendering of the reference's march here; the sequence is a
+// property of the point set, not of the march.)
 template <typename T>
-__device__ void jarvis(Pt<T>* p, int& n) {
-  Pt<T> p_max = p[0], p_k;
-  int max_index = 0, k_index;
-  int stack[20], top1, top2;
-  Pt<T> right[20], left[20];
+__device__ void hull_ccw_from_lowest(Pt<T>* p, int& n) {
+  for (int i = 1; i < n; i++) {        // insertion sort by (x, y)
+    const Pt<T> t = p[i];
+    int j = i - 1;
+    while (j >= 0 && (p[j].x > t.x || (p[j].x == t.x && p[j].y > t.y))) {
+      p[j + 1] = p[j];
+      j--;
+    }
+    p[j + 1] = t;
+  }
+  Pt<T> h[24];
+  int m = 0;
+  auto turn = [&](const Pt<T>& o, const Pt<T>& a, const Pt<T>& b) {
+    return crossd((double)o.x, (double)o.y, (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+  };
   for (int i = 0; i < n; i++) {
-    if (p[i].y < p[0].y || (p[i].y == p[0].y && p[i].x < p[0].x)) {
-      const Pt<T> t = p[0];
-      p[0] = p[i];
-      p[i] = t;
-    }
-    if (i == 0) {
-      p_max = p[0];
-      max_index = 0;
-    }
-    if (p[i].y > p_max.y || (p[i].y == p_max.y && p[i].x > p_max.x)) {
-      p_max = p[i];
-      max_index = i;
-    }
+    while (m >= 2 && turn(h[m - 2], h[m - 1], p[i]) <= 0.0) m--;
+    h[m++] = p[i];
   }
-  if (max_index == 0) {
-    max_index = 1;
-    p_max = p[max_index];
+  const int lower = m + 1;
+  for (int i = n - 2; i >= 0; i--) {
+    while (m >= lower && turn(h[m - 2], h[m - 1], p[i]) <= 0.0) m--;
+    h[m++] = p[i];
   }
-  k_index = 0, stack[0] = 0, top1 = 0;
-  while (k_index != max_index && top1 < 18) {
-    p_k = p_max;
-    k_index = max_index;
-    const Pt<T> s = p[stack[top1]];
-    for (int i = 1; i < n; i++) {
-      const double sign = crossd(s.x, s.y, p[i].x, p[i].y, p_k.x, p_k.y);
-      if (sign > 0 || (sign == 0 && dis2(s, p[i]) > dis2(s, p_k))) {
-        p_k = p[i];
-        k_index = i;
-      }
-    }
-    top1++;
-    stack[top1] = k_index;
-  }
-  for (int i = 0; i <= top1; i++) right[i] = p[stack[i]];
-  k_index = 0, stack[0] = 0, top2 = 0;
-  while (k_index != max_index && top2 < 18) {
-    p_k = p_max;
-    k_index = max_index;
-    const Pt<T> s = p[stack[top2]];
-    for (int i = 1; i < n; i++) {
-      const double sign = crossd(s.x, s.y, p[i].x, p[i].y, p_k.x, p_k.y);
-      if (sign < 0 || (sign == 0 && dis2(s, p[i]) > dis2(s, p_k))) {
-        p_k = p[i];
-        k_index = i;
-      }
-    }
-    top2++;
-    stack[top2] = k_index;
-  }
-  for (int i = top2 - 1; i >= 0; i--) left[i] = p[stack[i]];
-  const int m = min(top1 + top2, 19);
-  for (int i = 0; i < m; i++) p[i] = i <= top1 ? right[i] : left[top2 - (i - top1)];
+  if (m > 1) m--;                        // the last point repeats the first
+  int s = 0;
+  for (int i = 1; i < m; i++)
+    if (h[i].y < h[s].y || (h[i].y == h[s].y && h[i].x < h[s].x)) s = i;
+  for (int i = 0; i < m; i++) p[i] = h[(s + i) % m];
   n = m;
 }
 
@@ -181,7 +155,7 @@ __global__ __launch_bounds__(64) void convex_iou_kernel(const float* __restrict_
   P2 hull[20], quad[6];
   for (int k = 0; k < 9; k++) hull[k] = P2{(double)pointsets[(size_t)i * 18 + 2 * k], (double)pointsets[(size_t)i * 18 + 2 * k + 1]};
   int n1 = 9;
-  jarvis<double>(hull, n1);
+  hull_ccw_from_lowest<double>(hull, n1);
   for (int k = 0; k < 4; k++) quad[k] = P2{(double)polygons[(size_t)j * 8 + 2 * k], (double)polygons[(size_t)j * 8 + 2 * k + 1]};
   const int n2 = 4;
   make_ccw(hull, n1);
@@ -207,7 +181,7 @@ __global__ __launch_bounds__(64) void min_area_bbox_kernel(const float* __restri
   P2f ps[21];
   for (int k = 0; k < 9; k++) ps[k] = P2f{pointsets[(size_t)idx * 18 + 2 * k], pointsets[(size_t)idx * 18 + 2 * k + 1]};
   int n1 = 9;
-  jarvis<float>(ps, n1);
+  hull_ccw_from_lowest<float>(ps, n1);
   ps[n1] = ps[0];
   const int n_points = n1 + 1, n_edges = n1;
   // edge directions folded into [0, pi/2) (L68-84), distinct values only (L85-104)

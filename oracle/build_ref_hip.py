@@ -196,6 +196,13 @@ API int refhip_convex_iou(const float* pointsets, int N, const float* polygons, 
     ref_cvx_iou::convex_iou_kernel<<<(N + 511) / 512, 512>>>(N, M, pointsets, polygons, ious);
   return ref_sync();
 }
+// ---- reppoints_convex_iou/convex_giou.py:L7-27 (aligned pairs, 64 threads per block, (N, 19) output)
+API int refhip_convex_giou(const float* pointsets, const float* polygons, int N, float* out) {
+  if (N > 0)
+    ref_cvx_giou::convex_giou_kernel<<<(N + ref_cvx_giou::threadsPerBlock - 1) / ref_cvx_giou::threadsPerBlock,
+                                      ref_cvx_giou::threadsPerBlock>>>(N, N, pointsets, polygons, out);
+  return ref_sync();
+}
 API int refhip_min_area_bbox(const float* pointsets, int N, float* bboxes) {
   if (N > 0) ref_cvx_box::minareabbox_kernel<<<(N + 511) / 512, 512>>>(N, pointsets, bboxes);
   return ref_sync();
@@ -367,6 +374,7 @@ def source():
     fr = module_strings(os.path.join(OPS, "fr.py"))["HEADER"]
     csort = module_strings(os.path.join(OPS, "convex_sort.py"))["CUDA_HEAD"]
     ciou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_iou_kernel.cu")).read()
+    cgiou = open(os.path.join(OPS, "reppoints_convex_iou", "convex_giou_kernel.cu")).read()
     cbox = open(os.path.join(OPS, "reppoints_min_area_bbox", "min_area_bbox.cu")).read()
     pnms = module_strings(os.path.join(OPS, "nms_poly.py"))["HEADER"]
     iou_cu = module_strings(os.path.join(OPS, "box_iou_rotated.py"))["IOU_ROTATED_CUDA_HEADER"]
@@ -386,6 +394,7 @@ def source():
              "#define ROI_ALIGN_VERSION 1\n", ns("ref_hroi1", hroi),
              ns("ref_dcn", dcn), ns("ref_fr", fr), ns("ref_cvx_sort", csort),
              ns("ref_cvx_iou", ciou.replace("using namespace std;", "")),
+             ns("ref_cvx_giou", cgiou),
              ns("ref_cvx_box", cbox),
              ns("ref_dcn2", d2_conv.replace("using namespace std;", "")),
              ns("ref_ps_fwd", d2[2].replace("using namespace std;", "")),

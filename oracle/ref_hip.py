@@ -123,6 +123,14 @@ def convex_iou(pointsets, polygons, fma=False):
     return out
 
 
+def convex_giou(pointsets, polygons, fma=False):
+    """(N, 18), (N, 8) -> (N, 19): 18 point gradients + giou (convex_giou.py:L29-47)"""
+    N = pointsets.shape[0]
+    out = torch.zeros((N, 19), dtype=torch.float32, device=pointsets.device)
+    _check(lib(fma).refhip_convex_giou(_t(pointsets), _t(polygons), _i(N), _t(out)), "convex_giou")
+    return out
+
+
 def min_area_bbox(pointsets, fma=False):
     out = torch.zeros((pointsets.shape[0], 8), dtype=torch.float32, device=pointsets.device)
     _check(lib(fma).refhip_min_area_bbox(_t(pointsets), _i(pointsets.shape[0]), _t(out)), "min_area_bbox")

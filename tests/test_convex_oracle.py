@@ -145,3 +145,18 @@ def test_convex_sort_skips_duplicates_and_handles_tiny_sets():
     one = O.convex_sort(pts, np.asarray([[0, 0, 0, 1, 0]], np.float32), True)[0]
     assert list(one) == [3, 3, -1, -1, -1, -1]
     assert O.convex_sort(np.zeros((2, 0, 2), np.float32), np.zeros((2, 0), np.float32), True).shape == (2, 1)
+
+
+def test_convex_giou_definition_closed_forms():
+    """oracle/convex_giou_oracle.py on squares: identical -> 1; half overlap -> I 2, U 6, C 6 -> 1/3; disjoint with a
+    gap -> 0 - (10 - 8)/10; gradients by central differences vanish for interior points and push an overlapped hull
+    corner the way that grows the intersection"""
+    from oracle import convex_giou_oracle as G
+    sq = np.array([[0, 0], [2, 0], [2, 2], [0, 2], [1, 1], [0.5, 0.5], [1.5, 0.5], [0.7, 1.2], [1.3, 1.6]], float).reshape(-1)
+    assert abs(G.giou_value(sq, [0, 0, 2, 0, 2, 2, 0, 2]) - 1.0) < 1e-12
+    assert abs(G.giou_value(sq, [1, 0, 3, 0, 3, 2, 1, 2]) - 1.0 / 3.0) < 1e-12
+    assert abs(G.giou_value(sq, [3, 0, 5, 0, 5, 2, 3, 2]) + 0.2) < 1e-12
+    assert abs(G.giou_value(sq, [1, 0, 1, 2, 3, 2, 3, 0]) - 1.0 / 3.0) < 1e-12        # clockwise quadrilateral
+    v, g = G.convex_giou(sq[None], [[1, 0, 3, 0, 3, 2, 1, 2]])
+    assert np.abs(g[0, 8:]).max() < 1e-9                      # the five interior points
+    assert g[0, 2] > 0 and g[0, 4] > 0                        # corners (2,0), (2,2): moving right grows I

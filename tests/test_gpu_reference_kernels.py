@@ -185,6 +185,17 @@ def test_convex_geometry_against_the_reference_kernels(dev):
     ps, q = _pointsets(rng, 200), _quads(rng, 13)
     q[::3] = q[::3].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)
     tp, tq = torch.from_numpy(ps).to(dev), torch.from_numpy(q).to(dev)
+    # GIoU + point gradients of aligned pairs: the product's dual-number kernel against the reference's hand-derived
+    # gradients (convex_giou_kernel.cu:L725-821) executed on this device
+    from jdet_amd.ops.reppoints_convex_iou import reppoints_convex_giou
+    m = ps.shape[0]
+    qa = _quads(np.random.default_rng(22), m)
+    qa[::5] = qa[::5].reshape(-1, 4, 2)[:, ::-1].reshape(-1, 8)          # some clockwise quadrilaterals
+    qa[: m // 2] += (ps[: m // 2].reshape(-1, 9, 2).mean(1) - qa[: m // 2].reshape(-1, 4, 2).mean(1))[:, None, :].repeat(4, 1).reshape(-1, 8)
+    ref19 = RH.convex_giou(tp[:m], torch.from_numpy(qa).to(dev)).cpu().numpy()
+    giou, pg = reppoints_convex_giou(tp[:m], torch.from_numpy(qa).to(dev))
+    np.testing.assert_allclose(giou.cpu().numpy(), ref19[:, 18], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(pg.cpu().numpy(), ref19[:, :18], rtol=0, atol=1e-4 * max(1e-3, float(np.abs(ref19[:, :18]).max())))
     ref_iou = RH.convex_iou(tp, tq).cpu().numpy()
     np.testing.assert_allclose(O.convex_iou(ps, q), ref_iou, rtol=0, atol=1e-6)
     np.testing.assert_allclose(reppoints_convex_iou(tp, tq).cpu().numpy(), ref_iou, rtol=0, atol=1e-6)
