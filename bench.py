@@ -36,12 +36,15 @@ def parse():
     p.add_argument("--steps", type=int, default=None)
     p.add_argument("--warmup", type=int, default=None)
     p.add_argument("--workload", default="s2anet_train")
-    p.add_argument("--batch", type=int, default=2, help="images per GPU (train workloads)")
+    p.add_argument("--batch", type=int, default=None,
+                   help="images per GPU (train workloads); default: the BASELINE.json config's -- 2, roitrans_train (cfg 4) 4")
     p.add_argument("--size", type=int, default=1024, help="tile size (s2anet_train)")
     p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"])
     p.add_argument("--rois", type=int, default=2000)
     p.add_argument("--no-cpu-baseline", action="store_true")
     a = p.parse_args()
+    if a.batch is None:
+        a.batch = 4 if a.workload == "roitrans_train" else 2      # configs[4]: batch 32 over 8 GPUs
     model_level = a.workload in ("s2anet_train", "retinanet_infer")
     if a.steps is None:
         a.steps = 20 if model_level else 200
