@@ -137,8 +137,8 @@ def test_retinanet_obb_train_and_infer(dev):
 
 
 def test_packed_small_levels_equal_the_per_level_path(dev):
-    """S2ANetHead runs the conv towers of the small pyramid levels on one packed tensor (LevelPack: levels stacked
-    along H, zero gaps kept zero); outputs and gradients equal the per-level execution up to the conv library's
+    """S2ANetHead runs the conv towers of the small pyramid levels on one packed tensor (LevelPack: levels placed
+    side by side, zero gaps kept zero); outputs and gradients equal the per-level execution up to the conv library's
     accumulation order"""
     import jdet_amd.models  # noqa: F401
     from jdet_amd.models.roi_heads.s2anet_head import S2ANetHead
@@ -151,7 +151,12 @@ def test_packed_small_levels_equal_the_per_level_path(dev):
     feats = [torch.randn(2, 32, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
              for h, w in sizes]
     pack = LevelPack(sizes[1:], dev)
-    assert pack.height == 20 + 1 + 10 + 1 + 5 + 1 + 3 and pack.width == 20
+    # placement: largest level top left, the others in a side column; any two levels at least one row / column apart,
+    # tighter than stacking along H (41 x 20)
+    import itertools
+    assert pack.height * pack.width < 41 * 20 and pack.mask.sum().item() == sum(h * w for h, w in sizes[1:])
+    for (sa, pa), (sb, pb) in itertools.combinations(list(zip(pack.sizes, pack.places)), 2):
+        assert pa[0] + sa[0] < pb[0] or pb[0] + sb[0] < pa[0] or pa[1] + sa[1] < pb[1] or pb[1] + sb[1] < pa[1]
     again = pack.unpack(pack.pack([f.detach() for f in feats[1:]]))
     assert all(torch.equal(a, f.detach()) for a, f in zip(again, feats[1:]))
 
