@@ -113,10 +113,10 @@ def make_step(workload, d):
         if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = XCD-aware schedule + RoI-stationary kernel
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
+            lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)      # (for the forward mode in force)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
             wp = ws.data_ptr()
-            lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
             if os.environ.get("JDET_ROI_SLICED_PLANAR", "0") == "1":
                 # EXPERIMENT (L2 channel spread): the map as [slice][pixel][32 channels]; same values, other addresses
                 planar = feat.permute(0, 2, 3, 1).reshape(256 * 256, 8, 32).permute(1, 0, 2).contiguous()

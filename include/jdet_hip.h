@@ -91,8 +91,9 @@ int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, in
  * geometry with double-precision trig once per RoI; the second gives every XCD one 32-channel slice of every RoI
  * (workgroup b -> slice b % (C/32); a group of 8 lanes = one (RoI, bin) x 32 channels), so a pixel is one 128-byte
  * line in exactly one XCD's L2.  Same values either way (merged-tap arithmetic).
- * workspace: jdet_roi_align_forward_cl_workspace(R, PH, PW) bytes (schedule + plan: ~ 136 bytes per (RoI, bin)), any
- * content, 256-byte aligned.
+ * workspace: jdet_roi_align_forward_cl_workspace(R, PH, PW) bytes FOR THE CURRENT FORWARD MODE (8 R + 256 for the
+ * schedule; mode 2: schedule + plan, ~ 136 bytes per (RoI, bin)), any content, 256-byte aligned; a buffer that is too
+ * small for the mode in force at the call returns JDET_E_WORKSPACE.
  * RoIs with a negative batch index are skipped as in jdet_roi_align_forward. */
 size_t jdet_roi_align_forward_cl_workspace(int R, int PH, int PW);
 int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W, const float* rois,

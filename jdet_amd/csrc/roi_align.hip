@@ -1225,7 +1225,10 @@ JDET_API int jdet_roi_align_forward_cl_roi(int variant, const float* feat, int N
 // XCD-aware spatial order.  The schedule / per-RoI records live in the caller's workspace.
 JDET_API size_t jdet_roi_align_forward_cl_workspace(int R, int PH, int PW) {
   if (R <= 0 || PH <= 0 || PW <= 0) return 256;
-  return jdet_roi_sliced::plan_carve(nullptr, R, (long)PH * PW).bytes;
+  // forward mode 2 (channel-sliced kernels): schedule + plan; otherwise the two int32 arrays of the spatial order
+  static const int sliced_env = env_int("JDET_ROI_FWD_SLICED", 0);
+  if (g_fwd_reference_order == 2 || sliced_env) return jdet_roi_sliced::plan_carve(nullptr, R, (long)PH * PW).bytes;
+  return 256 + 2 * sizeof(int32_t) * (size_t)R;
 }
 
 JDET_API int jdet_roi_align_forward_cl(int variant, const float* feat, int N, int C, int H, int W, const float* rois,

@@ -284,9 +284,9 @@ def _fwd_cl_both(variant, x, rois, hw, scale, nO, rois_legacy=None):
     for sliced in (True, False):
         out = torch.full((R, C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
         if sliced:
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R, hw[0], hw[1])
-            ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
             prev = lib.jdet_set_roi_forward_mode(2)        # the channel-sliced kernels (not the default path)
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R, hw[0], hw[1])     # (the query follows the mode)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
             try:
                 L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0],
                                                       hw[1], scale, 2, nO, out.data_ptr(), ws.data_ptr(), wsb,
