@@ -47,6 +47,12 @@ int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_
 int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
                                        int pairs, int n_blocks, float* out, jdet_stream_t stream);
 
+/* Calibration probe (scripts/mfma_probe.py; csrc/experimental/mfma_probe.hip): shader cycles per wave of `steps` K steps
+ * of 32 v_mfma_f32_32x32x2_f32 with the pieces of the conv_wgrad.hip loop added one at a time (variant 0 bare MFMAs, 1 +
+ * LDS fragment fetches, 2 + LDS tile writes and the barrier, 3 + buffer loads).  cycles: n_blocks * 4 values. */
+int jdet_debug_mfma_probe(int variant, const float* src, int n_blocks, int steps, long long* cycles, float* sink,
+                          jdet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,6 +254,17 @@ int jdet_conv3x3_igemm_forward(const float* x_nhwc, int N, int H, int W, int Cin
  * single pass.  0 when the shape is not split. */
 size_t jdet_conv3x3_igemm_workspace(int N, int H, int W, int Cin, int Cout);
 
+/* Weight gradient of the same convolution, ACCUMULATED into gw: gw (Cout,3,3,Cin) += sum over positions of
+ * gy (N,H,W,Cout) x the (shifted | bilinearly gathered, offset non-NULL) input x (N,H,W,Cin).  Replaces the weight
+ * gradient Jittor derives for nn.Conv inside ConvModule (models/utils/modules.py:L91-175) and DeformConvFunction.grad's
+ * im2col + matmul into grad_weight (ops/dcn_v1.py:L508-556).  The reduction over positions is split over workgroups
+ * and meets in gw by float atomics, so several calls (the pyramid levels of a shared tower) may target one buffer --
+ * the caller zero-fills it once (or passes p.grad).  ksplit = 0 chooses the split.  Cin % 4 == 0, Cout % 4 == 0,
+ * 16-byte aligned x / gy, else JDET_E_UNSUPPORTED / JDET_E_BADARG. */
+int jdet_conv3x3_wgrad_supported(int Cin, int Cout);
+int jdet_conv3x3_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, int N, int H, int W, int Cin,
+                       int Cout, float* gw_krsc, int ksplit, jdet_stream_t stream);
+
 /* RepPoints geometry on 9-point sets (pointsets (N,18) = 9 (x,y) pairs) and the Graham scan of the polygon-IoU loss.
  * jdet_convex_iou: replaces convex_iou_kernel (ops/reppoints_convex_iou/convex_iou_kernel.cu:L258-305): IoU of the
  *   convex hull of every point set with every quadrilateral polygons (M,8) -> ious (N,M), computed in double.

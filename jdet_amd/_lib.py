@@ -60,6 +60,8 @@ SIGNATURES = {
     "jdet_conv3x3_igemm_supported": (_i, [_i, _i]),
     "jdet_conv3x3_igemm_forward": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _i, _p, _p, _sz, _p]),
     "jdet_conv3x3_igemm_workspace": (_sz, [_i] * 5),
+    "jdet_conv3x3_wgrad_supported": (_i, [_i, _i]),
+    "jdet_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "jdet_sigmoid_focal_loss_workspace": (_sz, []),
     "jdet_sigmoid_focal_loss": (_i, [_p, _p, _p, _l, _i, _f, _f, _p, _p, _p, _sz, _p]),
     "jdet_smooth_l1_loss": (_i, [_p, _p, _p, _l, _f, _p, _p, _p, _sz, _p]),

@@ -84,6 +84,71 @@ def preferred(x, weight, min_positions=None):
     return N * H * W >= (MIN_POSITIONS if min_positions is None else min_positions)
 
 
+def wgrad_supported(cin, cout):
+    return bool(L.lib().jdet_conv3x3_wgrad_supported(int(cin), int(cout)))
+
+
+def conv3x3_wgrad_nhwc(x_nhwc, gy_nhwc, offset=None, out=None, ksplit=0):
+    """x (N,H,W,Cin), gy (N,H,W,Cout) contiguous fp32 [offset (N,18,H,W): the deformable form] -> the weight gradient
+    (Cout,3,3,Cin).  `out`: a contiguous (Cout,3,3,Cin) buffer the gradient is ADDED to (csrc/conv_wgrad.hip), else a
+    fresh zero-filled one."""
+    L.need_device(x_nhwc, gy_nhwc, offset, out)
+    N, H, W, Cin = x_nhwc.shape
+    Cout = gy_nhwc.shape[3]
+    if tuple(gy_nhwc.shape[:3]) != (N, H, W):
+        raise ValueError("gy %r does not match x %r" % (tuple(gy_nhwc.shape), tuple(x_nhwc.shape)))
+    if offset is not None and tuple(offset.shape) != (N, 18, H, W):
+        raise ValueError("offset must be (N, 18, H, W), got %r" % (tuple(offset.shape),))
+    x_nhwc, gy_nhwc = L.f32c(x_nhwc), L.f32c(gy_nhwc)
+    if out is None:
+        out = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=x_nhwc.device)
+    elif tuple(out.shape) != (Cout, 3, 3, Cin) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("out must be a contiguous fp32 (Cout, 3, 3, Cin) tensor")
+    L.check(L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc),
+                                       L.ptr(L.f32c(offset)) if offset is not None else None, N, H, W, Cin, Cout,
+                                       L.ptr(out), int(ksplit), L.stream_ptr(x_nhwc)), "jdet_conv3x3_wgrad")
+    return out
+
+
+def conv3x3_wgrad(x, gy, offset=None, ksplit=0):
+    """NCHW-logical form: x (N,Cin,H,W), gy (N,Cout,H,W) -> (Cout,Cin,3,3) logical weight gradient (channels_last
+    memory: a view of the kernel's (Cout,3,3,Cin) result)"""
+    gw = conv3x3_wgrad_nhwc(L.f32c(x.permute(0, 2, 3, 1)), L.f32c(gy.permute(0, 2, 3, 1)), offset, None, ksplit)
+    return gw.permute(0, 3, 1, 2)
+
+
+# Weight gradient of the igemm layers by csrc/conv_wgrad.hip (JDET_CONV_WGRAD=1; default: the library's).  Several uses
+# of ONE weight inside one backward pass (a tower shared by the pyramid levels) accumulate into the buffer the first use
+# returned: the kernel adds in place, so the engine neither zero-fills per call nor sums the uses afterwards.
+# Measured (profiles/r04_conv_wgrad.md): the kernel runs 91 % MFMA-busy in cycles and ties the library's in isolation
+# (312 vs 314-326 us at 2 x 128^2 x 256), but inside the autotuned S2ANet step the library's pick is faster than its
+# stand-alone time: 29.28 ms with this switch on against 29.02-29.06 ms off -- so it is off by default.
+WGRAD = os.environ.get("JDET_CONV_WGRAD", "0") == "1"
+_GW_ACC = {}           # weight.data_ptr() -> (backward pass id, device pointer of the (Cout,3,3,Cin) buffer, its shape)
+
+
+def shared_wgrad(weight, x_nhwc, gy_nhwc, offset=None):
+    """weight gradient of y = conv3x3(x, weight) [deformable with `offset`] for this use of `weight`, as autograd wants
+    it: the first use in a backward pass returns a fresh (Cout, Cin, 3, 3) tensor (channels_last memory, so a
+    channels_last parameter takes it without a copy); later uses add into that tensor's memory and return None.  Only
+    the pointer is remembered -- a second reference would make AccumulateGrad clone the gradient instead of taking it."""
+    tid = torch._C._current_graph_task_id()
+    key = weight.data_ptr()          # (the saved tensor may come back in a new Python wrapper: the storage names the weight)
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    hit = _GW_ACC.get(key)
+    if tid >= 0 and hit is not None and hit[0] == tid and hit[2] == (Cout, Cin, x_nhwc.device):
+        N, H, W, _ = x_nhwc.shape
+        x_nhwc, gy_nhwc = L.f32c(x_nhwc), L.f32c(gy_nhwc)
+        L.check(L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc),
+                                           L.ptr(L.f32c(offset)) if offset is not None else None, N, H, W, Cin, Cout,
+                                           hit[1], 0, L.stream_ptr(x_nhwc)), "jdet_conv3x3_wgrad")
+        return None
+    buf = conv3x3_wgrad_nhwc(x_nhwc, gy_nhwc, offset)
+    if tid >= 0:
+        _GW_ACC[key] = (tid, buf.data_ptr(), (Cout, Cin, x_nhwc.device))
+    return buf.permute(0, 3, 1, 2)
+
+
 _FLIPPED = {}          # id(weight) -> (data_ptr, version, tensor): the data-gradient weights of the current step
 # grad_x through this kernel (flipped weights): 296 vs 341 us against the library's data gradient in isolation
 # (scripts/wgrad_bar.py), but no difference inside the autotuned train step (30.30 vs 30.30 ms): off by default.
@@ -211,9 +276,13 @@ class _ConvBiasAct(torch.autograd.Function):
         if need[0] and igemm and DGRAD and supported(weight.shape[0], weight.shape[1]):
             gx = conv3x3_nhwc(L.f32c(g.permute(0, 2, 3, 1)), dgrad_weight(weight)).permute(0, 3, 1, 2)
             need[0] = False
-        lx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
+        own_gw = need[1] and igemm and WGRAD and wgrad_supported(weight.shape[1], weight.shape[0])
+        if own_gw:
+            gw = shared_wgrad(weight, x.permute(0, 2, 3, 1), g.permute(0, 2, 3, 1))
+            need[1] = False
+        lx, lw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
                                                         groups, need) if any(need) else (None, None, None)
-        return (gx if gx is not None else lx), gw, gb, None, None, None, None, None, None
+        return (gx if gx is not None else lx), (gw if own_gw else lw), gb, None, None, None, None, None, None
 
 
 _Conv3x3BiasAct = _ConvBiasAct      # (name used by the round-3 notes)

@@ -12,8 +12,13 @@ L490,L547); the bilinear gather / scatter around it is hand-written:
 * general path (groups / deformable groups / offset gradient): csrc/deform_nchw.hip, the reference's
   NCHW column layout.
 Both compute the same per-element arithmetic.
+
+Training without the column matrix (optional: JDET_DCN_FUSED_TRAIN_MIN_POS; 3x3 / stride 1 / pad 1, offsets without
+gradient, maps of at least that many positions): forward = csrc/conv_igemm.hip with a gathered A operand, weight gradient =
+csrc/conv_wgrad.hip with a gathered B operand; only grad_input still forms grad_cols for the sorted gather.
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -109,6 +114,23 @@ def _weight_grad(g, cols, split_rows=16384, splits=4):
     return torch.mm(g.t(), cols)
 
 
+# Training without the column matrix (3x3 / stride 1 / pad 1, offsets without gradient): maps of at least this many
+# positions take the gathered-operand kernels in the forward and the weight gradient.  0 = never (the default: the
+# S2ANet step measured 29.39 ms with the finest level fused, 29.53 ms with the three finest, 29.28 ms with none --
+# profiles/r04_conv_wgrad.md; what the fused path saves is memory, 0.8 GB of saved columns at 1024^2 batch 2).
+FUSED_TRAIN_MIN_POSITIONS = int(os.environ.get("JDET_DCN_FUSED_TRAIN_MIN_POS", "0"))
+
+
+def _fused_train_ok(x_nhwc, off, weight, kh, kw, stride, padding, dilation):
+    from jdet_amd.ops import conv_igemm
+    B, H, W, Cin = x_nhwc.shape
+    return (FUSED_TRAIN_MIN_POSITIONS > 0 and B * H * W >= FUSED_TRAIN_MIN_POSITIONS
+            and (kh, kw, tuple(stride), tuple(padding), tuple(dilation)) == (3, 3, (1, 1), (1, 1), (1, 1))
+            and not off.requires_grad and tuple(off.shape) == (B, 18, H, W)
+            and conv_igemm.supported(Cin, weight.shape[0]) and conv_igemm.wgrad_supported(Cin, weight.shape[0])
+            and B * H * W * max(Cin, weight.shape[0]) < 2 ** 30 - 2 ** 20)
+
+
 class DeformConvFunction(torch.autograd.Function):
     @staticmethod
     def _forward_nhwc(ctx, input, off, weight, stride, padding, dilation):
@@ -117,15 +139,22 @@ class DeformConvFunction(torch.autograd.Function):
         Ho, Wo = _out_hw(H, W, kh, kw, padding, stride, dilation)
         x = _nhwc(input)
         wt = L.f32c(weight.permute(0, 2, 3, 1)).view(Cout, kh * kw * Cin)   # K index = tap*Cin + c
+        ctx.fused = _fused_train_ok(x, off, weight, kh, kw, stride, padding, dilation)
+        if ctx.fused:
+            # no column matrix in either direction: the forward gathers its A operand (csrc/conv_igemm.hip), the weight
+            # gradient gathers its B operand (csrc/conv_wgrad.hip); only grad_input still goes through columns
+            from jdet_amd.ops import conv_igemm
+            ctx.save_for_backward(x, off, wt, None, weight)
+            return conv_igemm.conv3x3_nhwc(x, wt.view(Cout, kh, kw, Cin), offset=off).permute(0, 3, 1, 2)
         cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
         out = F.linear(cols, wt)                                              # (B*Ho*Wo, Cout) == NHWC
         keep = SAVE_COLUMNS and weight.requires_grad
-        ctx.save_for_backward(x, off, wt, cols if keep else None)
+        ctx.save_for_backward(x, off, wt, cols if keep else None, None)
         return out.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
 
     @staticmethod
     def _backward_nhwc(ctx, grad_output):
-        x, off, wt, cols = ctx.saved_tensors
+        x, off, wt, cols, weight = ctx.saved_tensors
         stride, padding, dilation = ctx.cfg[:3]
         Cout, Cin, kh, kw = ctx.wshape
         B, H, W, _ = x.shape
@@ -141,7 +170,10 @@ class DeformConvFunction(torch.autograd.Function):
             gcols = torch.mm(g, wt)
             gx = deformable_col2im_nhwc(gcols, off, x.shape, kh, kw, padding, stride, dilation)
             grad_input = gx.permute(0, 3, 1, 2)
-        if need_w:
+        if need_w and ctx.fused:
+            from jdet_amd.ops import conv_igemm
+            grad_weight = conv_igemm.shared_wgrad(weight, x, g.view(B, H, W, Cout), off)
+        elif need_w:
             if cols is None:
                 cols = deformable_im2col_nhwc(x, off, kh, kw, padding, stride, dilation)
             grad_weight = _weight_grad(g, cols).view(Cout, kh, kw, Cin).permute(0, 3, 1, 2)

@@ -133,3 +133,44 @@ def test_arf_vs_golden_and_orconv(golden, dev):
     assert p.shape == (2, 4, 9, 9)
     assert torch.equal(p, y.view(2, 4, 8, 9, 9).max(2).values)
     assert any(k.startswith("conv.") for k in rip.state_dict())  # checkpoint-compatible unused submodule
+
+
+def test_deform_conv_fused_training_path_vs_oracle(dev, monkeypatch):
+    """Training without the column matrix (forward: gathered A operand of conv_igemm.hip; weight gradient: gathered B
+    operand of conv_wgrad.hip): same oracle as the column path; the conv is used TWICE in one backward pass (a tower
+    shared by two pyramid levels), so the second use adds into the gradient buffer of the first."""
+    from jdet_amd.ops import dcn_v1
+    from jdet_amd.ops.dcn_v1 import DeformConv
+    monkeypatch.setattr(dcn_v1, "FUSED_TRAIN_MIN_POSITIONS", 1)
+    rng = np.random.default_rng(11)
+    Cin, Cout = 64, 12
+    conv = DeformConv(Cin, Cout, 3, padding=1).to(dev)
+    w = conv.weight.detach().cpu().numpy()
+    a = (3, 3, (1, 1), (1, 1), (1, 1), 1)
+    gw_ref = np.zeros((Cout, Cin * 9))
+    xs, gxs = [], []
+    total = 0
+    for (B, H, W) in ((2, 11, 14), (1, 7, 20)):
+        x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+        off = (rng.standard_normal((B, 18, H, W)) * 3).astype(np.float32)
+        xt = _t(x, dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = conv(xt, _t(off, dev))
+        col = O.deform_im2col(x, off, *a)
+        ref = (w.reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64)).reshape(Cout, B, H, W).transpose(1, 0, 2, 3)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref, rtol=1e-4, atol=2e-4)
+        gy = rng.standard_normal(y.shape).astype(np.float32)
+        total = total + (y * _t(gy, dev)).sum()
+        gcol = (w.reshape(Cout, -1).T.astype(np.float64) @ gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64)).astype(np.float32).reshape(col.shape)
+        xs.append(xt)
+        gxs.append(O.deform_col2im(gcol, off, x.shape, *a))
+        gw_ref += gy.transpose(1, 0, 2, 3).reshape(Cout, -1).astype(np.float64) @ col.reshape(Cin * 9, -1).astype(np.float64).T
+    total.backward()
+    for xt, gx in zip(xs, gxs):
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gx, rtol=1e-4, atol=3e-4)
+    np.testing.assert_allclose(conv.weight.grad.cpu().numpy().reshape(Cout, -1), gw_ref, rtol=1e-4, atol=3e-4)
+    # a second backward pass starts a fresh buffer (nothing of the first pass's gradient leaks in)
+    conv.weight.grad = None
+    y = conv(xs[0].detach(), _t(np.zeros((2, 18, 11, 14), np.float32), dev))
+    y.sum().backward()
+    ref = torch.autograd.grad(torch.nn.functional.conv2d(xs[0].detach(), conv.weight, padding=1).sum(), conv.weight)[0]
+    assert torch.allclose(conv.weight.grad, ref, rtol=1e-4, atol=1e-3)
