@@ -6,6 +6,7 @@ orientation-pooled map), initialisation, target dict keys and the loss bookkeepi
 reference; the device work underneath is this repo's HIP path: DeformConv sampling, ARF gather,
 rotated IoU, fused max-IoU assignment, fused delta codec, rotated NMS.
 """
+import contextlib
 import os
 
 import torch
@@ -15,6 +16,16 @@ from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
 from jdet_amd.models.boxes.box_ops import delta2bbox_rotated
 from jdet_amd.models.utils.level_pack import LevelPack
+
+HEAD_STREAMS = os.environ.get("JDET_HEAD_STREAMS", "1") == "1"
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device)
+    return s
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.ops.dcn_v1 import DeformConv
@@ -284,13 +295,31 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         small = [i for i, f in enumerate(feats)
                  if f.is_cuda and f.shape[-2] * f.shape[-1] <= self.pack_max_positions]
         outs = [None] * len(feats)
+        side = None
         if len(small) >= 2:
-            packed = self.forward_packed([feats[i] for i in small], [self.anchor_strides[i] for i in small])
+            # The packed small levels and the big levels are independent until the losses, and the packed tower's
+            # launches leave most of the chip idle (57 x 32 positions: 58 output tiles for 256 CUs): they run on a side
+            # stream next to the big levels' (autograd replays each branch's backward on its forward stream, so the
+            # backward overlaps the same way).  Not under graph capture (one capture stream), JDET_HEAD_STREAMS=0: off.
+            if (HEAD_STREAMS and len(small) < len(feats) and torch.is_grad_enabled()
+                    and not torch.cuda.is_current_stream_capturing()):
+                side = _side_stream(feats[0].device)
+                main = torch.cuda.current_stream(feats[0].device)
+                side.wait_stream(main)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                packed = self.forward_packed([feats[i] for i in small], [self.anchor_strides[i] for i in small])
             for i, o in zip(small, packed):
                 outs[i] = o
         for i, f in enumerate(feats):
             if outs[i] is None:
                 outs[i] = self.forward_single(f, self.anchor_strides[i])
+        if side is not None:
+            main.wait_stream(side)
+            for i in small:                       # made on the side stream, consumed (and freed) on the main one
+                feats[i].record_stream(side)
+                for t in outs[i]:
+                    if torch.is_tensor(t):
+                        t.record_stream(main)
         return tuple(map(list, zip(*outs)))
 
     def forward(self, feats, targets):

@@ -1,0 +1,7 @@
+#!/bin/bash
+set -u
+timeout 900 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_ddp_detectors.py -x -q 2>&1 | tail -4
+for v in 1 0 1 0; do
+  echo "== JDET_HEAD_STREAMS=$v"
+  JDET_HEAD_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+done
