@@ -106,7 +106,11 @@ int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C,
  *   1          : the reference's operation order (roi_align_rotated.py:L70-118) -- bit-identical to the
  *                CPU oracle; used by the parity tests.
  *   2          : mode 0's arithmetic through the channel-sliced kernels of jdet_roi_align_forward_cl where they apply
- *                (bit-equal to mode 0; measured slower at the north-star point, profiles/r04_roi_fwd_notes.md). */
+ *                (bit-equal to mode 0; measured slower at the north-star point, profiles/r04_roi_fwd_notes.md).
+ *   3          : channels-last entries with sample_num == 2 and PH, PW <= 8: every distinct pixel row of a LINE of bins
+ *                (a bin row or a bin column, whichever packs tighter) is loaded once and multiplied into the line's
+ *                accumulators (csrc/roi_align_line.h); mode 0's values up to the order of a bin's sum (<= 2e-6 on
+ *                N(0,1) maps); 45 % fewer rows through the L1, measured slower (same notes).  Elsewhere: mode 0. */
 int jdet_set_roi_forward_mode(int mode);
 
 /* XCD-aware spatial schedule for the RoIAlign kernels (no reference counterpart: the reference

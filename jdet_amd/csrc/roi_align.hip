@@ -555,6 +555,8 @@ __global__ __launch_bounds__(NW * 64) void roi_align_fwd_merged_kernel(
   }
 }
 
+#include "roi_align_line.h"
+
 // (An LDS pixel-cache variant -- per-RoI bitmap + rank dedup, distinct pixels staged once per 64-channel pass, taps
 // served by ds_read_b128 -- was built and measured at 155 us against 69 us for the direct path at the time: four
 // channel passes with two barriers each and 2 workgroups per CU leave the vector-memory path idle most of the time.
@@ -949,6 +951,7 @@ int env_int(const char* name, int dflt) {
 
 // 0 = merged taps (default), 1 = reference operation order (bit-identical to the CPU oracle),
 // 2 = merged taps through the channel-sliced kernels where they apply (roi_align_sliced.h; measured, not default)
+// 3 = taps deduplicated over a line of bins where that kernel applies (roi_align_line.h; measured, not default)
 int g_fwd_reference_order = 0;
 
 template <int VARIANT>
@@ -997,6 +1000,21 @@ int launch_fwd(const float* feat, const float* rois, float* out, int R, int C, i
       // in flight, smaller working set.  JDET_ROI_FWD_LDS_KB overrides (profiling).
       static const int lds_kb = env_int("JDET_ROI_FWD_LDS_KB", 36);
       const size_t lds_cl = lds_kb > 16 ? (size_t)lds_kb * 1024 : 8 * 2048;
+      static const int line_env = env_int("JDET_ROI_FWD_LINE", 0);     // (A/B runs; 2 = 8 rows per batch)
+      const int line = g_fwd_reference_order == 3 ? 2 : (g_fwd_reference_order == 0 ? line_env : 0);
+      if (line && PH <= kLineMaxBins && PW <= kLineMaxBins && nbins * 4 <= 256) {
+        // taps deduplicated over a line of bins (roi_align_line.h): 36 KiB of tables = 4 workgroups per CU as well
+        const size_t lds_ln = (size_t)kLineMaxBins * kLineSlots * (4 + 32);
+        if (PH <= 7 && PW <= 7 && line == 2)
+          hipLaunchKernelGGL((roi_align_fwd_line_kernel<V, 7, 8>), grid, dim3(256), lds_ln, st, feat, rois, out, C, H,
+                             W, PH, PW, scale, order);
+        else if (PH <= 7 && PW <= 7)
+          hipLaunchKernelGGL((roi_align_fwd_line_kernel<V, 7, 16>), grid, dim3(256), lds_ln, st, feat, rois, out, C, H,
+                             W, PH, PW, scale, order);
+        else
+          hipLaunchKernelGGL((roi_align_fwd_line_kernel<V, 8, 16>), grid, dim3(256), lds_ln, st, feat, rois, out, C, H,
+                             W, PH, PW, scale, order);
+      } else
       hipLaunchKernelGGL((roi_align_fwd_merged_kernel<V, 4, 0, true>), grid, dim3(256), lds_cl, st, feat, rois, out,
                          C, H, W, PH, PW, scale, order, 0);
     }
@@ -1157,7 +1175,7 @@ JDET_API int jdet_nhwc_to_nchw(const float* x, int N, int C, int H, int W, float
 
 JDET_API int jdet_set_roi_forward_mode(int mode) {
   const int prev = g_fwd_reference_order;
-  if (mode == 0 || mode == 1 || mode == 2) g_fwd_reference_order = mode;
+  if (mode >= 0 && mode <= 3) g_fwd_reference_order = mode;
   return prev;
 }
 

@@ -362,3 +362,45 @@ def test_sliced_forward_north_star_equals_roi_stationary(dev):
     assert torch.equal(a, b)
     a2, _ = _fwd_cl_both(O.V_ROT, x, rois, (7, 7), 0.25, 1)
     assert torch.equal(a, a2)
+
+
+@pytest.mark.parametrize("variant,C", [(O.V_ROT, 256), (O.V_ROT, 96), (O.V_ROT_V1, 64), (O.V_HBB0, 32), (O.V_HBB1, 128)])
+@pytest.mark.parametrize("hw", [(7, 7), (4, 4), (5, 8)])
+def test_line_forward_matches_the_oracle(dev, variant, C, hw):
+    """Forward mode 3 (csrc/roi_align_line.h): every distinct pixel row of a LINE of bins loaded once, per-bin weights
+    from an LDS table.  Same geometry and the same within-bin merge as mode 0; a bin's sum runs in another order, so
+    the bar is the merged-tap tolerance against the oracle (and the same distance from mode 0).  Several images, masked
+    RoIs (rows untouched), RoIs over the border, thin and fat RoIs (lines along rows / along columns)."""
+    from jdet_amd import _lib as L
+    if fwd_mode_is_reference():
+        pytest.skip("merged-tap arithmetic only")
+    lib = L.lib()
+    rng = np.random.default_rng(300 + variant * 7 + C + hw[1])
+    N, H, W, scale = 3, 40, 56, 0.25
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    R = 203
+    rois = np.concatenate([I.rois_from_obbs(I.random_obbs(rng, R, extent=W / scale, wh=(4.0, 200.0)),
+                                            rng.integers(0, N, R)), I.edge_rois(H, W, scale)], 0)
+    rois[rng.random(rois.shape[0]) < 0.2, 0] = -1.0        # masked
+    if variant in (O.V_HBB0, O.V_HBB1):
+        rois = I.obb_to_hbb_rois(rois)
+    x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.from_numpy(rois).to(dev)
+    outs = []
+    for mode in (3, 0):
+        out = torch.full((rois.shape[0], C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
+        prev = lib.jdet_set_roi_forward_mode(mode)
+        try:
+            L.check(lib.jdet_roi_align_forward_cl_roi(variant, x.data_ptr(), N, C, H, W, r.data_ptr(), rois.shape[0],
+                                                      hw[0], hw[1], scale, 2, 1, None, out.data_ptr(),
+                                                      L.stream_ptr(x)), "fwd_cl_roi")
+        finally:
+            lib.jdet_set_roi_forward_mode(prev)
+        outs.append(out.cpu().numpy())
+    a, b = outs
+    masked = rois[:, 0] < 0
+    assert np.isnan(a[masked]).all()
+    assert not np.isnan(a[~masked]).any()
+    ref = O.roi_align_forward(variant, feat, rois[~masked], hw, scale, 2)
+    np.testing.assert_allclose(a[~masked], ref, rtol=0, atol=FWD_MERGED_ATOL)
+    np.testing.assert_allclose(a[~masked], b[~masked], rtol=0, atol=FWD_MERGED_ATOL)
