@@ -346,6 +346,13 @@ int jdet_arf_forward(const float* weight, const uint8_t* indices, int nOut, int 
 int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
                       int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream);
 
+/* RotationInvariantPooling (orn.py:L595-618: `x.view(N, -1, nOrientation, h, w).max(2)`) on channels-last rows:
+ * x (P, C) with C = groups * nO (nO 4 or 8), y (P, groups) = max over each group's nO orientation channels; backward
+ * = the gradient autograd derives for that maximum (to the channels equal to it, split evenly among ties). */
+int jdet_rip_forward(const float* x_nhwc, long P, int C, int nO, float* y_nhwc, jdet_stream_t stream);
+int jdet_rip_backward(const float* x_nhwc, const float* y_nhwc, const float* grad_y_nhwc, long P, int C, int nO,
+                      float* grad_x_nhwc, jdet_stream_t stream);
+
 /* Rotated box delta codec (fused elementwise).  Replace the Jittor tensor programs
  * models/boxes/box_ops.py:L229-285 (delta2bbox_rotated: rois (n,5), deltas (n, ncls*5) -> out
  * (n, ncls*5); max_shape / clip_border are accepted by the reference but never applied) and

@@ -65,4 +65,79 @@ JDET_API int jdet_arf_backward(const uint8_t* indices, const float* grad_out, in
   return arf_launch(true, grad_out, indices, nOut, nIn, nOri, kH, kW, nRot, grad_weight, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RotationInvariantPooling (orn.py:L595-618): y[p, g] = max over the nO orientation channels g*nO .. g*nO+nO-1 of a
+// channels-last row; backward: the gradient goes to the channels that equal the maximum, split evenly among ties (what
+// autograd derives for amax).  One thread per (position, group): nO consecutive floats in, one float out.
+namespace {
+
+template <int NO>
+__global__ __launch_bounds__(256) void rip_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* src = reinterpret_cast<const v4f*>(x + t * NO);
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NO / 4; i++) {
+    const v4f v = src[i];
+    m = fmaxf(fmaxf(fmaxf(m, v.x), fmaxf(v.y, v.z)), v.w);
+  }
+  y[t] = m;
+}
+
+template <int NO>
+__global__ __launch_bounds__(256) void rip_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ gy, long n, float* __restrict__ gx) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* src = reinterpret_cast<const v4f*>(x + t * NO);
+  v4f* dst = reinterpret_cast<v4f*>(gx + t * NO);
+  const float m = y[t], g = gy[t];
+  v4f v[NO / 4];
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < NO / 4; i++) {
+    v[i] = src[i];
+    cnt += (v[i].x == m) + (v[i].y == m) + (v[i].z == m) + (v[i].w == m);
+  }
+  const float share = g / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+  for (int i = 0; i < NO / 4; i++)
+    dst[i] = v4f{v[i].x == m ? share : 0.f, v[i].y == m ? share : 0.f, v[i].z == m ? share : 0.f,
+                 v[i].w == m ? share : 0.f};
+}
+
+}  // namespace
+
+// x (P, C) channels-last rows with C = groups * nO, nO in {4, 8}; y (P, groups).  16-byte aligned x / gx.
+JDET_API int jdet_rip_forward(const float* x_nhwc, long P, int C, int nO, float* y_nhwc, jdet_stream_t stream) {
+  if (P < 0 || C <= 0 || (nO != 4 && nO != 8) || C % nO != 0) return JDET_E_UNSUPPORTED;
+  if (P == 0) return JDET_OK;
+  if (!x_nhwc || !y_nhwc || (((uintptr_t)x_nhwc) & 15)) return JDET_E_BADARG;
+  const long n = P * (C / nO);
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (nO == 8) hipLaunchKernelGGL(rip_fwd_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nhwc, n, y_nhwc);
+  else hipLaunchKernelGGL(rip_fwd_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nhwc, n, y_nhwc);
+  return jdet_launch_status();
+}
+
+JDET_API int jdet_rip_backward(const float* x_nhwc, const float* y_nhwc, const float* grad_y_nhwc, long P, int C,
+                               int nO, float* grad_x_nhwc, jdet_stream_t stream) {
+  if (P < 0 || C <= 0 || (nO != 4 && nO != 8) || C % nO != 0) return JDET_E_UNSUPPORTED;
+  if (P == 0) return JDET_OK;
+  if (!x_nhwc || !y_nhwc || !grad_y_nhwc || !grad_x_nhwc || ((((uintptr_t)x_nhwc) | ((uintptr_t)grad_x_nhwc)) & 15))
+    return JDET_E_BADARG;
+  const long n = P * (C / nO);
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (nO == 8)
+    hipLaunchKernelGGL(rip_bwd_kernel<8>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nhwc, y_nhwc, grad_y_nhwc, n,
+                       grad_x_nhwc);
+  else
+    hipLaunchKernelGGL(rip_bwd_kernel<4>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_nhwc, y_nhwc, grad_y_nhwc, n,
+                       grad_x_nhwc);
+  return jdet_launch_status();
+}
+
 JDET_API int jdet_version(void) { return 2; }

@@ -26,6 +26,15 @@ class LevelPack:
         for (h, w), (r0, c0) in zip(self.sizes, self.places):
             mask[:, :, r0:r0 + h, c0:c0 + w] = True
         self.mask = mask
+        self._rows = {}
+
+    def row_mask(self, batch):
+        """the mask per position of a batch, flat fp32 (batch * height * width): what the fused conv multiplies into its
+        finished rows (ops/conv_igemm: rowmask)"""
+        rows = self._rows.get(batch)
+        if rows is None:
+            rows = self._rows[batch] = self.mask.to(torch.float32).expand(batch, 1, self.height, self.width).reshape(-1).contiguous()
+        return rows
 
     @staticmethod
     def _stack(sizes):

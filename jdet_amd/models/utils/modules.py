@@ -73,6 +73,15 @@ class ConvModule(nn.Module):
             return None      # (autocast: the framework path casts per op; the fused route is fp32 only)
         return conv_igemm.conv_module(conv, x, relu)
 
+    def masked(self, x, rowmask):
+        """relu(conv(x)) * mask as one kernel (mask: 0 / 1 per position, flat) when this is a plain conv + bias + ReLU
+        module on the fused path; None otherwise"""
+        if (self.with_norm or not self.with_activation or type(self.activate) is not nn.ReLU
+                or self.order.index("conv") > self.order.index("act") or type(self.conv) is not nn.Conv2d
+                or not (x.is_cuda and x.dtype == self.conv.weight.dtype)):
+            return None
+        return conv_igemm.masked_conv_module(self.conv, x, rowmask)
+
     def forward(self, x, activate=True, norm=True):
         y = self._fused_conv_relu(x, activate)
         if y is not None:

@@ -222,10 +222,14 @@ class _ConvBiasAct(torch.autograd.Function):
     data / weight gradients (with DGRAD, for the igemm shapes: grad_x by the igemm kernel on the flipped weights)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, stride, padding, dilation, groups, igemm):
+    def forward(ctx, x, weight, bias, relu, stride, padding, dilation, groups, igemm, rowmask=None):
+        # rowmask (igemm + ReLU only): the finished rows are multiplied by a 0 / 1 mask per position (the gap rows of a
+        # LevelPack).  It needs no backward of its own: a masked row of y is 0, so the ReLU mask [y > 0] of
+        # bias_act_backward already zeroes the gradient there.
         k1 = _is_1x1(x, weight, stride, padding, groups)
         if igemm:
-            y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu).permute(0, 3, 1, 2)
+            y = conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu,
+                             rowmask).permute(0, 3, 1, 2)
         elif k1 and weight.shape[1] >= 256 and x.shape[0] * x.shape[2] * x.shape[3] <= 32768:
             # stride-1 1x1 convolution of a channels-last map = GEMM on its (positions, channels) matrix view; the
             # forward wins from 256 input channels up (scripts/conv1x1_probe.py, profiles/r04_conv1x1_probe.txt)
@@ -272,7 +276,7 @@ class _ConvBiasAct(torch.autograd.Function):
                 need[1] = False
             lx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False,
                                                             [0, 0], groups, need) if any(need) else (None, None, None)
-            return gx, (gw1 if gw1 is not None else gw), gb, None, None, None, None, None, None
+            return gx, (gw1 if gw1 is not None else gw), gb, None, None, None, None, None, None, None
         if need[0] and igemm and DGRAD and supported(weight.shape[0], weight.shape[1]):
             gx = conv3x3_nhwc(L.f32c(g.permute(0, 2, 3, 1)), dgrad_weight(weight)).permute(0, 3, 1, 2)
             need[0] = False
@@ -282,22 +286,40 @@ class _ConvBiasAct(torch.autograd.Function):
             need[1] = False
         lx, lw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False, [0, 0],
                                                         groups, need) if any(need) else (None, None, None)
-        return (gx if gx is not None else lx), (gw if own_gw else lw), gb, None, None, None, None, None, None
+        return (gx if gx is not None else lx), (gw if own_gw else lw), gb, None, None, None, None, None, None, None
 
 
 _Conv3x3BiasAct = _ConvBiasAct      # (name used by the round-3 notes)
 
 
-def conv3x3_bias_act(x, weight, bias=None, relu=False):
-    """(N, Cin, H, W) logical (channels_last memory is free) -> (N, Cout, H, W) channels_last; differentiable"""
+def conv3x3_bias_act(x, weight, bias=None, relu=False, rowmask=None):
+    """(N, Cin, H, W) logical (channels_last memory is free) -> (N, Cout, H, W) channels_last; differentiable.
+    rowmask: (N*H*W,) 0 / 1 floats multiplied into the finished rows (with relu=True and a bias when gradients flow:
+    see _ConvBiasAct)"""
     if needs_grad(x, weight, bias):
-        return _ConvBiasAct.apply(x, weight, bias, relu, (1, 1), (1, 1), (1, 1), 1, True)
+        return _ConvBiasAct.apply(x, weight, bias, relu, (1, 1), (1, 1), (1, 1), 1, True, rowmask)
+    if rowmask is not None:
+        return conv3x3_nhwc(L.f32c(x.permute(0, 2, 3, 1)), weight_krsc(weight), bias, relu, rowmask).permute(0, 3, 1, 2)
     return conv3x3(x, weight, bias, relu)
 
 
 def _is_igemm_conv(conv):
     return ((conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.groups)
             == ((3, 3), (1, 1), (1, 1), (1, 1), 1))
+
+
+def masked_conv_module(conv, x, rowmask):
+    """`relu(conv(x)) * mask` in ONE kernel for a plain 3x3 / stride 1 / pad 1 nn.Conv2d with a bias where the fused
+    kernel applies (the towers on a LevelPack); None = not applicable here, the caller multiplies."""
+    plain = (type(conv).__name__ == "Conv2d" and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
+             and not torch.is_autocast_enabled())
+    grad = needs_grad(x, conv.weight, conv.bias)
+    if not (plain and _is_igemm_conv(conv) and preferred(x, conv.weight) and (TRAIN or not grad)):
+        return None
+    if grad and not (BIAS_ACT_BWD and conv.bias is not None and conv.bias.requires_grad
+                     and _bias_bwd_supported(conv.out_channels)):
+        return None          # (the ReLU mask of the one-pass bias backward is what zeroes the masked rows' gradient)
+    return conv3x3_bias_act(x, conv.weight, conv.bias, True, rowmask)
 
 
 def conv_module(conv, x, relu=False):

@@ -4,6 +4,7 @@
 calls them)
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -88,6 +89,34 @@ def arf_indices(n_orientation, n_rotation, kernel_size):
     return idx.view(n_orientation, kH, kW, n_rotation)
 
 
+RIP_KERNEL = os.environ.get("JDET_RIP_KERNEL", "1") == "1"     # A/B switch
+
+
+class _RipFunction(torch.autograd.Function):
+    """max over the orientation channels of a channels-last map as one kernel per direction (the framework's `amax`
+    backward is an equality mask, a count, a division and a product: four passes over the 8x larger tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, nO):
+        N, C, H, W = x.shape
+        xn = x.permute(0, 2, 3, 1)                      # (N, H, W, C) contiguous view of a channels-last map
+        y = torch.empty((N, H, W, C // nO), dtype=torch.float32, device=x.device)
+        L.check(L.lib().jdet_rip_forward(L.ptr(xn), N * H * W, C, nO, L.ptr(y), L.stream_ptr(x)), "jdet_rip_forward")
+        ctx.nO = nO
+        ctx.save_for_backward(x, y)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gn = L.f32c(g.permute(0, 2, 3, 1))
+        gx = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+        L.check(L.lib().jdet_rip_backward(L.ptr(x.permute(0, 2, 3, 1)), L.ptr(y), L.ptr(gn), N * H * W, C, ctx.nO,
+                                          L.ptr(gx), L.stream_ptr(x)), "jdet_rip_backward")
+        return gx.permute(0, 3, 1, 2), None
+
+
 class RotationInvariantPooling(nn.Module):
     def __init__(self, nInputPlane, nOrientation=8):
         super().__init__()
@@ -103,6 +132,9 @@ class RotationInvariantPooling(nn.Module):
 
     def forward(self, x):
         N, c, h, w = x.shape
+        if (RIP_KERNEL and x.is_cuda and x.dtype == torch.float32 and self.nOrientation in (4, 8) and c % self.nOrientation == 0
+                and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
+            return _RipFunction.apply(x, self.nOrientation)      # one pass forward, one backward (csrc/arf.hip)
         return x.view(N, -1, self.nOrientation, h, w).amax(dim=2)
 
     execute = forward

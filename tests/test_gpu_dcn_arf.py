@@ -174,3 +174,22 @@ def test_deform_conv_fused_training_path_vs_oracle(dev, monkeypatch):
     y.sum().backward()
     ref = torch.autograd.grad(torch.nn.functional.conv2d(xs[0].detach(), conv.weight, padding=1).sum(), conv.weight)[0]
     assert torch.allclose(conv.weight.grad, ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("nO,C", [(8, 256), (4, 64)])
+def test_rotation_invariant_pooling_kernels_match_amax(dev, nO, C):
+    """RotationInvariantPooling on a channels-last map (csrc/arf.hip: jdet_rip_forward / _backward) against the
+    framework's view + amax and its gradient, ties included (half the values are rounded so that maxima repeat)."""
+    from jdet_amd.ops.orn import RotationInvariantPooling
+    g = torch.Generator().manual_seed(nO)
+    x = torch.randn(2, C, 9, 13, generator=g)
+    x[:, :, ::2] = (x[:, :, ::2] * 2).round() / 2          # ties
+    pool = RotationInvariantPooling(C, nO).to(dev)
+    xa = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xb = x.to(dev).requires_grad_(True)                    # NCHW-contiguous: the framework path
+    ya, yb = pool(xa), pool(xb)
+    assert torch.equal(ya, yb)
+    gy = torch.randn(ya.shape, generator=g).to(dev)
+    ya.backward(gy)
+    yb.backward(gy)
+    assert torch.allclose(xa.grad, xb.grad, rtol=0, atol=1e-7)
