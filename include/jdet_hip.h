@@ -345,6 +345,12 @@ int jdet_arf_forward(const float* weight, const uint8_t* indices, int nOut, int 
                      int kH, int kW, int nRot, float* out, jdet_stream_t stream);
 int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
                       int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream);
+/* the same with the expanded bank in channels-last memory (nOut*nRot, kH, kW, nIn*nOri): the layout the channels-last
+ * convolution reads (the library otherwise converts the bank inside every forward / gradient call) */
+int jdet_arf_forward_cl(const float* weight, const uint8_t* indices, int nOut, int nIn, int nOri, int kH, int kW,
+                        int nRot, float* out_cl, jdet_stream_t stream);
+int jdet_arf_backward_cl(const uint8_t* indices, const float* grad_out_cl, int nOut, int nIn, int nOri, int kH, int kW,
+                         int nRot, float* grad_weight, jdet_stream_t stream);
 
 /* RotationInvariantPooling (orn.py:L595-618: `x.view(N, -1, nOrientation, h, w).max(2)`) on channels-last rows:
  * x (P, C) with C = groups * nO (nO 4 or 8), y (P, groups) = max over each group's nO orientation channels; backward

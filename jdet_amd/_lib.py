@@ -72,6 +72,8 @@ SIGNATURES = {
     "jdet_bias_act_backward": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _sz, _p]),
     "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
+    "jdet_arf_forward_cl": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
+    "jdet_arf_backward_cl": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_rip_forward": (_i, [_p, _l, _i, _i, _p, _p]),
     "jdet_rip_backward": (_i, [_p, _p, _p, _l, _i, _i, _p, _p]),
     "jdet_delta2bbox_rotated": (_i, [_p, _p, _i, _i, _p, _p, _f, _p, _p]),

@@ -9,12 +9,17 @@ namespace {
 
 struct ArfShape {
   int nIn, nEntry, nRot;   // nEntry = nOri * kH * kW
+  int ks, cl;              // kH * kW; cl: the expanded filter bank in channels-last memory (Cout, kH, kW, Cin)
 };
 
 // destination element of source element (i, j, l) under rotation k
 __device__ __forceinline__ size_t arf_dst(const ArfShape& s, const uint8_t* __restrict__ indices, int i, int j, int l,
                                           int k) {
   const int m = (int)indices[l * s.nRot + k] - 1;
+  if (s.cl) {   // (co, h, w, ci) with ci = j * nOri + orientation plane of m
+    const int lo = m / s.ks, hw = m - lo * s.ks, nOri = s.nEntry / s.ks;
+    return ((size_t)(i * s.nRot + k) * s.ks + hw) * ((size_t)s.nIn * nOri) + (size_t)j * nOri + lo;
+  }
   return ((size_t)(i * s.nRot + k) * s.nIn + j) * s.nEntry + m;
 }
 
@@ -38,12 +43,12 @@ __global__ __launch_bounds__(256) void arf_kernel(long n, const float* __restric
 }
 
 int arf_launch(bool backward, const float* src, const uint8_t* indices, int nOut, int nIn, int nOri, int kH, int kW,
-               int nRot, float* dst, hipStream_t st) {
+               int nRot, float* dst, hipStream_t st, bool cl = false) {
   if (nOut < 0 || nIn < 0 || nOri <= 0 || kH <= 0 || kW <= 0 || nRot <= 0) return JDET_E_BADARG;
   const long n = (long)nOut * nIn * nOri * kH * kW;
   if (n == 0) return JDET_OK;
   if (!src || !indices || !dst) return JDET_E_BADARG;
-  ArfShape s{nIn, nOri * kH * kW, nRot};
+  ArfShape s{nIn, nOri * kH * kW, nRot, kH * kW, cl ? 1 : 0};
   long g = (n + 255) / 256;
   if (g > 262144) g = 262144;
   if (backward)
@@ -63,6 +68,18 @@ JDET_API int jdet_arf_forward(const float* weight, const uint8_t* indices, int n
 JDET_API int jdet_arf_backward(const uint8_t* indices, const float* grad_out, int nOut, int nIn, int nOri,
                                int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream) {
   return arf_launch(true, grad_out, indices, nOut, nIn, nOri, kH, kW, nRot, grad_weight, (hipStream_t)stream);
+}
+
+// the same with the expanded filter bank (forward: out, backward: grad_out) in channels-last memory (Cout, kH, kW, Cin):
+// what the channels-last convolution wants -- the library otherwise converts the bank on every call
+JDET_API int jdet_arf_forward_cl(const float* weight, const uint8_t* indices, int nOut, int nIn, int nOri, int kH,
+                                 int kW, int nRot, float* out_cl, jdet_stream_t stream) {
+  return arf_launch(false, weight, indices, nOut, nIn, nOri, kH, kW, nRot, out_cl, (hipStream_t)stream, true);
+}
+
+JDET_API int jdet_arf_backward_cl(const uint8_t* indices, const float* grad_out_cl, int nOut, int nIn, int nOri,
+                                  int kH, int kW, int nRot, float* grad_weight, jdet_stream_t stream) {
+  return arf_launch(true, grad_out_cl, indices, nOut, nIn, nOri, kH, kW, nRot, grad_weight, (hipStream_t)stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -5,7 +5,11 @@ The dense heads apply the SAME conv towers to every FPN level.  On the small lev
 launch whatever the map size -- and every level adds its own data-gradient, weight-gradient and gradient-accumulation
 launches.  `LevelPack` places such levels in one tensor; a tower then costs one launch per layer for all of them.
 """
+import os
+
 import torch
+
+PACK_FUNCTIONS = os.environ.get("JDET_PACK_FUNCTIONS", "1") == "1"      # A/B switch (see _Pack / _Unpack)
 
 
 class LevelPack:
@@ -81,17 +85,63 @@ class LevelPack:
             cls._cache[key] = cls(sizes, device)
         return cls._cache[key]
 
+    def _canvas(self, like, channels):
+        cl = like.dim() == 4 and like.is_contiguous(memory_format=torch.channels_last)
+        return torch.empty((like.shape[0], channels, self.height, self.width), dtype=like.dtype, device=like.device,
+                           memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
+
+    def _slices(self, y):
+        return [y[:, :, r0:r0 + h, c0:c0 + w] for (h, w), (r0, c0) in zip(self.sizes, self.places)]
+
     def pack(self, xs):
-        x0 = xs[0]
-        cl = x0.dim() == 4 and x0.is_contiguous(memory_format=torch.channels_last)
-        out = torch.empty((x0.shape[0], x0.shape[1], self.height, self.width), dtype=x0.dtype, device=x0.device,
-                          memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
+        if PACK_FUNCTIONS and torch.is_grad_enabled() and any(x.requires_grad for x in xs):
+            return _Pack.apply(self, *xs)
+        out = self._canvas(xs[0], xs[0].shape[1])
         for x, (h, w), (r0, c0) in zip(xs, self.sizes, self.places):
             out[:, :, r0:r0 + h, c0:c0 + w] = x
         return out
 
     def unpack(self, y):
-        return [y[:, :, r0:r0 + h, c0:c0 + w] for (h, w), (r0, c0) in zip(self.sizes, self.places)]
+        if PACK_FUNCTIONS and torch.is_grad_enabled() and y.requires_grad:
+            return list(_Unpack.apply(self, y))
+        return self._slices(y)
+
+
+class _Pack(torch.autograd.Function):
+    """canvas of zeros + one copy per level; backward: the levels' windows of the canvas gradient (views).  (Written
+    as slice assignments the framework records a CopySlices node per level, each with its own backward launches.)"""
+
+    @staticmethod
+    def forward(ctx, pack, *xs):
+        ctx.pack = pack
+        out = pack._canvas(xs[0], xs[0].shape[1])
+        for x, dst in zip(xs, pack._slices(out)):
+            dst.copy_(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(ctx.pack._slices(g))
+
+
+class _Unpack(torch.autograd.Function):
+    """the levels' windows of a packed tensor (views); backward: ONE zero canvas + one copy per level -- the
+    framework's slice backward builds a full zero canvas PER level and then adds the canvases up"""
+
+    @staticmethod
+    def forward(ctx, pack, y):
+        ctx.pack = pack
+        ctx.like = y
+        return tuple(pack._slices(y))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        y = ctx.like
+        g = ctx.pack._canvas(y, y.shape[1])
+        for gl, dst in zip(grads, ctx.pack._slices(g)):
+            if gl is not None:
+                dst.copy_(gl)
+        return None, g
 
 
 def run_levels(feats, fn, max_positions=1024):

@@ -59,6 +59,36 @@ class _ActiveRotatingFilter(torch.autograd.Function):
 
 active_rotating_filter = _ActiveRotatingFilter.apply
 
+
+class _ActiveRotatingFilterCL(torch.autograd.Function):
+    """the expanded filter bank written straight in channels-last memory (and its gradient read from it): a
+    channels-last convolution then takes the bank as it is -- the library converted a contiguous one inside the
+    forward, the data gradient and the weight gradient of every call"""
+
+    @staticmethod
+    def forward(ctx, input, indices):
+        L.need_device(input, indices)
+        w, idx = input.contiguous(), indices.contiguous()
+        nOut, nIn, nOri, kH, kW = w.shape
+        nRot = idx.shape[3]
+        out = torch.empty((nOut * nRot, kH, kW, nIn * nOri), dtype=torch.float32, device=w.device)
+        L.check(L.lib().jdet_arf_forward_cl(L.ptr(w), L.ptr(idx), nOut, nIn, nOri, kH, kW, nRot, L.ptr(out),
+                                            L.stream_ptr(w)), "jdet_arf_forward_cl")
+        ctx.save_for_backward(idx)
+        ctx.wshape = tuple(w.shape)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (idx,) = ctx.saved_tensors
+        nOut, nIn, nOri, kH, kW = ctx.wshape
+        nRot = idx.shape[3]
+        g = L.f32c(grad_output.permute(0, 2, 3, 1))       # free when the gradient is channels-last
+        gw = torch.empty(ctx.wshape, dtype=torch.float32, device=g.device)
+        L.check(L.lib().jdet_arf_backward_cl(L.ptr(idx), L.ptr(g), nOut, nIn, nOri, kH, kW, nRot, L.ptr(gw),
+                                             L.stream_ptr(g)), "jdet_arf_backward_cl")
+        return gw, None
+
 # which source tap (1-based) feeds each tap of a 3x3 / 1x1 kernel rotated by k*45 degrees
 _KERNEL_INDICES = {
     1: {a: (1,) for a in range(0, 360, 45)},
@@ -90,6 +120,7 @@ def arf_indices(n_orientation, n_rotation, kernel_size):
 
 
 RIP_KERNEL = os.environ.get("JDET_RIP_KERNEL", "1") == "1"     # A/B switch
+ARF_CL = os.environ.get("JDET_ARF_CL", "1") == "1"             # A/B switch
 
 
 class _RipFunction(torch.autograd.Function):
@@ -162,10 +193,13 @@ class ORConv2d(nn.Conv2d):
             n *= k
         nn.init.normal_(self.weight, 0, math.sqrt(2.0 / n))
 
-    def rotate_arf(self):
+    def rotate_arf(self, channels_last=False):
+        if ARF_CL and channels_last and self.weight.is_cuda and self.weight.dtype == torch.float32:
+            return _ActiveRotatingFilterCL.apply(self.weight, self.indices)
         return active_rotating_filter(self.weight, self.indices)
 
     def forward(self, input):
-        return F.conv2d(input, self.rotate_arf(), self.bias, self.stride, self.padding, self.dilation, self.groups)
+        cl = input.dim() == 4 and input.is_cuda and input.is_contiguous(memory_format=torch.channels_last)
+        return F.conv2d(input, self.rotate_arf(cl), self.bias, self.stride, self.padding, self.dilation, self.groups)
 
     execute = forward

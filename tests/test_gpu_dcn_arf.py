@@ -193,3 +193,26 @@ def test_rotation_invariant_pooling_kernels_match_amax(dev, nO, C):
     ya.backward(gy)
     yb.backward(gy)
     assert torch.allclose(xa.grad, xb.grad, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("arf_config,k", [((1, 8), 3), ((8, 8), 3), ((4, 4), 1)])
+def test_orconv_channels_last_bank_equals_the_contiguous_one(dev, arf_config, k):
+    """ORConv2d on a channels-last map expands its filters straight into channels-last memory (jdet_arf_forward_cl) and
+    reads the bank's gradient from that layout (jdet_arf_backward_cl): same output and gradients as the contiguous bank
+    (the values are copies, the weight gradient a sum of the same copies in the same order: bit-equal)."""
+    from jdet_amd.ops.orn import ORConv2d, active_rotating_filter
+    torch.manual_seed(3)
+    nOri = arf_config[0]
+    conv = ORConv2d(2 * nOri, 3, kernel_size=k, padding=k // 2, arf_config=arf_config).to(dev)
+    bank = active_rotating_filter(conv.weight, conv.indices)
+    bank_cl = conv.rotate_arf(channels_last=True)
+    assert bank_cl.is_contiguous(memory_format=torch.channels_last) or k == 1
+    assert torch.equal(bank, bank_cl)
+    gb = torch.randn_like(bank)
+    (g0,) = torch.autograd.grad(bank, conv.weight, gb)
+    (g1,) = torch.autograd.grad(bank_cl, conv.weight, gb.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(g0, g1)
+    x = torch.randn(2, conv.in_channels * nOri, 7, 9, device=dev)
+    y_cl = conv(x.contiguous(memory_format=torch.channels_last))
+    y = conv(x)
+    assert torch.allclose(y_cl, y, atol=1e-5)
