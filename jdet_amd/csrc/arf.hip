@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256) void rip_fwd_kernel(const float* __restrict__ 
   typedef float v4f __attribute__((ext_vector_type(4)));
   const v4f* src = reinterpret_cast<const v4f*>(x + t * NO);
   float m = -INFINITY;
+  bool nan = false;                 // amax propagates NaN (fmaxf drops it): a diverged map must surface as NaN losses
 #pragma unroll
   for (int i = 0; i < NO / 4; i++) {
     const v4f v = src[i];
     m = fmaxf(fmaxf(fmaxf(m, v.x), fmaxf(v.y, v.z)), v.w);
+    nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
   }
-  y[t] = m;
+  y[t] = nan ? __builtin_nanf("") : m;
 }
 
 template <int NO>
@@ -120,6 +122,11 @@ __global__ __launch_bounds__(256) void rip_bwd_kernel(const float* __restrict__ 
     cnt += (v[i].x == m) + (v[i].y == m) + (v[i].z == m) + (v[i].w == m);
   }
   const float share = g / (float)(cnt > 0 ? cnt : 1);
+  if (m != m) {                     // NaN maximum: the gradient is NaN on the whole group, as amax's backward gives
+#pragma unroll
+    for (int i = 0; i < NO / 4; i++) dst[i] = v4f{m, m, m, m};
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NO / 4; i++)
     dst[i] = v4f{v[i].x == m ? share : 0.f, v[i].y == m ? share : 0.f, v[i].z == m ? share : 0.f,

@@ -37,6 +37,8 @@ class LevelPack:
         finished rows (ops/conv_igemm: rowmask)"""
         rows = self._rows.get(batch)
         if rows is None:
+            while len(self._rows) >= 4:
+                self._rows.pop(next(iter(self._rows)))
             rows = self._rows[batch] = self.mask.to(torch.float32).expand(batch, 1, self.height, self.width).reshape(-1).contiguous()
         return rows
 
@@ -77,18 +79,26 @@ class LevelPack:
         return places if area(places) < area(stacked) else stacked
 
     _cache = {}
+    CACHE_MAX = 32          # distinct (level sizes, device) layouts kept (multi-scale training cycles through a few)
 
     @classmethod
     def cached(cls, sizes, device):
         key = (tuple(tuple(s) for s in sizes), str(device))
-        if key not in cls._cache:
-            cls._cache[key] = cls(sizes, device)
-        return cls._cache[key]
+        hit = cls._cache.pop(key, None)
+        if hit is None:
+            hit = cls(sizes, device)
+            while len(cls._cache) >= cls.CACHE_MAX:          # least recently used first (dict order = recency)
+                cls._cache.pop(next(iter(cls._cache)))
+        cls._cache[key] = hit
+        return hit
 
     def _canvas(self, like, channels):
         cl = like.dim() == 4 and like.is_contiguous(memory_format=torch.channels_last)
-        return torch.empty((like.shape[0], channels, self.height, self.width), dtype=like.dtype, device=like.device,
-                           memory_format=torch.channels_last if cl else torch.contiguous_format).zero_()
+        return self._canvas_like(like.shape[0], channels, like.dtype, like.device, cl)
+
+    def _canvas_like(self, batch, channels, dtype, device, channels_last):
+        return torch.empty((batch, channels, self.height, self.width), dtype=dtype, device=device,
+                           memory_format=torch.channels_last if channels_last else torch.contiguous_format).zero_()
 
     def _slices(self, y):
         return [y[:, :, r0:r0 + h, c0:c0 + w] for (h, w), (r0, c0) in zip(self.sizes, self.places)]
@@ -131,13 +141,14 @@ class _Unpack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pack, y):
         ctx.pack = pack
-        ctx.like = y
+        # only what the backward's canvas needs (keeping `y` itself would hold every head output's canvas until then)
+        ctx.like = (y.shape, y.dtype, y.device, y.is_contiguous(memory_format=torch.channels_last))
         return tuple(pack._slices(y))
 
     @staticmethod
     def backward(ctx, *grads):
-        y = ctx.like
-        g = ctx.pack._canvas(y, y.shape[1])
+        shape, dtype, device, cl = ctx.like
+        g = ctx.pack._canvas_like(shape[0], shape[1], dtype, device, cl)
         for gl, dst in zip(grads, ctx.pack._slices(g)):
             if gl is not None:
                 dst.copy_(gl)

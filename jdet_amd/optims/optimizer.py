@@ -33,6 +33,7 @@ class SGD(torch.optim.SGD):
             params = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
             norm_type = float(self.grad_clip.get("norm_type", 2))
             fused = self.fused_step and all(g.get("fused") for g in self.param_groups)   # (a loaded state may say otherwise)
+            fused = fused and self._seed_late_momentum()
             if fused and params and norm_type == 2.0 and not any(p.grad.is_sparse for p in params):
                 # clip_grad_norm_'s coefficient (same formula), applied inside the update kernel: it DIVIDES the
                 # gradients by `grad_scale` (and writes them back), so the scale is the reciprocal
@@ -46,7 +47,31 @@ class SGD(torch.optim.SGD):
                     del self.grad_scale
             torch.nn.utils.clip_grad_norm_(params, max_norm=self.grad_clip["max_norm"], norm_type=norm_type,
                                            foreach=True)
+        elif self.fused_step:
+            self._seed_late_momentum()
         super().step()
+
+    def _seed_late_momentum(self):
+        """torch's fused multi-tensor SGD takes "no momentum buffer yet" as a property of the whole group: a parameter
+        whose FIRST gradient arrives after the others already hold buffers (a conditionally used branch, a partial
+        state resume) makes it raise.  Such a parameter gets a zero buffer here -- `momentum * 0 + d` is the first-step
+        rule `buf = d` when dampening is 0; with dampening the group drops to the foreach form, which seeds per tensor.
+        Returns whether every group can still take the fused kernel."""
+        ok = True
+        for g in self.param_groups:
+            if not g.get("fused") or g["momentum"] == 0:
+                continue
+            with_grad = [p for p in g["params"] if p.grad is not None]
+            late = [p for p in with_grad if self.state[p].get("momentum_buffer") is None]
+            if not late or len(late) == len(with_grad):
+                continue
+            if g["dampening"] == 0:
+                for p in late:
+                    self.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            else:
+                g["fused"], g["foreach"] = False, True
+                ok = False
+        return ok
 
     def cur_lr(self):
         return self.param_groups[0].get("lr", self.lr)

@@ -53,3 +53,52 @@ def test_state_round_trip_keeps_the_step_form():
     opt.step((p ** 2).sum())
     opt2.step((q ** 2).sum())
     assert torch.allclose(p.detach(), q.detach())
+
+
+def _force_fused(opt):
+    """host parameters default to the foreach form; torch's fused kernel also runs on the host, which lets the
+    fused + clip path (device default) be pinned without a GPU"""
+    opt.fused_step = True
+    for g in opt.param_groups:
+        g["fused"], g["foreach"] = True, False
+    return opt
+
+
+def test_fused_clip_step_equals_foreach_with_a_late_first_gradient():
+    """a parameter whose first gradient arrives at step 2 (torch's fused SGD raises on the mixed None / tensor momentum
+    list): seeded with a zero buffer, and the whole fused + grad_scale update equals clip_grad_norm_ + foreach"""
+    torch.manual_seed(2)
+    init = [torch.randn(6, 4), torch.randn(5), torch.randn(3)]
+    pa = [torch.nn.Parameter(t.clone()) for t in init]
+    pb = [torch.nn.Parameter(t.clone()) for t in init]
+    kw = dict(lr=0.05, momentum=0.9, weight_decay=1e-2, grad_clip=dict(max_norm=0.3, norm_type=2))
+    fused, plain = _force_fused(SGD(pa, **kw)), SGD(pb, **kw)
+    assert not plain.fused_step
+    for step in range(4):
+        x = torch.randn(6, 4)
+
+        def loss(ps):
+            out = (ps[0] * x).sum() * 2 + (ps[1] ** 2).sum()
+            if step >= 1:                       # ps[2] takes part from the second step on
+                out = out + (ps[2] ** 3).sum() * (step + 1)
+            return out
+        fused.step(loss(pa))
+        plain.step(loss(pb))
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a.detach(), b.detach(), rtol=1e-6, atol=1e-7), step
+    assert all(g["fused"] for g in fused.param_groups)
+
+
+def test_late_gradient_with_dampening_drops_to_foreach():
+    torch.manual_seed(3)
+    init = [torch.randn(4), torch.randn(3)]
+    pa = [torch.nn.Parameter(t.clone()) for t in init]
+    pb = [torch.nn.Parameter(t.clone()) for t in init]
+    kw = dict(lr=0.1, momentum=0.8, dampening=0.5, grad_clip=dict(max_norm=10.0, norm_type=2))
+    fused, plain = _force_fused(SGD(pa, **kw)), SGD(pb, **kw)
+    for step in range(3):
+        fused.step((pa[0] ** 2).sum() + ((pa[1] ** 2).sum() if step else 0))
+        plain.step((pb[0] ** 2).sum() + ((pb[1] ** 2).sum() if step else 0))
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a.detach(), b.detach(), rtol=1e-6, atol=1e-7), step
+    assert not fused.param_groups[0]["fused"]
