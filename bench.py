@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"])
     p.add_argument("--rois", type=int, default=2000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="leave out the `secondary` object (ms/step of the other BASELINE.json model configs)")
     a = p.parse_args()
     if a.batch is None:
         a.batch = 4 if a.workload == "roitrans_train" else 2      # configs[4]: batch 32 over 8 GPUs
@@ -370,16 +372,81 @@ def timed(step, steps, warmup, dist, dev):
     return t, dev_ms
 
 
-def roofline_obj(workload, nbytes, dev_ms, kname):
+_COPY_PEAK = {}
+
+
+def measured_copy_peak(dev, gib=1, reps=20):
+    """HBM rate of THIS device, measured on the lease: a device-to-device copy of `gib` GiB (far beyond the 256 MB
+    Infinity Cache), `reps` timed repetitions between HIP events; GB/s = (bytes read + bytes written) / time.  The
+    denominator SURVEY 8(d) / BASELINE.md 3 prescribe next to the datasheet's 8 TB/s."""
+    key = (dev.index, gib, reps)
+    if key not in _COPY_PEAK:
+        n = gib * (1 << 30) // 4
+        src = torch.empty((n,), dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        _COPY_PEAK[key] = 2.0 * n * 4 * reps / 1e9 / (e0.elapsed_time(e1) / 1e3)
+        del src, dst
+        torch.cuda.empty_cache()
+    return _COPY_PEAK[key]
+
+
+def roofline_obj(workload, nbytes, dev_ms, kname, dev=None):
     ach = nbytes / 1e9 / (dev_ms / 1e3)
-    traffic = None
-    try:  # PMC HBM bytes per launch from the last committed rocprofv3 counter passes
+    traffic, source = None, None
+    try:  # PMC bytes per launch from the last committed rocprofv3 counter passes (NOT measured in this run)
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             traffic = json.load(f).get(workload, {}).get("traffic_bytes")
+            source = ("profiles/hbm_traffic.json (committed rocprofv3 --pmc passes, not live; the timed loop re-reads one "
+                      "67 MB map, which stays in the 256 MB Infinity Cache: the counted reads beyond the L2 are fabric / "
+                      "MALL reads, an upper bound of the HBM reads)")
     except OSError:
         pass
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-            "traffic": traffic, "kernel": kname, "kernel_ms": dev_ms, "algorithmic_bytes": nbytes}
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+           "traffic": traffic, "traffic_source": source, "kernel": kname, "kernel_ms": dev_ms,
+           "algorithmic_bytes": nbytes}
+    if dev is not None:
+        try:
+            out["peak_measured"] = measured_copy_peak(dev)
+            out["peak_measured_how"] = "device-to-device copy of 1 GiB, 20 repetitions, (read + write) bytes / HIP-event time, this run"
+            out["frac_of_measured"] = ach / out["peak_measured"]
+        except RuntimeError as e:       # (out of memory on a crowded device: the datasheet fraction stands alone)
+            out["peak_measured"] = None
+            out["peak_measured_how"] = "failed: %s" % str(e)[:120]
+    return out
+
+
+def secondary_lines(a, dev):
+    """ms/step of the other model configurations of BASELINE.json -- configs[1] RetinaNet-OBB inference, configs[3]
+    Oriented R-CNN train step, configs[4] RoI-Transformer R101 train step (4 images) -- 10 timed steps each after the
+    headline run, so that the driver's own run witnesses them; an entry that fails reports the error, not the line."""
+    out = {}
+    for wl, batch, steps, warmup in (("retinanet_infer", 1, 10, 5), ("orcnn_train", 2, 10, 6),
+                                     ("roitrans_train", 4, 10, 6)):
+        b = argparse.Namespace(**vars(a))
+        b.workload, b.batch, b.steps, b.warmup = wl, batch, steps, warmup
+        try:
+            t0 = time.perf_counter()
+            step, keep = make_train(b, 0, dev) if wl in TRAIN_WORKLOADS else make_retinanet_infer(b, 0, dev)
+            t, _ = timed(step, steps, warmup, None, dev)
+            out[wl] = {"ms_per_step": 1e3 * t / steps, "img_per_s": batch * steps / t, "batch": batch, "steps": steps,
+                       "warmup": warmup, "tile": "%dx%d" % (a.size, a.size), "dtype": "f32",
+                       "setup_and_run_s": round(time.perf_counter() - t0, 1)}
+            del step, keep
+        except Exception as e:      # noqa: BLE001 -- reported in the line
+            out[wl] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    return out
 
 
 def launch_command(argv, gpus, port=None):
@@ -479,11 +546,17 @@ def main():
             d = make_inputs("roi_align_rotated", a.rois, 1000, dev)
             rstep, _, _, nbytes, kname, _ = make_step("roi_align_rotated", d)
             _, rms = timed(rstep, 200, 20, None, dev)
-            line["roofline"] = roofline_obj("roi_align_rotated", nbytes, rms, kname)
+            line["roofline"] = roofline_obj("roi_align_rotated", nbytes, rms, kname, dev)
             if world == 1 and not a.no_cpu_baseline:
                 cb = cpu_baseline("roi_align_rotated", d, a.rois)
                 cb["sample"] = "rotated RoIAlign forward leg (the roofline kernel), not the whole train step: " + cb["sample"]
                 line["cpu_baseline"] = cb
+            if world == 1 and a.workload == "s2anet_train" and a.amp == "none" and not a.no_secondary:
+                del step, runner, rstep, d
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                line["secondary"] = secondary_lines(a, dev)
             print(json.dumps(line))
     else:
         d = make_inputs(a.workload, a.rois, 1000 + rank, dev)
@@ -503,7 +576,7 @@ def main():
                            "pooled": "7x7", "sampling_ratio": 2, "spatial_scale": 0.25,
                            "parallelism": "image-parallel x%d (no collective)" % world},
             }
-            line["roofline"] = roofline_obj(a.workload, nbytes, dev_ms, kname)
+            line["roofline"] = roofline_obj(a.workload, nbytes, dev_ms, kname, dev)
             if world == 1 and not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)
             print(json.dumps(line))

@@ -8,7 +8,7 @@ timeout 1500 python -m pytest $1 -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pyte
 tail -4 $OUT/pytest.log
 shift
 for wl in "$@"; do
-  timeout 400 python bench.py --workload $wl --steps 10 --warmup 5 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+  timeout 400 python bench.py --workload $wl --steps 10 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   python - <<PY
 import json
 try:

@@ -8,7 +8,7 @@ i=0
 cd /tmp
 for e in "$@"; do
   i=$((i+1))
-  env $e timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $OUT/p$i -o t -- python $OLDPWD/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p$i.log 2>&1
+  env $e timeout 300 rocprofv3 --pmc $pmc --output-format csv -d $OUT/p$i -o t -- python $OLDPWD/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p$i.log 2>&1
   python - <<PY
 import csv,glob,collections
 for f in sorted(glob.glob("$OUT/p$i/**/*counter_collection.csv",recursive=True)):

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 i=0
 for e in "$@"; do
   i=$((i+1))
-  env $e timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/e$i -o t -- python bench.py --workload roi_align_rotated --no-cpu-baseline --steps 50 > $OUT/e$i.log 2>&1
+  env $e timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/e$i -o t -- python bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/e$i.log 2>&1
   python - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/e$i/**/*kernel_trace.csv",recursive=True)

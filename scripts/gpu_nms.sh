@@ -3,7 +3,7 @@ set -u
 OUT=$PWD/gpurun_out/r3_nms; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_iou_nms.py tests/test_gpu_poly.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o t -- python bench.py --workload nms_rotated --no-cpu-baseline --steps 50 > $OUT/bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o t -- python bench.py --workload nms_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/bench.log 2>&1
 python - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/t/**/*kernel_trace.csv",recursive=True)

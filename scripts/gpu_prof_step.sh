@@ -4,7 +4,7 @@ set -u
 WL=$1; MARK=$2; PER=$3
 R=$PWD; OUT=$R/gpurun_out/prof_$WL; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $R/bench.py --workload $WL --steps 8 --warmup 4 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $R/bench.py --workload $WL --steps 8 --warmup 4 --no-cpu-baseline --no-secondary > $OUT/trace.log 2>&1
 cd $R
 f=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
 python scripts/steady_state.py $f $MARK $PER 4 120 | cut -c1-220 > $OUT/steady_state.txt

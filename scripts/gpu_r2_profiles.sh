@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-600
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $OUT/trace_default.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_default -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-secondary > $OUT/trace_default.log 2>&1
 cd $R
 f=$(find $OUT/trace_default -name '*kernel_trace.csv' | head -1)
 python scripts/steady_state.py $f assign_anchor_kernel 4 5 > $OUT/steady_state_s2anet.txt 2>&1
@@ -26,7 +26,7 @@ rm -rf $OUT/pmc_fwd/trace $OUT/pmc_fwd/pmc_*
 # kernel stats of the other hand-written kernels
 for wl in roi_align_rotated_bwd box_iou_rotated nms_rotated; do
   cd /tmp
-  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$wl -o t -- python $R/bench.py --workload $wl --no-cpu-baseline > $OUT/trace_$wl.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_$wl -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary > $OUT/trace_$wl.log 2>&1
   cd $R
   k=$(find $OUT/trace_$wl -name '*kernel_stats.csv' | head -1)
   [ -n "$k" ] && head -12 $k | cut -c1-200 > $OUT/kernel_stats_$wl.csv
@@ -36,7 +36,7 @@ done
 # backward traffic
 for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp
-  timeout 300 rocprofv3 --pmc $c -f csv -d $OUT/pmc_bwd_$c -o p -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 5 --warmup 2 > $OUT/pmc_bwd_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c -f csv -d $OUT/pmc_bwd_$c -o p -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --no-secondary --steps 5 --warmup 2 > $OUT/pmc_bwd_$c.log 2>&1
   cd $R
 done
 python scripts/summarize_prof.py $OUT > $OUT/pmc_bwd_summary.txt 2>&1 || true
@@ -55,7 +55,7 @@ rm -rf $OUT/pmc_bwd_FETCH_SIZE $OUT/pmc_bwd_WRITE_SIZE
 cd /tmp
 for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
-  timeout 900 rocprofv3 --pmc $c -f csv -d $OUT/mfma_$n -o p -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $OUT/mfma_$n.log 2>&1 || echo "pmc $c failed"
+  timeout 900 rocprofv3 --pmc $c -f csv -d $OUT/mfma_$n -o p -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/mfma_$n.log 2>&1 || echo "pmc $c failed"
 done
 cd $R
 python - <<PY

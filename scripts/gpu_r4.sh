@@ -12,7 +12,7 @@ timeout 900 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_frozen_b
 echo "pytest rc=$?"; tail -4 $OUT/pytest.log
 trace() {  # $1 = tag, rest = env
   tag=$1; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -31,7 +31,7 @@ trace b16 JDET_ROI_SLICED_BATCH=16
 trace legacy JDET_ROI_FWD_LEGACY=1
 pmc() {  # $1 = tag, $2 = counters, rest = env
   tag=$1; c=$2; shift; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 for f in sorted(glob.glob("$OUT/p_$tag/**/*counter_collection.csv",recursive=True)):
@@ -48,7 +48,7 @@ pmc fetch "FETCH_SIZE" A=1
 pmc write "WRITE_SIZE" A=1
 pmc tcp "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" A=1
 pmc sq "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD" A=1
-timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
+timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-400
 # two ranks on one device, graph mode, probes at every hand-over (scripts/ddp_graph_diag.py)
 timeout 900 python scripts/ddp_graph_diag.py orcnn 9 4 > $OUT/ddp_diag.log 2>&1
 grep -E "^== run|RESULT|DISAGREE|GARBAGE|Error|error" $OUT/ddp_diag.log | cut -c1-400 | head -40
@@ -61,7 +61,7 @@ OUT=$R/gpurun_out/r4_d; mkdir -p $OUT
 export TMPDIR=/tmp
 trace() {  # $1 = tag, rest = env
   tag=$1; shift
-  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -83,7 +83,7 @@ trace planar_w16 JDET_ROI_FWD_SLICED=1 JDET_ROI_SLICED_PLANAR=1 JDET_ROI_SLICED_
 trace legacy A=1
 pmc() {  # $1 = tag, $2 = counters, rest = env
   tag=$1; c=$2; shift; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 for f in sorted(glob.glob("$OUT/p_$tag/**/*counter_collection.csv",recursive=True)):
@@ -113,7 +113,7 @@ timeout 600 python -m pytest tests/test_gpu_reference_kernels.py -x -q -k "roi" 
 echo "pytest ref rc=$?"; tail -3 $OUT/pytest_ref.log
 trace() {  # $1 = tag, $2 = workload, rest = env
   tag=$1; wl=$2; shift; shift
-  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -130,7 +130,7 @@ trace bwd4 roi_align_rotated_bwd A=1
 trace bwd2 roi_align_rotated_bwd JDET_ROI_BWD_PATCH=2
 trace riroi riroi_align A=1
 trace fwd roi_align_rotated A=1
-for wl in roi_align_rotated_bwd riroi_align roi_align_rotated; do timeout 120 python bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["config"]["workload"], round(d["ms_per_step"]*1000,1),"us/step frac", round(d["roofline"]["frac"],3))'; done
+for wl in roi_align_rotated_bwd riroi_align roi_align_rotated; do timeout 120 python bench.py --workload $wl --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["config"]["workload"], round(d["ms_per_step"]*1000,1),"us/step frac", round(d["roofline"]["frac"],3))'; done
 }
 
 run_f() {
@@ -143,7 +143,7 @@ timeout 1500 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_closed_
 echo "pytest rc=$?"; tail -4 $OUT/pytest.log
 trace() {  # $1 = tag, $2 = workload, rest = env
   tag=$1; wl=$2; shift; shift
-  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env JDET_BENCH_CHECKSUM=1 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -158,7 +158,7 @@ PY
 }
 trace bwd roi_align_rotated_bwd A=1
 trace riroi riroi_align A=1
-for wl in roi_align_rotated_bwd riroi_align roi_align_rotated; do timeout 120 python bench.py --workload $wl --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["config"]["workload"], round(d["ms_per_step"]*1000,1),"us/step frac", round(d["roofline"]["frac"],3))'; done
+for wl in roi_align_rotated_bwd riroi_align roi_align_rotated; do timeout 120 python bench.py --workload $wl --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["config"]["workload"], round(d["ms_per_step"]*1000,1),"us/step frac", round(d["roofline"]["frac"],3))'; done
 # the reference's own RoIAlign kernels on this GPU (kernel durations from the trace)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_refk -o t -- python $R/scripts/refk_diag.py --time > $OUT/refk_time.log 2>&1)
 tail -3 $OUT/refk_time.log
@@ -171,7 +171,7 @@ for r in csv.DictReader(open(f[0])):
 for k,v in sorted(d.items(), key=lambda kv:-sum(kv[1])):
     if len(v)>=10: print("  %-90s n=%d avg %.1f us"%(k,len(v),sum(v[2:])/len(v[2:])))
 PY
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet", d["value"], "img/s", d["ms_per_step"], "ms; roofline", d["roofline"]["frac"], d["roofline"]["kernel_ms"])'
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet", d["value"], "img/s", d["ms_per_step"], "ms; roofline", d["roofline"]["frac"], d["roofline"]["kernel_ms"])'
 for i in 1 2; do timeout 600 python -m pytest tests/test_gpu_ddp_detectors.py -q -k "graph" --runxfail > $OUT/ddp_$i.log 2>&1; tail -1 $OUT/ddp_$i.log; grep -E "^FAILED|AssertionError|replicas diverged" $OUT/ddp_$i.log | cut -c1-600 | head -6; done
 }
 
@@ -186,7 +186,7 @@ export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-900
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $OUT/trace_default.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-secondary > $OUT/trace_default.log 2>&1)
 f=$(find $OUT/trace_default -name '*kernel_trace.csv' | head -1)
 python scripts/steady_state.py $f assign_anchor_kernel 4 5 120 > $OUT/steady_state_s2anet.txt 2>&1
 head -3 $OUT/steady_state_s2anet.txt | cut -c1-160
@@ -198,7 +198,7 @@ rm -rf $OUT/trace_default
 # traffic of the roofline kernel (default path), one counter set per pass
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_READ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-30)
-  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_fwd_$n -o p -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/pmc_fwd_$n.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_fwd_$n -o p -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/pmc_fwd_$n.log 2>&1)
 done
 python - <<PY > $OUT/roi_align_fwd_counters.txt
 import csv, glob, collections
@@ -214,7 +214,7 @@ PY
 cut -c40-200 $OUT/roi_align_fwd_counters.txt
 rm -rf $OUT/pmc_fwd_*/
 for wl in roi_align_rotated roi_align_rotated_bwd riroi_align box_iou_rotated nms_rotated; do
-  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o t -- python $R/bench.py --workload $wl --no-cpu-baseline > $OUT/trace_$wl.log 2>&1)
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary > $OUT/trace_$wl.log 2>&1)
   k=$(find $OUT/trace_$wl -name '*kernel_stats.csv' | head -1)
   [ -n "$k" ] && head -12 $k | cut -c1-220 > $OUT/kernel_stats_$wl.csv
   grep -o '"ms_per_step": [0-9.]*' $OUT/trace_$wl.log | head -1
@@ -224,7 +224,7 @@ done
 # MFMA counters over the S2ANet step (two passes)
 for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
-  (cd /tmp && timeout 900 rocprofv3 --pmc $c -f csv -d $OUT/mfma_$n -o p -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline > $OUT/mfma_$n.log 2>&1 || echo "pmc $c failed")
+  (cd /tmp && timeout 900 rocprofv3 --pmc $c -f csv -d $OUT/mfma_$n -o p -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/mfma_$n.log 2>&1 || echo "pmc $c failed")
 done
 python - <<PY
 import csv, glob, collections
@@ -251,7 +251,7 @@ print(open("$OUT/s2anet_mfma_utilisation.txt").read()[:3500])
 PY
 rm -rf $OUT/mfma_SQ*
 for wl in retinanet_infer orcnn_train roitrans_r50_train roitrans_train; do
-  timeout 600 python bench.py --workload $wl --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+  timeout 600 python bench.py --workload $wl --no-cpu-baseline --no-secondary > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   python -c "
 import json,sys
 l=json.loads(open('$OUT/bench_$wl.json').read().strip().splitlines()[-1]); print('$wl', l['ms_per_step'], 'ms/step', l['value'], l['unit'], l['config'].get('global_batch'))" 2>/dev/null || echo "$wl failed"
@@ -269,7 +269,7 @@ timeout 900 python -m pytest tests/test_gpu_roi_align.py -x -q -k "sliced or gol
 echo "pytest rc=$?"; tail -5 $OUT/pytest.log
 trace() {  # $1 = tag, rest = env
   tag=$1; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -287,7 +287,7 @@ trace b16plain JDET_ROI_SLICED_BATCH=16 JDET_ROI_SLICED_STORE=1
 trace legacy JDET_ROI_FWD_LEGACY=1
 pmc() {  # $1 = tag, $2 = counters, rest = env
   tag=$1; c=$2; shift; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$tag -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections
 for f in sorted(glob.glob("$OUT/p_$tag/**/*counter_collection.csv",recursive=True)):
@@ -307,7 +307,7 @@ for v in default legacy; do
   pmc ${v}_tcp "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" $e
   pmc ${v}_sq "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD" $e
 done
-timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline 2>/dev/null | tail -1
+timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary 2>/dev/null | tail -1
 }
 
 run_g() {
@@ -322,7 +322,7 @@ for m in shared own eager; do
 done
 trace() {  # $1 = tag, $2 = workload, rest = env
   tag=$1; wl=$2; shift; shift
-  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 50 > $OUT/t_$tag.log 2>&1)
+  (cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$tag -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$tag.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$tag/**/*kernel_trace.csv",recursive=True)
@@ -337,7 +337,7 @@ PY
 trace bwd_fold roi_align_rotated_bwd A=1
 trace bwd_nofold roi_align_rotated_bwd JDET_ROI_BWD_FOLD_SCAN=0
 timeout 300 python -m pytest tests/test_gpu_roi_align.py -x -q -k "channels_last or kept_workspace or cfg0 or full_size" 2>&1 | tail -2
-for p in 1024 4096; do JDET_PACK_MAX_POS=$p timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet pack_max_pos='$p'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
+for p in 1024 4096; do JDET_PACK_MAX_POS=$p timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet pack_max_pos='$p'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
 }
 
 run_h() {
@@ -354,8 +354,8 @@ R=$PWD
 OUT=$R/gpurun_out/r4_i; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_conv1x1.py tests/test_gpu_s2anet.py -q 2>&1 | tail -3
-for g in 0 1; do JDET_CONV1X1_GEMM=$g timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet conv1x1_gemm='$g'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
-for g in 0 1; do JDET_CONV1X1_GEMM=$g timeout 600 python bench.py --workload orcnn_train --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("orcnn conv1x1_gemm='$g'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
+for g in 0 1; do JDET_CONV1X1_GEMM=$g timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet conv1x1_gemm='$g'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
+for g in 0 1; do JDET_CONV1X1_GEMM=$g timeout 600 python bench.py --workload orcnn_train --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("orcnn conv1x1_gemm='$g'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
 }
 
 run_j() {
@@ -364,7 +364,7 @@ OUT=$R/gpurun_out/r4_j; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 2400 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.log 2>&1
 echo "pytest -m gpu rc=$?"; tail -5 $OUT/pytest_gpu.log
-for wl in s2anet_train orcnn_train retinanet_infer roitrans_r50_train; do timeout 600 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("'$wl'", round(d["value"],2), d["unit"], round(d["ms_per_step"],3), "ms")'; done
+for wl in s2anet_train orcnn_train retinanet_infer roitrans_r50_train; do timeout 600 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("'$wl'", round(d["value"],2), d["unit"], round(d["ms_per_step"],3), "ms")'; done
 }
 
 run_k() {
@@ -373,14 +373,14 @@ timeout 900 python -m pytest tests/test_gpu_convex_ops.py tests/test_gpu_referen
 
 run_l() {
 timeout 900 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_head_parity.py -q 2>&1 | tail -3
-for p in 1024 4096 16384; do JDET_PACK_MAX_POS=$p timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet pack_max_pos='$p'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
-JDET_PACK_MAX_POS=4096 timeout 600 python bench.py --workload retinanet_infer --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-200
+for p in 1024 4096 16384; do JDET_PACK_MAX_POS=$p timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("s2anet pack_max_pos='$p'", round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")'; done
+JDET_PACK_MAX_POS=4096 timeout 600 python bench.py --workload retinanet_infer --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | cut -c1-200
 }
 
 run_m() {
 R=$PWD; OUT=$R/gpurun_out/r4_m; mkdir -p $OUT; export TMPDIR=/tmp
-for e in 0 1 0 1; do JDET_BENCH_CHECKSUM=1 JDET_ROI_FWD_EXACT=$e timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline 2>$OUT/err_$e.log | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("exact='$e'", round(d["ms_per_step"]*1000,2),"us/step", round(d["roofline"]["kernel_ms"]*1000,2), "us (events)")'; grep checksum $OUT/err_$e.log | tail -1; done
-(cd /tmp && JDET_ROI_FWD_EXACT=1 timeout 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD --output-format csv -d $OUT/p -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p.log 2>&1)
+for e in 0 1 0 1; do JDET_BENCH_CHECKSUM=1 JDET_ROI_FWD_EXACT=$e timeout 120 python bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary 2>$OUT/err_$e.log | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print("exact='$e'", round(d["ms_per_step"]*1000,2),"us/step", round(d["roofline"]["kernel_ms"]*1000,2), "us (events)")'; grep checksum $OUT/err_$e.log | tail -1; done
+(cd /tmp && JDET_ROI_FWD_EXACT=1 timeout 300 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD --output-format csv -d $OUT/p -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p.log 2>&1)
 python - <<PY
 import csv,glob,collections
 for f in glob.glob("$OUT/p/**/*counter_collection.csv",recursive=True):
@@ -401,7 +401,7 @@ timeout 600 python bench.py 2>/dev/null | tail -1 | cut -c1-700
 run_o() {
 R=$PWD; OUT=$R/gpurun_out/r4_o; mkdir -p $OUT; export TMPDIR=/tmp
 for kb in 0 20 26 36 52; do
-  (cd /tmp && JDET_ROI_BWD_GATHER_LDS_KB=$kb timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$kb -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 50 > $OUT/t_$kb.log 2>&1)
+  (cd /tmp && JDET_ROI_BWD_GATHER_LDS_KB=$kb timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t_$kb -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$kb.log 2>&1)
   python - <<PY
 import csv,glob,collections,re
 f=glob.glob("$OUT/t_$kb/**/*kernel_trace.csv",recursive=True)
@@ -413,7 +413,7 @@ print("lds_kb=$kb", "; ".join("%s %.1f"%(k,sum(v[5:])/len(v[5:])) for k,v in d.i
 PY
 done
 for kb in 0 26; do
-(cd /tmp && JDET_ROI_BWD_GATHER_LDS_KB=$kb timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_READ_sum --output-format csv -d $OUT/p_$kb -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p_$kb.log 2>&1)
+(cd /tmp && JDET_ROI_BWD_GATHER_LDS_KB=$kb timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_READ_sum --output-format csv -d $OUT/p_$kb -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p_$kb.log 2>&1)
 python - <<PY
 import csv,glob,collections
 for f in glob.glob("$OUT/p_$kb/**/*counter_collection.csv",recursive=True):
@@ -442,7 +442,7 @@ for l in sys.stdin:
 for cfg in "1 32768" "0 0" "1 0" "1 8192" "1 32768" "0 0"; do
   set -- $cfg
   echo "== JDET_CONV_WGRAD=$1 JDET_DCN_FUSED_TRAIN_MIN_POS=$2"
-  JDET_CONV_WGRAD=$1 JDET_DCN_FUSED_TRAIN_MIN_POS=$2 timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_CONV_WGRAD=$1 JDET_DCN_FUSED_TRAIN_MIN_POS=$2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 
@@ -450,7 +450,7 @@ run_s() {
 timeout 900 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_ddp_detectors.py -x -q 2>&1 | tail -4
 for v in 1 0 1 0; do
   echo "== JDET_HEAD_STREAMS=$v"
-  JDET_HEAD_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_HEAD_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 
@@ -458,11 +458,11 @@ run_t() {
 timeout 900 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_ddp_detectors.py tests/test_gpu_conv1x1.py tests/test_gpu_conv_igemm.py -x -q 2>&1 | tail -4
 for v in 1 0 1 0; do
   echo "== JDET_CONV_BWD_STREAMS=$v"
-  JDET_CONV_BWD_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_CONV_BWD_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 for v in 1 0; do
   echo "== orcnn JDET_CONV_BWD_STREAMS=$v"
-  JDET_CONV_BWD_STREAMS=$v timeout 600 python bench.py --workload orcnn_train --no-cpu-baseline --steps 20 --warmup 6 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_CONV_BWD_STREAMS=$v timeout 600 python bench.py --workload orcnn_train --no-cpu-baseline --no-secondary --steps 20 --warmup 6 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 
@@ -472,10 +472,10 @@ R=$PWD; OUT=$R/gpurun_out/r4_v; mkdir -p $OUT; export TMPDIR=/tmp
 JDET_ROI_FWD_LINE=1 timeout 900 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_reference_kernels.py -q 2>&1 | tail -4
 for v in ${LINES:-0 1 0 1}; do
   echo "== JDET_ROI_FWD_LINE=$v"
-  JDET_ROI_FWD_LINE=$v timeout 300 python bench.py --workload roi_align_rotated --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_ROI_FWD_LINE=$v timeout 300 python bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 for v in ${TRACE:-0 1}; do
-  (cd /tmp && JDET_ROI_FWD_LINE=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t_$v -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 50 > $OUT/t_$v.log 2>&1)
+  (cd /tmp && JDET_ROI_FWD_LINE=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t_$v -o t -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 50 > $OUT/t_$v.log 2>&1)
   k=$(find $OUT/t_$v -name '*kernel_stats.csv' | head -1); echo "LINE=$v"; head -4 $k | cut -c1-160
   rm -rf $OUT/t_$v
 done
@@ -483,7 +483,7 @@ if [ "${PMC:-0}" = "1" ]; then
 for v in ${TRACE:-0 1}; do
   for c in "TCC_EA0_RDREQ_sum TCC_READ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
     n=$(echo $c | tr ' ' '_' | cut -c1-20)
-    (cd /tmp && JDET_ROI_FWD_LINE=$v timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_${v}_$n -o p -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --steps 10 --warmup 3 > $OUT/p_${v}_$n.log 2>&1)
+    (cd /tmp && JDET_ROI_FWD_LINE=$v timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/p_${v}_$n -o p -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/p_${v}_$n.log 2>&1)
   done
   python - <<PY
 import csv, glob, collections
@@ -510,11 +510,11 @@ run_x() {
 timeout 900 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_ddp_detectors.py -q 2>&1 | tail -3
 for v in 1 0 1 0; do
   echo "== JDET_FUSED_SGD=$v"
-  JDET_FUSED_SGD=$v timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_FUSED_SGD=$v timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 for v in 1 0; do
   echo "== orcnn JDET_FUSED_SGD=$v"
-  JDET_FUSED_SGD=$v timeout 600 python bench.py --workload orcnn_train --no-cpu-baseline --steps 20 --warmup 6 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_FUSED_SGD=$v timeout 600 python bench.py --workload orcnn_train --no-cpu-baseline --no-secondary --steps 20 --warmup 6 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 
@@ -524,7 +524,7 @@ timeout 900 python -m pytest tests/test_gpu_dcn_arf.py tests/test_gpu_s2anet.py 
 for cfg in "1 1" "0 0" "1 0" "1 1" "0 0"; do
   set -- $cfg
   echo "== JDET_PACK_FUSED_MASK=$1 JDET_RIP_KERNEL=$2"
-  JDET_PACK_FUSED_MASK=$1 JDET_RIP_KERNEL=$2 timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_PACK_FUSED_MASK=$1 JDET_RIP_KERNEL=$2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 
@@ -533,7 +533,7 @@ run_z() {
 for cfg in "1 1" "0 0" "1 1" "0 0"; do
   set -- $cfg
   echo "== JDET_PACK_FUNCTIONS=$1 JDET_ARF_CL=$2"
-  JDET_PACK_FUNCTIONS=$1 JDET_ARF_CL=$2 timeout 600 python bench.py --no-cpu-baseline --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+  JDET_PACK_FUNCTIONS=$1 JDET_ARF_CL=$2 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 30 --warmup 8 2>&1 | grep -o '"ms_per_step": [0-9.]*'
 done
 }
 

@@ -6,7 +6,7 @@ timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -1 gpurun_out/bench_default.json | cut -c1-1800
 # same command under rocprofv3 (kernel trace + stats): steady-state step breakdown + the roofline kernel's average
 mkdir -p $R/gpurun_out/prof_default; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_default/trace -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $R/gpurun_out/prof_default/trace.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_default/trace -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-secondary > $R/gpurun_out/prof_default/trace.log 2>&1
 cd $R
 f=$(find gpurun_out/prof_default/trace -name '*kernel_trace.csv' | head -1)
 python scripts/steady_state.py $f assign_anchor_kernel 4 5 > gpurun_out/prof_default/steady_state.txt

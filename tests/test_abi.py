@@ -111,6 +111,9 @@ def test_bench_contract_pieces_importable_without_gpu():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - 167508864 / 1e9 / 0.064e-3) < 1e-6
     assert r["traffic"] is None or r["traffic"] > 100e6          # PMC bytes per launch, when profiles/ has them
+    assert r["traffic"] is None or "not live" in r["traffic_source"]     # the line says where the constant comes from
+    assert "peak_measured" not in r                              # (measured on a device only: bench passes `dev`)
+    assert callable(bench.measured_copy_peak) and callable(bench.secondary_lines)
     for name in ("S2ANET_CFG", "RETINANET_CFG", "ORCNN_CFG"):
         cfg = getattr(bench, name)
         assert cfg["model"]["type"] and cfg["model"]["backbone"]["type"].startswith("Resnet")
