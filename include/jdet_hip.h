@@ -269,6 +269,90 @@ int jdet_conv3x3_wgrad_supported(int Cin, int Cout);
 int jdet_conv3x3_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, int N, int H, int W, int Cin,
                        int Cout, float* gw_krsc, int ksplit, jdet_stream_t stream);
 
+/* ---- The ResNet bottleneck convolutions with the layer's neighbours in the epilogue (csrc/conv_bn.hip) -------------
+ * Replaces, for Bottleneck.execute (python/jdet/models/backbones/resnet.py:L61-93) and ResNet._make_layer's downsample
+ * pair (L131-154) under `norm_eval` (L177-185), the nn.Conv -> nn.BatchNorm(eval) [-> + identity] [-> relu] chains and
+ * the gradients Jittor derives for them: forward, data gradient (the same kernel on jdet_conv_dgrad_weights' flipped /
+ * transposed weights) and, through jdet_conv_wgrad, the weight gradient.
+ *
+ * jdet_bn_params_t: an eval-mode BatchNorm as the affine map a = weight * rsqrt(var + eps), sh = bias - mean * a
+ *   (weight NULL = 1, bias NULL = 0; var NULL: a = weight, sh = bias, i.e. a plain convolution bias).
+ * jdet_conv_epilogue_t.mode:
+ *   JDET_EPI_FORWARD  y = [relu]( [affine: acc * a + sh] [+ residual (M, Cout)] )
+ *   JDET_EPI_ADD      y = acc + grad_out * [act > 0]        grad_out, act: (M, Cout) -- the identity branch's gradient
+ *                                                            joins the data gradient of conv1 (the block's grad_x)
+ *   JDET_EPI_MASK     g = acc * [act > 0];  y = g * a;  sums (rows, 2, Cout) non-NULL: partial column sums of g and of
+ *                     g * (act - bias), rows = jdet_conv_bn_sums_rows(...) -- `bn` / `act` are the BatchNorm and the
+ *                     activation act = relu(bn(conv)) of the layer BELOW: y is the gradient w.r.t. that conv's output */
+typedef struct jdet_bn_params {
+  const float* weight;
+  const float* bias;
+  const float* mean;
+  const float* var;
+  float eps;
+} jdet_bn_params_t;
+
+#define JDET_EPI_FORWARD 0
+#define JDET_EPI_ADD 1
+#define JDET_EPI_MASK 2
+
+typedef struct jdet_conv_epilogue {
+  int mode;
+  int affine; /* FORWARD: apply bn to the accumulator */
+  int relu;   /* FORWARD */
+  jdet_bn_params_t bn;
+  const float* residual; /* FORWARD */
+  const float* grad_out; /* ADD */
+  const float* act;      /* ADD, MASK */
+  float* sums;           /* MASK */
+} jdet_conv_epilogue_t;
+
+/* x (N,H,W,Cin), w (Cout,R,R,Cin), y (N,Ho,Wo,Cout), Ho = (H + 2*(R/2) - R) / stride + 1; R in {1, 3}, stride in
+ * {1, 2}, Cin % 16 == 0, 16-byte aligned x / w, positions * channels < 2^30 (else JDET_E_UNSUPPORTED / _BADARG).
+ * tile: as jdet_conv3x3_igemm_forward.  workspace (jdet_conv_bn_workspace bytes, optional): small maps split their K
+ * steps over workgroups.  jdet_conv_bn_sums_rows: rows of `sums` a MASK launch with these arguments writes
+ * (with_workspace: whether a sufficient workspace will be passed). */
+int jdet_conv_bn_supported(int Cin, int Cout, int R, int stride);
+size_t jdet_conv_bn_workspace(int N, int H, int W, int Cin, int Cout, int R, int stride);
+size_t jdet_conv_bn_sums_rows(int N, int H, int W, int Cin, int Cout, int R, int stride, int tile,
+                              int with_workspace);
+int jdet_conv_bn_forward(const float* x_nhwc, int N, int H, int W, int Cin, const float* w_krsc, int Cout, int R,
+                         int stride, const jdet_conv_epilogue_t* epilogue, int tile, float* y_nhwc, void* workspace,
+                         size_t workspace_bytes, jdet_stream_t stream);
+/* weights of the data gradient for any number of layers in ONE launch: dst (Cin,R,R,Cout)[ci][R*R-1-tap][co] =
+ * src (Cout,R,R,Cin)[co][tap][ci].  jobs_device: DEVICE array of njobs 32-byte records {const float* src; float* dst;
+ * int Cout, Cin, taps, tile_begin} with tile_begin the running sum of ceil(Cout/32) * ceil(Cin/32) * taps over the
+ * preceding jobs; total_tiles = that sum over all jobs. */
+int jdet_conv_dgrad_weights(const void* jobs_device, int njobs, int total_tiles, jdet_stream_t stream);
+/* weight gradient, ACCUMULATED: gw (Cout,R,R,Cin) += sum over positions of gy (N,Ho,Wo,Cout) x the input window of
+ * x (N,H,W,Cin); the general (R, stride) form of jdet_conv3x3_wgrad, same tiling / split / atomics. */
+int jdet_conv_wgrad(const float* x_nhwc, const float* gy_nhwc, int N, int H, int W, int Cin, int Cout, int R,
+                    int stride, float* gw_krsc, int ksplit, jdet_stream_t stream);
+/* Backward of a BatchNorm whose (possibly summed) output went through a ReLU, from the ACTIVATION y (the fused forward
+ * stores no conv output c): grad_c = grad_y * [y > 0] * a; sums non-NULL: partial sums (rows, 2, C) of
+ * g = grad_y * [y > 0] and g * t, rows = jdet_bn_act_backward_from_output_rows(P, C), where t / gamma = xhat:
+ *   t = y - bias (y = relu(bn(c)));  identity != NULL: t = y - identity - bias (y = relu(bn(c) + identity));
+ *   own_output != NULL: t = own_output - bias (y = relu(other + bn(c)), own_output = bn(c): the downsample branch).
+ * Channel counts as jdet_frozen_bn_act_forward. */
+size_t jdet_bn_act_backward_from_output_rows(long P, int C);
+int jdet_bn_act_backward_from_output(const float* grad_y_nhwc, const float* y_nhwc, const float* identity_nhwc,
+                                     const float* own_output_nhwc, long P, int C, const float* weight,
+                                     const float* bias, const float* running_mean, const float* running_var,
+                                     float eps, float* grad_c_nhwc, float* sums, size_t sums_bytes,
+                                     jdet_stream_t stream);
+/* Second stage of such partial sums for up to 4 BatchNorm layers in one launch (deterministic: fixed summation order):
+ * grad_beta = column sums of the first halves, grad_gamma = column sums of the second halves / gamma (gamma NULL = 1;
+ * a zero gamma gives inf / NaN on purpose -- xhat is not recoverable from the activation then).  jobs: HOST array. */
+typedef struct jdet_bn_sums_job {
+  const float* partial; /* (rows, 2, C) */
+  long rows;
+  int C;
+  const float* gamma;
+  float* grad_gamma;
+  float* grad_beta;
+} jdet_bn_sums_job_t;
+int jdet_bn_sums_finish(const jdet_bn_sums_job_t* jobs, int njobs, jdet_stream_t stream);
+
 /* RepPoints geometry on 9-point sets (pointsets (N,18) = 9 (x,y) pairs) and the Graham scan of the polygon-IoU loss.
  * jdet_convex_iou: replaces convex_iou_kernel (ops/reppoints_convex_iou/convex_iou_kernel.cu:L258-305): IoU of the
  *   convex hull of every point set with every quadrilateral polygons (M,8) -> ious (N,M), computed in double.

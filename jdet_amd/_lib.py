@@ -16,6 +16,23 @@ LIB_PATH = os.path.join(CSRC, "libjdet_hip.so")
 
 _i, _f, _p, _sz, _l = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long
 
+
+
+class BnParams(ctypes.Structure):           # jdet_bn_params_t
+    _fields_ = [("weight", _p), ("bias", _p), ("mean", _p), ("var", _p), ("eps", _f)]
+
+
+class ConvEpilogue(ctypes.Structure):       # jdet_conv_epilogue_t
+    _fields_ = [("mode", _i), ("affine", _i), ("relu", _i), ("bn", BnParams), ("residual", _p), ("grad_out", _p),
+                ("act", _p), ("sums", _p)]
+
+
+class BnSumsJob(ctypes.Structure):          # jdet_bn_sums_job_t
+    _fields_ = [("partial", _p), ("rows", _l), ("C", _i), ("gamma", _p), ("grad_gamma", _p), ("grad_beta", _p)]
+
+
+EPI_FORWARD, EPI_ADD, EPI_MASK = 0, 1, 2
+
 # name -> (restype, argtypes); mirrors include/jdet_hip.h one to one (tests/test_abi.py checks it)
 SIGNATURES = {
     "jdet_version": (_i, []),
@@ -62,6 +79,15 @@ SIGNATURES = {
     "jdet_conv3x3_igemm_workspace": (_sz, [_i] * 5),
     "jdet_conv3x3_wgrad_supported": (_i, [_i, _i]),
     "jdet_conv3x3_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "jdet_conv_bn_supported": (_i, [_i] * 4),
+    "jdet_conv_bn_workspace": (_sz, [_i] * 7),
+    "jdet_conv_bn_sums_rows": (_sz, [_i] * 9),
+    "jdet_conv_bn_forward": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, ctypes.POINTER(ConvEpilogue), _i, _p, _p, _sz, _p]),
+    "jdet_conv_dgrad_weights": (_i, [_p, _i, _i, _p]),
+    "jdet_conv_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "jdet_bn_act_backward_from_output_rows": (_sz, [_l, _i]),
+    "jdet_bn_act_backward_from_output": (_i, [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _p, _p, _sz, _p]),
+    "jdet_bn_sums_finish": (_i, [ctypes.POINTER(BnSumsJob), _i, _p]),
     "jdet_sigmoid_focal_loss_workspace": (_sz, []),
     "jdet_sigmoid_focal_loss": (_i, [_p, _p, _p, _l, _i, _f, _f, _p, _p, _p, _sz, _p]),
     "jdet_smooth_l1_loss": (_i, [_p, _p, _p, _l, _f, _p, _p, _p, _sz, _p]),

@@ -42,6 +42,7 @@ struct WgradArgs {
   const float* offset;   // deformable: (N, 18, H, W), else null
   float* gw;             // (Cout, 3, 3, Cin), accumulated into
   int N, H, W, Cin, Cout, ksplit, steps_per_chunk, skip_epilogue;
+  int R, stride, Ho, Wo;   // R x R taps (pad R / 2), stride: gy is (N, Ho, Wo, Cout); 3 / 1 / H / W for the 3x3 form
 };
 
 constexpr unsigned kOob = 0xFFFFFFF0u;
@@ -51,7 +52,8 @@ __device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff)
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 
-template <int TM, int TN, bool DEFORM, bool WIDE>
+// S2: the strided form (stride 2, or any case where the x pixel of a position is not at a constant distance from it)
+template <int TM, int TN, bool DEFORM, bool WIDE, bool S2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEFORM ? 3 : 4)))
 void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -63,23 +65,25 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
   static_assert(PA >= 1 && PB >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) char s_raw[2 * (TILE_A + TILE_B)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long M = (long)a.N * a.H * a.W;
+  const long M = (long)a.N * a.Ho * a.Wo;            // positions of gy
+  const long Mx = (long)a.N * a.H * a.W;             // positions of x
+  const int taps = a.R * a.R, pad = a.R >> 1;
   const int mt = (a.Cout + BM - 1) / BM, nt = (a.Cin + BN - 1) / BN;
-  const int tiles = mt * nt * 9;
+  const int tiles = mt * nt * taps;
   // grid = tiles * (ksplit rounded up to whole rounds over the 8 XCDs); the surplus workgroups of the last round leave
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int chunk = xcd + 8 * (j / tiles), tile = j % tiles;
   if (chunk >= a.ksplit) return;
-  const int tap = tile % 9, rest = tile / 9;
+  const int tap = tile % taps, rest = tile / taps;
   const int n0 = (rest % nt) * BN, m0 = (rest / nt) * BM;
-  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int dy = tap / a.R - pad, dx = tap % a.R - pad;
   const long p_begin = (long)chunk * a.steps_per_chunk * BK;
   if (p_begin >= M) return;
   long left = (M - p_begin + BK - 1) / BK;
   const int nsteps = left < a.steps_per_chunk ? (int)left : a.steps_per_chunk;
 
   const __amdgpu_buffer_rsrc_t rx =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)(M * a.Cin * 4), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)(Mx * a.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rg =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.gy, 0, (unsigned)(M * a.Cout * 4), 0x00020000);
 
@@ -115,24 +119,30 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
     }
   };
   auto plain_off = [&](int p) {
-    const bool in = b_cok && bp[p] < M && (unsigned)(by[p] + dy) < (unsigned)a.H && (unsigned)(bx[p] + dx) < (unsigned)a.W;
-    b_off[p][0] = in ? b_lin[p] : kOob;
+    if (S2) {
+      const int yy = by[p] * a.stride + dy, xx = bx[p] * a.stride + dx;
+      const bool in = b_cok && bp[p] < M && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      b_off[p][0] = in ? ((unsigned)(((bi[p] * a.H + yy) * a.W + xx) * a.Cin + n0 + b_chunk * 4)) * 4u : kOob;
+    } else {
+      const bool in = b_cok && bp[p] < M && (unsigned)(by[p] + dy) < (unsigned)a.H && (unsigned)(bx[p] + dx) < (unsigned)a.W;
+      b_off[p][0] = in ? b_lin[p] : kOob;
+    }
   };
   auto advance = [&](int p) {                 // row p: BK positions on
     bp[p] += BK;
     bx[p] += BK;
     b_lin[p] += b_step;
     if (WIDE) {
-      const bool cx = bx[p] >= a.W;
-      bx[p] -= cx ? a.W : 0;
+      const bool cx = bx[p] >= a.Wo;
+      bx[p] -= cx ? a.Wo : 0;
       by[p] += cx ? 1 : 0;
-      const bool cy = by[p] >= a.H;
-      by[p] -= cy ? a.H : 0;
+      const bool cy = by[p] >= a.Ho;
+      by[p] -= cy ? a.Ho : 0;
       bi[p] += cy ? 1 : 0;
     } else {
-      while (bx[p] >= a.W) {
-        bx[p] -= a.W;
-        if (++by[p] == a.H) {
+      while (bx[p] >= a.Wo) {
+        bx[p] -= a.Wo;
+        if (++by[p] == a.Ho) {
           by[p] = 0;
           bi[p]++;
         }
@@ -145,10 +155,10 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
     const int row = p * (256 / CB) + b_row;
     const long pp = p_begin + row;
     bp[p] = (int)pp;
-    bi[p] = (int)(pp / ((long)a.H * a.W));
-    const int rem = (int)(pp - (long)bi[p] * a.H * a.W);
-    by[p] = rem / a.W;
-    bx[p] = rem - by[p] * a.W;
+    bi[p] = (int)(pp / ((long)a.Ho * a.Wo));
+    const int rem = (int)(pp - (long)bi[p] * a.Ho * a.Wo);
+    by[p] = rem / a.Wo;
+    bx[p] = rem - by[p] * a.Wo;
     b_lin[p] = (unsigned)(((pp + dy * a.W + dx) * a.Cin + n0 + b_chunk * 4) * 4);
     b_st[p] = TILE_A + (row * SB + b_chunk * 4) * 4;
     o_h[p] = o_w[p] = 0.f;
@@ -274,7 +284,7 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) {
         const int co = m0 + wm * 32 * TM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (co < a.Cout && ci < a.Cin) unsafeAtomicAdd(a.gw + ((size_t)co * 9 + tap) * a.Cin + ci, acc[i][j][e]);
+        if (co < a.Cout && ci < a.Cin) unsafeAtomicAdd(a.gw + ((size_t)co * taps + tap) * a.Cin + ci, acc[i][j][e]);
       }
     }
 }
@@ -282,16 +292,54 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
 template <int TM, int TN>
 int launch(const WgradArgs& a, hipStream_t st) {
   const int mt = (a.Cout + 64 * TM - 1) / (64 * TM), nt = (a.Cin + 64 * TN - 1) / (64 * TN);
-  const unsigned grid = (unsigned)(mt * nt * 9 * ((a.ksplit + 7) & ~7));
-  const bool wide = a.W >= BK;
+  const unsigned grid = (unsigned)(mt * nt * a.R * a.R * ((a.ksplit + 7) & ~7));
+  const bool wide = a.Wo >= BK;
+  const bool s2 = a.stride != 1 || a.Ho != a.H || a.Wo != a.W;
   if (a.offset) {
-    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, false>), dim3(grid), dim3(256), 0, st, a);
+    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, false, false>), dim3(grid), dim3(256), 0, st, a);
+  } else if (s2) {
+    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false>), dim3(grid), dim3(256), 0, st, a);
+    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return jdet_launch_status();
+}
+
+int wgrad_out_dim(int in, int R, int stride) { return (in + 2 * (R / 2) - R) / stride + 1; }
+
+int run_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, int N, int H, int W, int Cin, int Cout,
+              int R, int stride, float* gw, int ksplit, hipStream_t st) {
+  const int Ho = wgrad_out_dim(H, R, stride), Wo = wgrad_out_dim(W, R, stride);
+  const long M = (long)N * Ho * Wo, Mx = (long)N * H * W;
+  if ((M + BK) * Cout >= (1L << 30) || (Mx + BK) * Cin >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
+  const int tm = Cout > 64 ? 2 : 1, tn = Cin > 64 ? 2 : 1;
+  const int mt = (Cout + 64 * tm - 1) / (64 * tm), nt = (Cin + 64 * tn - 1) / (64 * tn);
+  const long tiles = (long)mt * nt * R * R;
+  const long steps = (M + BK - 1) / BK;
+  const int skip = (ksplit >> 16) & 1;   // bit 16: leave the result out (measurement aid)
+  long ks = ksplit & 0xFFFF;
+  if (ks == 0) {
+    // measured on MI355X (scripts/conv_wgrad_timing.py, profiles/r04_conv_wgrad.md): ~2300 workgroups (the chip holds
+    // 1024; the staggered later rounds run denser than one lock-step round), at least 16 K steps each -- small maps
+    // trade that for parallelism down to 4 steps -- and never more than 64 chunks (each adds a tile of atomics).
+    // 1x1 layers have a ninth of the tiles: up to 256 chunks of at least 8 steps there.
+    ks = (2304 + tiles - 1) / tiles;
+    long cap = steps / (R == 1 ? 8 : 16);
+    const long small = steps / 4 < 8 ? steps / 4 : 8;
+    if (cap < small) cap = small;
+    const long most = R == 1 ? 256 : 64;
+    if (cap > most) cap = most;
+    if (ks > cap) ks = cap;
+  }
+  if (ks < 1) ks = 1;
+  if (ks > steps) ks = steps;
+  WgradArgs a{x_nhwc, gy_nhwc, offset, gw, N, H, W, Cin, Cout, (int)ks, (int)((steps + ks - 1) / ks), skip,
+              R, stride, Ho, Wo};
+  if (tm == 2) return tn == 2 ? launch<2, 2>(a, st) : launch<2, 1>(a, st);
+  return tn == 2 ? launch<1, 2>(a, st) : launch<1, 1>(a, st);
 }
 
 }  // namespace
@@ -310,29 +358,18 @@ JDET_API int jdet_conv3x3_wgrad(const float* x_nhwc, const float* gy_nhwc, const
   if (N == 0) return JDET_OK;
   if (!x_nhwc || !gy_nhwc || !gw_krsc) return JDET_E_BADARG;
   if ((((uintptr_t)x_nhwc) | ((uintptr_t)gy_nhwc)) & 15) return JDET_E_BADARG;
-  const long M = (long)N * H * W;
-  if ((M + BK) * (Cin > Cout ? Cin : Cout) >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
-  const int tm = Cout > 64 ? 2 : 1, tn = Cin > 64 ? 2 : 1;
-  const int mt = (Cout + 64 * tm - 1) / (64 * tm), nt = (Cin + 64 * tn - 1) / (64 * tn);
-  const long tiles = (long)mt * nt * 9;
-  const long steps = (M + BK - 1) / BK;
-  const int skip = (ksplit >> 16) & 1;   // bit 16: leave the result out (measurement aid)
-  long ks = ksplit & 0xFFFF;
-  if (ks == 0) {
-    // measured on MI355X (scripts/conv_wgrad_timing.py, profiles/r04_conv_wgrad.md): ~2300 workgroups (the chip holds
-    // 1024; the staggered later rounds run denser than one lock-step round), at least 16 K steps each -- small maps
-    // trade that for parallelism down to 4 steps -- and never more than 64 chunks (each adds a tile of atomics)
-    ks = (2304 + tiles - 1) / tiles;
-    long cap = steps / 16;
-    const long small = steps / 4 < 8 ? steps / 4 : 8;
-    if (cap < small) cap = small;
-    if (cap > 64) cap = 64;
-    if (ks > cap) ks = cap;
-  }
-  if (ks < 1) ks = 1;
-  if (ks > steps) ks = steps;
-  WgradArgs a{x_nhwc, gy_nhwc, offset, gw_krsc, N, H, W, Cin, Cout, (int)ks, (int)((steps + ks - 1) / ks), skip};
-  hipStream_t st = (hipStream_t)stream;
-  if (tm == 2) return tn == 2 ? launch<2, 2>(a, st) : launch<2, 1>(a, st);
-  return tn == 2 ? launch<1, 2>(a, st) : launch<1, 1>(a, st);
+  return run_wgrad(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, 3, 1, gw_krsc, ksplit, (hipStream_t)stream);
+}
+
+// The general form of the backbone: R x R taps (R = 1 | 3, pad R / 2), stride 1 | 2: x (N, H, W, Cin),
+// gy (N, Ho, Wo, Cout) with Ho = (H + 2 * (R / 2) - R) / stride + 1, gw_krsc (Cout, R, R, Cin) +=.
+JDET_API int jdet_conv_wgrad(const float* x_nhwc, const float* gy_nhwc, int N, int H, int W, int Cin, int Cout, int R,
+                             int stride, float* gw_krsc, int ksplit, jdet_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksplit < 0) return JDET_E_BADARG;
+  if ((R != 1 && R != 3) || (stride != 1 && stride != 2)) return JDET_E_UNSUPPORTED;
+  if (!jdet_conv3x3_wgrad_supported(Cin, Cout)) return JDET_E_UNSUPPORTED;
+  if (N == 0) return JDET_OK;
+  if (!x_nhwc || !gy_nhwc || !gw_krsc) return JDET_E_BADARG;
+  if ((((uintptr_t)x_nhwc) | ((uintptr_t)gy_nhwc)) & 15) return JDET_E_BADARG;
+  return run_wgrad(x_nhwc, gy_nhwc, nullptr, N, H, W, Cin, Cout, R, stride, gw_krsc, ksplit, (hipStream_t)stream);
 }

@@ -144,6 +144,126 @@ __global__ __launch_bounds__(1024) void frozen_bn_bwd_kernel(const v4f* __restri
   }
 }
 
+// Backward of y = relu(bn(c) + idn) FROM ITS OUTPUT: the fused convolution (conv_bn.hip) never stores c, and wherever
+// y > 0 the normalised input is recoverable as xhat = (y - idn - beta) / gamma.  One pass: reads dy, y (, idn); writes
+// dc = dy * [y > 0] * a; per-channel partial sums of g = dy * [y > 0] and g * (y - idn - beta) -- the second stage
+// divides the latter by gamma (jdet_bn_sums_finish).  Same launch geometry / partial layout as frozen_bn_bwd_kernel.
+// SRC selects the second sum's factor: 0: y - beta (a plain conv -> bn -> relu layer), 1: y - v - beta (v = the identity
+// added before the ReLU), 2: u - beta (u = this BatchNorm's own output, e.g. the downsample branch bn_d(c_d) that was
+// added into y: its xhat is (u - beta) / gamma everywhere, the mask still comes from y).
+template <int SRC, bool AFFINE>
+__global__ __launch_bounds__(1024) void bn_out_bwd_kernel(const v4f* __restrict__ dy, const v4f* __restrict__ y,
+                                                          const v4f* __restrict__ uv, v4f* __restrict__ dc,
+                                                          BnParams p, int cpt, size_t n4, float* __restrict__ partial) {
+  extern __shared__ float s_red[];   // [blockDim][8] when AFFINE
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int cq = (int)(g % cpt);
+  v4f a, sh, mean, invstd, beta;
+  affine4(p, cq * 4, a, sh, mean, invstd);
+#pragma unroll
+  for (int k = 0; k < 4; k++) beta[k] = p.b ? p.b[cq * 4 + k] : 0.f;
+  v4f sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+  auto one = [&](size_t i, const v4f& d, const v4f& yy, const v4f& rr) {
+    v4f gq;
+#pragma unroll
+    for (int k = 0; k < 4; k++) gq[k] = yy[k] > 0.f ? d[k] : 0.f;
+    dc[i] = gq * a;
+    if (AFFINE) {
+      sg += gq;
+      sgx += gq * (SRC == 1 ? (yy - rr) - beta : (SRC == 2 ? rr - beta : yy - beta));
+    }
+  };
+  size_t i = g;
+  for (; i + stride < n4; i += 2 * stride) {
+    v4f d[2], yy[2], rr[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      d[u] = dy[i + u * stride];
+      yy[u] = y[i + u * stride];
+      if (SRC != 0 && AFFINE) rr[u] = uv[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) one(i + u * stride, d[u], yy[u], rr[u]);
+  }
+  for (; i < n4; i += stride) {
+    v4f d = dy[i], yy = y[i], rr = d;
+    if (SRC != 0 && AFFINE) rr = uv[i];
+    one(i, d, yy, rr);
+  }
+  if (AFFINE) {
+    float* mine = s_red + (size_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      mine[k] = sg[k];
+      mine[4 + k] = sgx[k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpt) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int t = threadIdx.x; t < (int)blockDim.x; t += cpt)
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] += s_red[(size_t)t * 8 + k];
+      float* out = partial + (size_t)blockIdx.x * 2 * cpt * 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        out[threadIdx.x * 4 + k] = acc[k];
+        out[cpt * 4 + threadIdx.x * 4 + k] = acc[4 + k];
+      }
+    }
+  }
+}
+
+// Second stage for up to 4 BatchNorm layers in ONE launch (a bottleneck's three or four): job j sums its partial rows
+// [rows][2][C] in a fixed order; grad_beta = sum of the first halves, grad_gamma = (sum of the second halves) / gamma.
+// gamma == 0 leaves xhat unrecoverable from the activation: the quotient is then inf / NaN on purpose (a silent 0 would
+// be a wrong gradient), see DESIGN.md 3.6.
+struct SumsJobs {
+  jdet_bn_sums_job_t job[4];
+  int first_block[5];
+  int njobs;
+};
+
+__global__ __launch_bounds__(1024) void bn_sums_finish_kernel(SumsJobs js) {
+  __shared__ float s_b[32][33];
+  __shared__ float s_g[32][33];
+  int j = 0;
+  while (j + 1 < js.njobs && (int)blockIdx.x >= js.first_block[j + 1]) j++;
+  const jdet_bn_sums_job_t job = js.job[j];
+  const int lane = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = ((int)blockIdx.x - js.first_block[j]) * 32 + lane;
+  const int C = job.C;
+  float acc = 0.f, accg = 0.f;
+  if (c < C) {
+    long b = rg;
+    for (; b + 96 < job.rows; b += 128) {          // 4 rows in flight per thread
+      const float v0 = job.partial[(size_t)b * 2 * C + c], v1 = job.partial[(size_t)(b + 32) * 2 * C + c];
+      const float v2 = job.partial[(size_t)(b + 64) * 2 * C + c], v3 = job.partial[(size_t)(b + 96) * 2 * C + c];
+      const float w0 = job.partial[(size_t)b * 2 * C + C + c], w1 = job.partial[(size_t)(b + 32) * 2 * C + C + c];
+      const float w2 = job.partial[(size_t)(b + 64) * 2 * C + C + c], w3 = job.partial[(size_t)(b + 96) * 2 * C + C + c];
+      acc += (v0 + v1) + (v2 + v3);
+      accg += (w0 + w1) + (w2 + w3);
+    }
+    for (; b < job.rows; b += 32) {
+      acc += job.partial[(size_t)b * 2 * C + c];
+      accg += job.partial[(size_t)b * 2 * C + C + c];
+    }
+  }
+  s_b[rg][lane] = acc;
+  s_g[rg][lane] = accg;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = 0.f, tg = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+      t += s_b[r][lane];
+      tg += s_g[r][lane];
+    }
+    if (job.grad_beta) job.grad_beta[c] = t;
+    if (job.grad_gamma) job.grad_gamma[c] = job.gamma ? tg / job.gamma[c] : tg;
+  }
+}
+
 // The same pass for a convolution's bias: g = dy * [y > 0] (when the conv is followed by a ReLU), dbias = sum g.
 // Replaces the framework's threshold_backward + per-channel reduce pair (two kernels, three tensor passes, the reduce
 // at ~1.7 TB/s) behind every conv + bias [+ ReLU] of the heads: one read of dy (and y), one write of g.
@@ -381,5 +501,86 @@ JDET_API int jdet_bias_act_backward(const float* grad_y_nhwc, const float* y_nhw
   if ((e = jdet_launch_status())) return e;
   hipLaunchKernelGGL((sums_finish_kernel<false>), dim3((C + 31) / 32), dim3(1024), 0, st, part, g.grid, C,
                      (float*)nullptr, grad_bias);
+  return jdet_launch_status();
+}
+
+namespace {
+// launch geometry of the output-based backward with sums: 1024-thread workgroups where the channel-quad count divides
+// 1024 (as the LDS combine needs), at most 256 of them
+int out_bwd_geometry(long P, int C, bool affine, Geo& g) {
+  int e = geometry(P, C, kBwdGrid, g);
+  if (e) return e;
+  if (affine && 1024 % g.cpt == 0) {
+    const size_t n4 = (size_t)P * g.cpt;
+    g.block = 1024;
+    long want = (long)((n4 + (size_t)g.block * 4 - 1) / ((size_t)g.block * 4));
+    g.grid = (int)(want < 1 ? 1 : (want > 256 ? 256 : want));
+  }
+  return JDET_OK;
+}
+}  // namespace
+
+/* rows of partial sums ([rows][2][C] floats) jdet_bn_act_backward_from_output writes for a (P, C) tensor; 0 = unsupported */
+JDET_API size_t jdet_bn_act_backward_from_output_rows(long P, int C) {
+  Geo g;
+  if (out_bwd_geometry(P, C, true, g) || P == 0) return 0;
+  return (size_t)g.grid;
+}
+
+/* Backward of a BatchNorm whose (possibly summed) output went through a ReLU, from the ACTIVATION y (conv_bn.hip's fused
+ * forward stores no conv output): grad_c = grad_y * [y > 0] * a, and -- sums non-NULL -- partial per-channel sums
+ * [rows][2][C] of g = grad_y * [y > 0] and g * t, rows = jdet_bn_act_backward_from_output_rows(P, C), to be finished by
+ * jdet_bn_sums_finish (which divides the second sum by gamma: t / gamma = xhat).  t is
+ *   own_output == NULL, identity == NULL :  y - beta                 y = relu(bn(c))
+ *   identity != NULL                     :  y - identity - beta      y = relu(bn(c) + identity)
+ *   own_output != NULL                   :  own_output - beta        y = relu(other + bn(c)), own_output = bn(c) */
+JDET_API int jdet_bn_act_backward_from_output(const float* grad_y_nhwc, const float* y_nhwc, const float* identity_nhwc,
+                                              const float* own_output_nhwc, long P, int C, const float* weight,
+                                              const float* bias, const float* running_mean, const float* running_var,
+                                              float eps, float* grad_c_nhwc, float* sums, size_t sums_bytes,
+                                              jdet_stream_t stream) {
+  Geo g;
+  const bool affine = sums != nullptr;
+  int e = out_bwd_geometry(P, C, affine, g);
+  if (e) return e;
+  if (P == 0) return JDET_OK;
+  if (!grad_y_nhwc || !y_nhwc || !grad_c_nhwc || !running_mean || !running_var) return JDET_E_BADARG;
+  if (identity_nhwc && own_output_nhwc) return JDET_E_BADARG;
+  if (affine && sums_bytes < sizeof(float) * (size_t)g.grid * 2 * C) return JDET_E_WORKSPACE;
+  BnParams p{weight, bias, running_mean, running_var, eps};
+  const size_t n4 = (size_t)P * g.cpt;
+  const size_t lds = affine ? sizeof(float) * 8 * (size_t)g.block : 0;
+  hipStream_t st = (hipStream_t)stream;
+  const v4f* dy = (const v4f*)grad_y_nhwc;
+  const v4f* y = (const v4f*)y_nhwc;
+  const v4f* r = (const v4f*)(identity_nhwc ? identity_nhwc : own_output_nhwc);
+  v4f* dc = (v4f*)grad_c_nhwc;
+#define JDET_BN_OUT_BWD(SRC, AFF) \
+  hipLaunchKernelGGL((bn_out_bwd_kernel<SRC, AFF>), dim3(g.grid), dim3(g.block), lds, st, dy, y, r, dc, p, g.cpt, n4, sums)
+  if (!affine) JDET_BN_OUT_BWD(0, false);
+  else if (identity_nhwc) JDET_BN_OUT_BWD(1, true);
+  else if (own_output_nhwc) JDET_BN_OUT_BWD(2, true);
+  else JDET_BN_OUT_BWD(0, true);
+#undef JDET_BN_OUT_BWD
+  return jdet_launch_status();
+}
+
+/* Second stage of the per-channel sums of up to 4 BatchNorm layers in one launch: job = {partial [rows][2][C], rows, C,
+ * gamma (C) or NULL, grad_gamma (C) or NULL, grad_beta (C) or NULL}: grad_beta = column sums of the first halves,
+ * grad_gamma = column sums of the second halves / gamma.  `jobs` is a HOST array read during the call. */
+JDET_API int jdet_bn_sums_finish(const jdet_bn_sums_job_t* jobs, int njobs, jdet_stream_t stream) {
+  if (njobs < 0 || njobs > 4 || (njobs && !jobs)) return JDET_E_BADARG;
+  if (njobs == 0) return JDET_OK;
+  SumsJobs js;
+  int blocks = 0;
+  for (int j = 0; j < njobs; j++) {
+    if (!jobs[j].partial || jobs[j].rows < 0 || jobs[j].C <= 0) return JDET_E_BADARG;
+    js.job[j] = jobs[j];
+    js.first_block[j] = blocks;
+    blocks += (jobs[j].C + 31) / 32;
+  }
+  for (int j = njobs; j < 5; j++) js.first_block[j] = blocks;
+  js.njobs = njobs;
+  hipLaunchKernelGGL(bn_sums_finish_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, js);
   return jdet_launch_status();
 }

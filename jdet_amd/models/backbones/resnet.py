@@ -3,16 +3,20 @@ the 3x3), `ResNet` L95-185 (return_stages, frozen_stages, norm_eval), `Resnet50`
 `Resnet101` L219-230.  Parameter names are the torchvision/Jittor ones (conv1, bn1, layerN.M.convK,
 downsample.0/1) so reference checkpoints map 1:1.
 
-The dense convs are the MFMA part of the path: they run through MIOpen/hipBLASLt in channels-last
-(the layout the RoI / deformable kernels want anyway); no custom conv kernels.  The
-eval-mode BatchNorm -> (+identity) -> ReLU chains between them are one fused HIP pass each
-(ops/frozen_bn.py) whenever the norm layer is an eval-mode BatchNorm2d on a channels-last fp32 tensor.
+The bottleneck blocks run on this repo's own fp32-MFMA convolution family (ops/conv_bn.py, csrc/conv_bn.hip): every
+1x1 / 3x3 convolution with its eval-mode BatchNorm, the identity add and the ReLU in the epilogue, forward and backward
+(data gradient = the same kernel on transposed weights, weight gradient = csrc/conv_wgrad.hip) -- whenever the input
+is a channels-last fp32 device tensor and the norm layers are eval-mode BatchNorm2d (`norm_eval`, the reference's
+training mode).  What is left to the library: the 7x7 stem, the stride-2 data gradients (three layers) and every case the
+fused path does not take (BasicBlock, training-mode BatchNorm, other dtypes), where the per-layer path below runs the
+library convolution + one fused BatchNorm / ReLU pass (ops/frozen_bn.py).
 """
 import os
 
 import torch
 from torch import nn
 
+from jdet_amd.ops import conv_bn
 from jdet_amd.ops.frozen_bn import frozen_bn_act
 from jdet_amd.utils.registry import BACKBONES
 
@@ -136,6 +140,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if conv_bn.fusable(self, x):
+            # the block on this repo's kernels: each conv with its BatchNorm / identity / ReLU in the epilogue, forward
+            # and backward (ops/conv_bn.py)
+            return conv_bn.bottleneck(self, x)
         identity = x
         out = frozen_bn_act(self.conv1(x), self.bn1)
         out = frozen_bn_act(self.conv2(out), self.bn2)
@@ -213,6 +221,9 @@ class ResNet(nn.Module):
         x = self.conv1(x)
         x = frozen_bn_act(x, self.bn1) if isinstance(self.bn1, nn.BatchNorm2d) else self.relu(self.bn1(x))
         x = self.maxpool(x)
+        if conv_bn.ENABLED and x.is_cuda and torch.is_grad_enabled():
+            # the data-gradient weights of every trainable bottleneck, rewritten in one launch per step
+            conv_bn.prepare([m for i in range(1, 5) for m in getattr(self, "layer%d" % i) if isinstance(m, Bottleneck)])
         for i in range(1, 5):
             name = f"layer{i}"
             x = getattr(self, name)(x)

@@ -1,0 +1,288 @@
+"""The bottleneck convolution family (csrc/conv_bn.hip, ops/conv_bn.py) against float64 framework references:
+ * every launch mode -- FORWARD (BatchNorm / residual / ReLU epilogue), ADD (identity gradient joins a data gradient),
+   MASK (ReLU mask + BatchNorm sums + scale of the layer below) -- at 1x1 / 3x3, stride 1 / 2, every tile shape, with
+   and without the cross-workgroup K split;
+ * the general weight gradient (R, stride) and the flipped / transposed data-gradient weights;
+ * a whole Bottleneck (python/jdet/models/backbones/resnet.py:L61-93 under norm_eval) -- output and EVERY gradient
+   (input, conv weights, BatchNorm weight / bias) -- against the same module in float64 on the framework's ops, for
+   identity and downsample blocks at every ResNet-50/101 channel configuration;
+ * ResNet-50 end to end: fused path vs the per-layer path (JDET_BOTTLENECK_FUSED off).
+
+Tolerances: fp32 products and accumulation (v_mfma_f32_32x32x2_f32) over K <= 4608 in a tiling-dependent order:
+forward / data gradient |err| <= 2e-5 * max|ref| + 1e-6; weight gradients and BatchNorm sums (K = positions) 5e-5."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, ref, rel, what=""):
+    err = (a.double().cpu() - ref.double().cpu()).abs().max().item()
+    lim = rel * ref.abs().max().item() + 1e-6
+    assert err <= lim, "%s: err %.3e > %.3e" % (what, err, lim)
+
+
+def _bn(C, g, dev):
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    return bn.to(dev).eval()
+
+
+def _bn64(bn, c):
+    """eval-mode BatchNorm of an NHWC double tensor"""
+    a = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    return (c - bn.running_mean.double()) * a + bn.bias.double()
+
+
+def _conv64(x_nhwc, w_krsc, stride):
+    R = w_krsc.shape[1]
+    y = F.conv2d(x_nhwc.double().permute(0, 3, 1, 2), w_krsc.double().permute(0, 3, 1, 2), None, stride, R // 2)
+    return y.permute(0, 2, 3, 1)
+
+
+FWD_CASES = [
+    # N, H, W, Cin, Cout, R, stride
+    (2, 16, 16, 64, 64, 1, 1),
+    (2, 16, 16, 64, 256, 1, 1),
+    (1, 17, 9, 256, 64, 1, 1),       # ragged positions
+    (2, 16, 16, 128, 128, 3, 1),
+    (2, 16, 16, 128, 128, 3, 2),
+    (1, 15, 13, 64, 64, 3, 2),       # odd sizes under stride 2
+    (2, 16, 16, 256, 512, 1, 2),     # downsample
+    (1, 9, 7, 48, 40, 3, 1),         # 16-deep K steps, channels off the tile grid
+    (2, 8, 8, 2048, 512, 1, 1),      # layer4 conv1: K split over workgroups
+    (2, 8, 8, 512, 512, 3, 1),       # layer4 conv2
+    (2, 32, 32, 512, 128, 1, 1),
+    (1, 64, 64, 256, 256, 3, 1),     # 128 x 128 tiles
+]
+TILES = [0, 64, 65, 66, 128, 129, 130]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,R,stride", FWD_CASES)
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_forward_epilogue_matches_float64(dev, N, H, W, Cin, Cout, R, stride, tile, res, relu):
+    from jdet_amd.ops import conv_bn as CB
+    if tile and N * H * W > 2048 and tile not in (64, 128):
+        pytest.skip("the measurement-aid tile variants are exercised on the small cases")
+    g = torch.Generator().manual_seed(N * 100 + Cin + Cout + R)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, R, R, Cin, generator=g) / (R * Cin ** 0.5)).to(dev)
+    bn = _bn(Cout, g, dev)
+    Ho, Wo = CB.out_size(H, R, stride), CB.out_size(W, R, stride)
+    r = torch.randn(N, Ho, Wo, Cout, generator=g).to(dev) if res else None
+    y = CB.conv_bn_nhwc(x, w, stride, bn, r, relu, tile=tile)
+    ref = _bn64(bn, _conv64(x, w, stride))
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    assert y.shape == (N, Ho, Wo, Cout)
+    _close(y, ref, 2e-5, "forward")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,R", [(2, 16, 16, 256, 64, 1), (2, 16, 16, 128, 128, 3), (2, 8, 8, 2048, 512, 1),
+                                              (1, 9, 7, 48, 40, 3), (1, 64, 64, 256, 256, 3), (2, 8, 8, 512, 512, 3)])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_mask_and_add_modes_match_float64(dev, N, H, W, Cin, Cout, R, tile):
+    """MASK: g = conv * [act > 0], y = g * a, sums -> (dbeta, dgamma) of the layer below's BatchNorm through
+    jdet_bn_sums_finish, against sum g and sum g * xhat computed from the TRUE conv output of that layer;
+    ADD: y = conv + grad_out * [act > 0]."""
+    from jdet_amd import _lib as L
+    from jdet_amd.ops import conv_bn as CB
+    g = torch.Generator().manual_seed(Cin + Cout + R + tile)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, R, R, Cin, generator=g) / (R * Cin ** 0.5)).to(dev)
+    bn = _bn(Cout, g, dev)
+    c_below = torch.randn(N, H, W, Cout, generator=g).to(dev)           # the layer below: act = relu(bn(c_below))
+    act = _bn64(bn, c_below.double()).clamp_min(0).float()
+    conv = _conv64(x, w, 1)
+    y, sums = CB.conv_bn_nhwc(x, w, 1, bn, mode=L.EPI_MASK, act=act, want_sums=True, tile=tile)
+    a = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+    gm = conv * (act > 0)
+    _close(y, gm * a, 2e-5, "mask")
+    (dgamma, dbeta), = CB.bn_sums_finish([(sums, bn)])
+    xhat = (c_below.double() - bn.running_mean.double()) / torch.sqrt(bn.running_var.double() + bn.eps)
+    _close(dbeta, gm.sum((0, 1, 2)), 5e-5, "dbeta")
+    ref_gamma = (gm * xhat).sum((0, 1, 2))
+    err = (dgamma.double() - ref_gamma).abs().max().item()
+    assert err <= 5e-5 * max(ref_gamma.abs().max().item(), gm.abs().sum((0, 1, 2)).max().item() * 1e-2) + 1e-5, err
+    go = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    y2 = CB.conv_bn_nhwc(x, w, 1, None, mode=L.EPI_ADD, grad_out=go, act=act, tile=tile)
+    _close(y2, conv + go.double() * (act > 0), 2e-5, "add")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,R,stride", FWD_CASES)
+@pytest.mark.parametrize("ksplit", [0, 1, 5])
+def test_general_weight_gradient_matches_float64(dev, N, H, W, Cin, Cout, R, stride, ksplit):
+    from jdet_amd.ops import conv_bn as CB
+    g = torch.Generator().manual_seed(Cin * 3 + Cout + R + stride)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    Ho, Wo = CB.out_size(H, R, stride), CB.out_size(W, R, stride)
+    gy = torch.randn(N, Ho, Wo, Cout, generator=g).to(dev)
+    base = torch.randn(Cout, R, R, Cin, generator=g).to(dev)
+    out = base.clone()
+    CB.conv_wgrad_nhwc(x, gy, R, stride, out, ksplit)
+    w64 = torch.zeros(Cout, Cin, R, R, dtype=torch.float64, device=dev, requires_grad=True)
+    yy = F.conv2d(x.double().permute(0, 3, 1, 2), w64, None, stride, R // 2)
+    (gw,) = torch.autograd.grad(yy, w64, gy.double().permute(0, 3, 1, 2))
+    ref = gw.permute(0, 2, 3, 1)
+    err = ((out - base).double() - ref).abs().max().item()
+    assert err <= 5e-5 * ref.abs().max().item() + 1e-5, err
+
+
+def test_dgrad_weight_bank_and_data_gradient(dev):
+    """DgradBank: (Cin, R, R, Cout)[ci][flipped tap][co] = W[co][tap][ci] for several layers in one launch, refreshed
+    when a weight changes; the forward kernel on those weights IS the data gradient of the stride-1 convolution."""
+    from jdet_amd.ops import conv_bn as CB
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(64, 256, 1, bias=False), torch.nn.Conv2d(128, 128, 3, padding=1, bias=False),
+             torch.nn.Conv2d(48, 40, 3, padding=1, bias=False)]
+    convs = [c.to(dev).to(memory_format=torch.channels_last) for c in convs]
+    bank = CB.DgradBank(convs)
+    bank.refresh()
+    for c in convs:
+        ref = c.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+        assert torch.equal(bank.get(c), ref)
+    with torch.no_grad():
+        convs[1].weight.mul_(2.0)          # a new version: `get` refreshes the bank
+    assert torch.equal(bank.get(convs[1]), convs[1].weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous())
+    for c in convs:
+        x = torch.randn(2, c.in_channels, 12, 10, device=dev, dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(x, c.weight.double(), None, 1, c.padding)
+        gy = torch.randn_like(y)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        own = CB.conv_bn_nhwc(gy.float().permute(0, 2, 3, 1).contiguous(), bank.get(c), 1)
+        _close(own, gx.permute(0, 2, 3, 1), 2e-5, "dgrad")
+
+
+def _make_block(inplanes, planes, stride, downsample, dev, seed):
+    from jdet_amd.models.backbones.resnet import Bottleneck, conv1x1
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    ds = None
+    if downsample:
+        ds = torch.nn.Sequential(conv1x1(inplanes, planes * 4, stride), torch.nn.BatchNorm2d(planes * 4))
+    blk = Bottleneck(inplanes, planes, stride, ds)
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    blk = blk.to(dev).eval()        # eval-mode BatchNorm, parameters trainable: the reference's norm_eval training mode
+    for p in blk.parameters():
+        if p.dim() == 4:
+            p.data = p.data.contiguous(memory_format=torch.channels_last)
+    return blk
+
+
+def _block64(blk, x64):
+    """the same Bottleneck on the framework's ops in float64 (resnet.py:L61-93)"""
+    import copy
+    ref = copy.deepcopy(blk).double()
+    y = F.relu(ref.bn1(F.conv2d(x64, ref.conv1.weight)))
+    y = F.relu(ref.bn2(F.conv2d(y, ref.conv2.weight, None, ref.conv2.stride, 1)))
+    y = ref.bn3(F.conv2d(y, ref.conv3.weight))
+    idn = x64
+    if ref.downsample is not None:
+        idn = ref.downsample[1](F.conv2d(x64, ref.downsample[0].weight, None, ref.downsample[0].stride))
+    return F.relu(y + idn), ref
+
+
+BLOCKS = [
+    # inplanes, planes, stride, downsample, N, H, W
+    (256, 64, 1, False, 2, 24, 20),     # layer1 identity block
+    (64, 64, 1, True, 2, 16, 16),       # layer1.0: stride-1 downsample
+    (256, 128, 2, True, 2, 24, 20),     # layer2.0
+    (512, 128, 1, False, 2, 16, 12),    # layer2 identity
+    (512, 256, 2, True, 1, 16, 16),     # layer3.0
+    (1024, 256, 1, False, 2, 8, 8),     # layer3 identity
+    (1024, 512, 2, True, 2, 8, 8),      # layer4.0
+    (2048, 512, 1, False, 2, 4, 4),     # layer4 identity
+    (512, 128, 1, False, 1, 64, 64),    # 128 x 128 tiles in the 1x1 layers
+]
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,downsample,N,H,W", BLOCKS)
+@pytest.mark.parametrize("need_gx", [True, False])
+def test_bottleneck_forward_and_every_gradient(dev, inplanes, planes, stride, downsample, N, H, W, need_gx):
+    from jdet_amd.ops import conv_bn as CB
+    blk = _make_block(inplanes, planes, stride, downsample, dev, inplanes + planes + stride)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, inplanes, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(need_gx)
+    assert CB.fusable(blk, x)
+    y = blk(x)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    x64 = x.detach().double().requires_grad_(need_gx)
+    y64, ref = _block64(blk, x64)
+    _close(y, y64, 2e-5, "block output")
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    y64.backward(gy.double())
+    if need_gx:
+        _close(x.grad, x64.grad, 5e-5, "grad_x")
+    names = dict(blk.named_parameters())
+    for name, p64 in ref.named_parameters():
+        assert names[name].grad is not None, name
+        assert names[name].grad.shape == names[name].shape
+        _close(names[name].grad, p64.grad, 1e-4, name)
+
+
+def test_frozen_block_and_eval_take_the_fused_forward_only(dev):
+    from jdet_amd.ops import conv_bn as CB
+    blk = _make_block(256, 64, 1, False, dev, 3)
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 256, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    assert CB.fusable(blk, x)
+    y = blk(x)
+    assert not y.requires_grad
+    y64, _ = _block64(blk, x.double())
+    _close(y, y64, 2e-5, "frozen block")
+    # gradients THROUGH a frozen block are the per-layer path's business
+    assert not CB.fusable(blk, x.clone().requires_grad_(True))
+    # BatchNorm in training mode: not this path
+    blk.train()
+    assert not CB.fusable(blk, x)
+
+
+def test_resnet50_fused_equals_the_per_layer_path(dev):
+    """ResNet-50 (frozen_stages 1, norm_eval) on a 2 x 3 x 128 x 128 batch: stage outputs and every trainable parameter's
+    gradient, fused bottlenecks vs the per-layer path (library convolutions + frozen-BN passes)."""
+    from jdet_amd.models.backbones.resnet import Resnet50
+    from jdet_amd.ops import conv_bn as CB
+    torch.manual_seed(11)
+    m = Resnet50(return_stages=["layer1", "layer2", "layer3", "layer4"], frozen_stages=1, norm_eval=True).to(dev).train()
+    for p in m.parameters():
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+            p.data = p.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(2, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    gys = None
+    results = []
+    for fused in (True, False):
+        CB.ENABLED = fused
+        try:
+            m.zero_grad(set_to_none=True)
+            outs = m(x)
+            if gys is None:
+                gys = [torch.randn_like(o) for o in outs]
+            torch.autograd.backward(outs, gys)
+            results.append(([o.detach().clone() for o in outs],
+                            {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        finally:
+            CB.ENABLED = True
+    (oa, ga), (ob, gb) = results
+    for a, b in zip(oa, ob):
+        _close(a, b, 1e-4, "stage output")
+    assert set(ga) == set(gb) and len(ga) > 100
+    for n in ga:
+        err = (ga[n] - gb[n]).abs().max().item()
+        assert err <= 2e-4 * gb[n].abs().max().item() + 1e-5, (n, err)
