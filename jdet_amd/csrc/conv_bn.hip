@@ -398,9 +398,11 @@ Plan make_plan(long M, int Cin, int Cout, int taps, int tile, bool workspace) {
   const int edge = tile & ~3;
   const long tiles128 = ((M + 127) / 128) * ((Cout + 127) / 128);
   const long tiles64 = ((M + 63) / 64) * ((Cout + 63) / 64);
-  // 128^2 tiles once they alone fill the chip -- and only if the layer HAS 128 output channels (Cout = 64 would run
-  // half of every MFMA on zero columns)
-  const bool big = tile ? edge == 128 : (tiles128 >= 512 && Cout > 64);
+  // 128^2 tiles only for the long reductions (3x3 from 256 input channels up) on maps whose 128-tiles alone fill the
+  // chip: measured at the ResNet-50 shapes of a 2 x 1024^2 step (scripts/conv_bn_timing.py tiles, profiles/
+  // r05_conv_bn.md), the 64^2 tile without the intra-workgroup K split wins or ties everywhere else (64 -> 256 at
+  // 2 x 256^2: 80 vs 103 us; 128 -> 512 at 2 x 128^2: 59 vs 70; 256 -> 256 3x3 at 2 x 64^2: 92 vs 171)
+  const bool big = tile ? edge == 128 : (tiles128 >= 512 && Cout > 64 && (long)taps * Cin >= 2304);
   const bool k32 = Cin % 32 == 0 && !(tile & 1);
   const int steps = taps * (Cin / (k32 ? 32 : 16));
   // intra-workgroup K split (8 waves): conv_igemm.hip's rule; not for a K loop of one or two steps (the hand-over

@@ -13,7 +13,8 @@ derives for that chain.  One block =
               g2' = dgrad3(g3') * [y2 > 0] * a2 (+ sums of bn2)     conv_bn, mode MASK
               g1' = dgrad2(g2') * [y1 > 0] * a1 (+ sums of bn1)     conv_bn, mode MASK  (stride 2: the library's data gradient)
               gx  = dgrad1(g1') + g * [y3 > 0]                      conv_bn, mode ADD   (downsample: + its data gradient)
-              gW_k += wgrad(g_k', input_k)                          conv_wgrad into one zero-filled buffer per block
+              gW_k = wgrad(g_k', input_k)                           the library's kernels, or (JDET_BOTTLENECK_WGRAD=own)
+                                                                    csrc/conv_wgrad.hip into one zero-filled buffer per block
               dgamma_k, dbeta_k                                     one finish launch for the block's BatchNorms
 
 No conv output is ever stored (the normalised input of a BatchNorm is recovered from its activation: xhat = (y - beta) /
@@ -36,6 +37,10 @@ from torch import nn
 from jdet_amd import _lib as L
 
 ENABLED = os.environ.get("JDET_BOTTLENECK_FUSED", "1") == "1"
+# Weight gradients of the fused block: "lib" = the library's kernels on the materialised g' tensors (default: measured
+# 10-40 us per layer faster than csrc/conv_wgrad.hip at the backbone's shapes, profiles/r05_conv_bn.md), "own" = the
+# general (R, stride) kernel of this repo accumulating into one zero-filled buffer per block.
+OWN_WGRAD = os.environ.get("JDET_BOTTLENECK_WGRAD", "lib") == "own"
 # stride-2 3x3 / 1x1 data gradients: the library's (a strided data gradient is a different kernel, not built here)
 _PLAN = {}           # (N, H, W, Cin, Cout, R, stride) -> (workspace bytes, sums rows with it)
 
@@ -327,25 +332,37 @@ class _BottleneckFunction(torch.autograd.Function):
         bank = _bank(blk)
         need_gx = ctx.needs_input_grad[0]
         convs = _block_convs(blk)
-        # one zero-filled buffer for the block's weight gradients (the kernel accumulates: K chunks meet by atomics)
-        sizes = [c.weight.numel() for c in convs]
-        gwbuf = torch.zeros((sum(sizes),), dtype=torch.float32, device=g.device)
-        gws, off = [], 0
-        for c, n in zip(convs, sizes):
-            Co, Ci, R, _ = c.weight.shape
-            gws.append(gwbuf[off:off + n].view(Co, R, R, Ci))
-            off += n
-        sums = []
+        gws = [None] * len(convs)
+        if OWN_WGRAD:
+            # one zero-filled buffer for the block's weight gradients (the kernel accumulates: K chunks meet by atomics)
+            sizes = [c.weight.numel() for c in convs]
+            gwbuf = torch.zeros((sum(sizes),), dtype=torch.float32, device=g.device)
+            off = 0
+            for k, (c, n) in enumerate(zip(convs, sizes)):
+                Co, Ci, R, _ = c.weight.shape
+                gws[k] = gwbuf[off:off + n].view(Co, R, R, Ci)
+                off += n
+
+        def wgrad(k, xin, gy, R, stride):
+            c = convs[k]
+            if OWN_WGRAD:
+                conv_wgrad_nhwc(xin, gy, R, stride, gws[k])
+                # the parameter's own strides: a 1x1 weight is plain (Cout, Cin, 1, 1) memory, a 3x3 one channels-last
+                gws[k] = gws[k].view(c.weight.shape) if R == 1 else gws[k].permute(0, 3, 1, 2)
+            else:
+                gws[k] = torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), c.weight,
+                                                             None, [stride, stride], [R // 2, R // 2], [1, 1], False,
+                                                             [0, 0], 1, [False, True, False])[1]
         # block output: y3 = relu(bn3(c3) + identity)
         g3p, s3 = bn_backward_from_output(g, y3, blk.bn3, identity=idn if ds is not None else xn)
         g2p, s2 = conv_bn_nhwc(g3p, bank.get(blk.conv3), 1, blk.bn2, mode=L.EPI_MASK, act=y2, want_sums=True)
-        conv_wgrad_nhwc(y2, g3p, 1, 1, gws[2])
+        wgrad(2, y2, g3p, 1, 1)
         if st == 1:
             g1p, s1 = conv_bn_nhwc(g2p, bank.get(blk.conv2), 1, blk.bn1, mode=L.EPI_MASK, act=y1, want_sums=True)
         else:
             g1p, s1 = bn_backward_from_output(_lib_dgrad(g2p, y1, blk.conv2.weight, st, 1), y1, blk.bn1)
-        conv_wgrad_nhwc(y1, g2p, 3, st, gws[1])
-        conv_wgrad_nhwc(xn, g1p, 1, 1, gws[0])
+        wgrad(1, y1, g2p, 3, st)
+        wgrad(0, xn, g1p, 1, 1)
         sums = [(s1, blk.bn1), (s2, blk.bn2), (s3, blk.bn3)]
         gx = None
         if ds is None:
@@ -354,7 +371,7 @@ class _BottleneckFunction(torch.autograd.Function):
         else:
             gdp, sd = bn_backward_from_output(g, y3, ds[1], own_output=idn)
             sums.append((sd, ds[1]))
-            conv_wgrad_nhwc(xn, gdp, 1, st, gws[3])
+            wgrad(3, xn, gdp, 1, st)
             if need_gx:
                 if st == 1:
                     gxd = conv_bn_nhwc(gdp, bank.get(ds[0]), 1, None)
@@ -363,10 +380,8 @@ class _BottleneckFunction(torch.autograd.Function):
                 gx = conv_bn_nhwc(g1p, bank.get(blk.conv1), 1, None, residual=gxd)
         bn_grads = bn_sums_finish(sums)
         out = [gx.permute(0, 3, 1, 2) if gx is not None else None, None]
-        for k, c in enumerate(convs):
-            # the parameter's own strides: a 1x1 weight is plain (Cout, Cin, 1, 1) memory, a 3x3 one channels-last
-            gw = gws[k].view(c.weight.shape) if c.kernel_size == (1, 1) else gws[k].permute(0, 3, 1, 2)
-            out += [gw, bn_grads[k][0], bn_grads[k][1]]
+        for k in range(len(convs)):
+            out += [gws[k], bn_grads[k][0], bn_grads[k][1]]
         return tuple(out)
 
 

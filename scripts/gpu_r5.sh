@@ -11,8 +11,18 @@ run_a() {   # first contact of the bottleneck family: parity, per-layer / per-bl
   bash scripts/ab_step.sh -n 1 -s 20 "JDET_BOTTLENECK_FUSED=1" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
 }
 
+run_b() {   # after the tile rule + library weight gradients: the whole parity file, block times, step A/B, step profile
+  OUT=$R/gpurun_out/r5_b; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_conv_bn.py -q 2>&1 | tail -15 | tee $OUT/pytest.txt
+  timeout 600 python scripts/conv_bn_timing.py blocks layers 2>&1 | grep -v Warning | tee $OUT/timing.txt
+  JDET_BOTTLENECK_WGRAD=own timeout 300 python scripts/conv_bn_timing.py blocks 2>&1 | grep -v Warning | tee $OUT/timing_own_wgrad.txt
+  bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_FUSED=1" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
+  bash scripts/gpu_prof_s2anet.sh > $OUT/prof.txt 2>&1; cp gpurun_out/prof_s2anet/steady_state.txt $OUT/steady_state_fused.txt
+  rm -rf gpurun_out/prof_s2anet/trace
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a} [args]"; exit 2;;
+  a|b) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b} [args]"; exit 2;;
 esac

@@ -142,7 +142,7 @@ def test_dgrad_weight_bank_and_data_gradient(dev):
     from jdet_amd.ops import conv_bn as CB
     torch.manual_seed(0)
     convs = [torch.nn.Conv2d(64, 256, 1, bias=False), torch.nn.Conv2d(128, 128, 3, padding=1, bias=False),
-             torch.nn.Conv2d(48, 40, 3, padding=1, bias=False)]
+             torch.nn.Conv2d(48, 32, 3, padding=1, bias=False)]
     convs = [c.to(dev).to(memory_format=torch.channels_last) for c in convs]
     bank = CB.DgradBank(convs)
     bank.refresh()
@@ -212,8 +212,11 @@ BLOCKS = [
 
 @pytest.mark.parametrize("inplanes,planes,stride,downsample,N,H,W", BLOCKS)
 @pytest.mark.parametrize("need_gx", [True, False])
-def test_bottleneck_forward_and_every_gradient(dev, inplanes, planes, stride, downsample, N, H, W, need_gx):
+@pytest.mark.parametrize("own_wgrad", [False, True])
+def test_bottleneck_forward_and_every_gradient(dev, monkeypatch, inplanes, planes, stride, downsample, N, H, W, need_gx,
+                                               own_wgrad):
     from jdet_amd.ops import conv_bn as CB
+    monkeypatch.setattr(CB, "OWN_WGRAD", own_wgrad)
     blk = _make_block(inplanes, planes, stride, downsample, dev, inplanes + planes + stride)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, inplanes, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
