@@ -174,6 +174,28 @@ void conv_bn_kernel(CbArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+  // ---- the neighbour tile(s) of the epilogue (residual | grad_out + act | act): with one 32 x 32 tile per wave (BT = 64)
+  // they are requested HERE, ahead of the K loop -- the 1x1 layers of the big maps run two to eight K steps, and a
+  // tile fetched only after them costs as much again as the loop (64 -> 256 channels at 2 x 256^2 with a residual:
+  // 133 us against 80 us without one, profiles/r05_conv_bn.md)
+  const jdet_conv_epilogue_t& ep = a.ep;
+  const int mode = ep.mode;
+  const float* p0 = mode == JDET_EPI_FORWARD ? ep.residual : (mode == JDET_EPI_ADD ? ep.grad_out : ep.act);
+  const float* p1 = mode == JDET_EPI_ADD ? ep.act : nullptr;
+  constexpr bool PRE = T == 1;
+  float pre0[PRE ? 16 : 1], pre1[PRE ? 16 : 1];
+  if (PRE && !a.partial && kg == 0) {
+    const long mrow = m0 + wm * (BT / 2) + 4 * (lane >> 5);
+    const int n = n0 + wn * (BT / 2) + (lane & 31);
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const long m = mrow + (e & 3) + 8 * (e >> 2);
+      const bool ok = n < a.Cout && m < M;
+      pre0[e] = (p0 && ok) ? p0[(size_t)m * a.Cout + n] : 0.f;
+      pre1[e] = (p1 && ok) ? p1[(size_t)m * a.Cout + n] : 0.f;
+    }
+  }
+
   int tap = step0 / spt, c = (step0 - tap * spt) * BK;
   set_tap(tap);
   load_step(tap, c);
@@ -230,13 +252,9 @@ void conv_bn_kernel(CbArgs a) {
   // ---- epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
   // The neighbour tiles (residual | grad_out + act_out | act) are fetched 8 rows at a time BEFORE the stores of those
   // rows: the loads are in flight together instead of one per dependent store.
-  const jdet_conv_epilogue_t& ep = a.ep;
-  const int mode = ep.mode;
   float cs1[T], cs2[T];
 #pragma unroll
   for (int j = 0; j < T; j++) cs1[j] = cs2[j] = 0.f;
-  const float* p0 = mode == JDET_EPI_FORWARD ? ep.residual : (mode == JDET_EPI_ADD ? ep.grad_out : ep.act);
-  const float* p1 = mode == JDET_EPI_ADD ? ep.act : nullptr;
 #pragma unroll
   for (int i = 0; i < T; i++) {
     const long mrow = m0 + wm * (BT / 2) + i * 32 + 4 * (lane >> 5);
@@ -252,7 +270,13 @@ void conv_bn_kernel(CbArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; h++) {          // 8 rows at a time: their neighbour loads are in flight together
         float t0[8], t1[8];
-        if (!a.partial) {
+        if (PRE) {
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            t0[u] = pre0[h * 8 + u];
+            t1[u] = pre1[h * 8 + u];
+          }
+        } else if (!a.partial) {
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const int e = h * 8 + u;

@@ -6,11 +6,11 @@ orientation-pooled map), initialisation, target dict keys and the loss bookkeepi
 reference; the device work underneath is this repo's HIP path: DeformConv sampling, ARF gather,
 rotated IoU, fused max-IoU assignment, fused delta codec, rotated NMS.
 """
-import contextlib
 import os
 
 import torch
 from torch import nn
+from torch.nn.utils.stateless import _reparametrize_module      # (what torch.func.functional_call is built on)
 
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
@@ -315,7 +315,17 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
                 side = _side_stream(feats[0].device)
                 main = torch.cuda.current_stream(feats[0].device)
                 side.wait_stream(main)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            if side is not None:
+                # The towers' weights are shared by both branches.  The side branch reads them through ALIASES made
+                # here, on the main stream: the gradients of the side branch then reach every parameter through a view
+                # node that lives on the main stream, where its AccumulateGrad node (and DDP's bucket hook) lives too --
+                # the autograd engine orders side -> main at that node like at any other cross-stream edge.  Reading
+                # the parameters directly on the side stream made their AccumulateGrad nodes' stream disagree with one
+                # of the two producers ("AccumulateGrad node's stream does not match ..." in the round-4 bench stderr).
+                alias = {n: p.view_as(p) for n, p in self.named_parameters() if p.requires_grad}
+                with torch.cuda.stream(side), _reparametrize_module(self, alias):
+                    packed = self.forward_packed([feats[i] for i in small], [self.anchor_strides[i] for i in small])
+            else:
                 packed = self.forward_packed([feats[i] for i in small], [self.anchor_strides[i] for i in small])
             for i, o in zip(small, packed):
                 outs[i] = o

@@ -21,8 +21,17 @@ run_b() {   # after the tile rule + library weight gradients: the whole parity f
   rm -rf gpurun_out/prof_s2anet/trace
 }
 
+run_c() {   # epilogue prefetch + side-stream aliases: parity, two-rank tests, times, DDP overhead on one GPU
+  OUT=$R/gpurun_out/r5_c; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_conv_bn.py tests/test_gpu_ddp_detectors.py tests/test_gpu_s2anet.py tests/test_gpu_frozen_bn.py tests/test_gpu_conv1x1.py -q 2>&1 | tail -15 | tee $OUT/pytest.txt
+  timeout 600 python scripts/conv_bn_timing.py layers blocks 2>&1 | grep -v Warning | tee $OUT/timing.txt
+  bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_FUSED=1" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
+  JDET_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 > $OUT/force_dist.json 2> $OUT/force_dist.err
+  grep -o '"ms_per_step": [0-9.]*' $OUT/force_dist.json; grep -c "AccumulateGrad" $OUT/force_dist.err
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b} [args]"; exit 2;;
+  a|b|c) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c} [args]"; exit 2;;
 esac
