@@ -350,9 +350,14 @@ class _BottleneckFunction(torch.autograd.Function):
                 # the parameter's own strides: a 1x1 weight is plain (Cout, Cin, 1, 1) memory, a 3x3 one channels-last
                 gws[k] = gws[k].view(c.weight.shape) if R == 1 else gws[k].permute(0, 3, 1, 2)
             else:
-                gws[k] = torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), c.weight,
-                                                             None, [stride, stride], [R // 2, R // 2], [1, 1], False,
-                                                             [0, 0], 1, [False, True, False])[1]
+                gw = torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), xin.permute(0, 3, 1, 2), c.weight, None,
+                                                         [stride, stride], [R // 2, R // 2], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+                if R == 1 and gw.stride() != c.weight.stride():
+                    # (Cout, Cin, 1, 1) is one memory order under two stride spellings; the parameter's own keeps the
+                    # gradient layout contract (DDP's bucket views would otherwise copy and warn)
+                    gw = gw.as_strided(c.weight.shape, c.weight.stride())
+                gws[k] = gw
         # block output: y3 = relu(bn3(c3) + identity)
         g3p, s3 = bn_backward_from_output(g, y3, blk.bn3, identity=idn if ds is not None else xn)
         g2p, s2 = conv_bn_nhwc(g3p, bank.get(blk.conv3), 1, blk.bn2, mode=L.EPI_MASK, act=y2, want_sums=True)

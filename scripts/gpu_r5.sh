@@ -26,12 +26,20 @@ run_c() {   # epilogue prefetch + side-stream aliases: parity, two-rank tests, t
   timeout 900 python -m pytest tests/test_gpu_conv_bn.py tests/test_gpu_ddp_detectors.py tests/test_gpu_s2anet.py tests/test_gpu_frozen_bn.py tests/test_gpu_conv1x1.py -q 2>&1 | tail -15 | tee $OUT/pytest.txt
   timeout 600 python scripts/conv_bn_timing.py layers blocks 2>&1 | grep -v Warning | tee $OUT/timing.txt
   bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_FUSED=1" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
-  JDET_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 > $OUT/force_dist.json 2> $OUT/force_dist.err
+  RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 JDET_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 > $OUT/force_dist.json 2> $OUT/force_dist.err
   grep -o '"ms_per_step": [0-9.]*' $OUT/force_dist.json; grep -c "AccumulateGrad" $OUT/force_dist.err
+}
+
+run_d() {   # the side-stream two-rank test with its full report + the one-GPU DDP overhead
+  OUT=$R/gpurun_out/r5_d; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_ddp_detectors.py -q -x --tb=short -k "side_stream or eager" > $OUT/pytest_full.txt 2>&1; tail -5 $OUT/pytest_full.txt
+  RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511 JDET_BENCH_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 > $OUT/force_dist.json 2> $OUT/force_dist.err
+  grep -o '"ms_per_step": [0-9.]*' $OUT/force_dist.json; grep -c "AccumulateGrad" $OUT/force_dist.err
+  timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 2> $OUT/plain.err | grep -o '"ms_per_step": [0-9.]*'; grep -c "AccumulateGrad" $OUT/plain.err
 }
 
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c} [args]"; exit 2;;
+  a|b|c|d) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d} [args]"; exit 2;;
 esac
