@@ -310,18 +310,30 @@ int launch(const WgradArgs& a, hipStream_t st) {
 
 int wgrad_out_dim(int in, int R, int stride) { return (in + 2 * (R / 2) - R) / stride + 1; }
 
+// general = the backbone's entry point (jdet_conv_wgrad): 64 x 64 tiles and a split aimed at ~2300 workgroups of at
+// least 32 K steps -- measured at every ResNet-50 layer shape of a 2 x 1024^2 step (scripts/conv_bn_timing.py wgrad,
+// profiles/r05_conv_bn.md): the smaller tile multiplies the workgroups a short tile list offers (a 128 -> 512 1x1 layer
+// has FOUR 128^2 tiles) and beats both the 128^2 form (45 vs 59-77 us there) and the library (45 vs 48 us; 3x3
+// 128 -> 128: 90 vs 104 us).
 int run_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, int N, int H, int W, int Cin, int Cout,
-              int R, int stride, float* gw, int ksplit, hipStream_t st) {
+              int R, int stride, float* gw, int ksplit, hipStream_t st, bool general = false) {
   const int Ho = wgrad_out_dim(H, R, stride), Wo = wgrad_out_dim(W, R, stride);
   const long M = (long)N * Ho * Wo, Mx = (long)N * H * W;
   if ((M + BK) * Cout >= (1L << 30) || (Mx + BK) * Cin >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
-  const int tm = Cout > 64 ? 2 : 1, tn = Cin > 64 ? 2 : 1;
+  // bit 17: 64 x 64 tiles whatever the channel counts, bit 18: 128-wide tiles where the channels allow (measurement aids)
+  const int small = ((ksplit >> 17) & 1) || (general && !((ksplit >> 18) & 1));
+  const int tm = (Cout > 64 && !small) ? 2 : 1, tn = (Cin > 64 && !small) ? 2 : 1;
   const int mt = (Cout + 64 * tm - 1) / (64 * tm), nt = (Cin + 64 * tn - 1) / (64 * tn);
   const long tiles = (long)mt * nt * R * R;
   const long steps = (M + BK - 1) / BK;
   const int skip = (ksplit >> 16) & 1;   // bit 16: leave the result out (measurement aid)
   long ks = ksplit & 0xFFFF;
-  if (ks == 0) {
+  if (ks == 0 && small) {
+    ks = (2304 + tiles - 1) / tiles;
+    long cap = steps / 32;
+    if (cap < 1) cap = 1;
+    if (ks > cap) ks = cap;
+  } else if (ks == 0) {
     // measured on MI355X (scripts/conv_wgrad_timing.py, profiles/r04_conv_wgrad.md): ~2300 workgroups (the chip holds
     // 1024; the staggered later rounds run denser than one lock-step round), at least 16 K steps each -- small maps
     // trade that for parallelism down to 4 steps -- and never more than 64 chunks (each adds a tile of atomics).
@@ -371,5 +383,5 @@ JDET_API int jdet_conv_wgrad(const float* x_nhwc, const float* gy_nhwc, int N, i
   if (N == 0) return JDET_OK;
   if (!x_nhwc || !gy_nhwc || !gw_krsc) return JDET_E_BADARG;
   if ((((uintptr_t)x_nhwc) | ((uintptr_t)gy_nhwc)) & 15) return JDET_E_BADARG;
-  return run_wgrad(x_nhwc, gy_nhwc, nullptr, N, H, W, Cin, Cout, R, stride, gw_krsc, ksplit, (hipStream_t)stream);
+  return run_wgrad(x_nhwc, gy_nhwc, nullptr, N, H, W, Cin, Cout, R, stride, gw_krsc, ksplit, (hipStream_t)stream, true);
 }

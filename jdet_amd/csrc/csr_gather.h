@@ -293,7 +293,7 @@ static __global__ __launch_bounds__(256) void csr_fill_patch_kernel(const TapRec
 }
 
 // One wave per patch; lane owns 4 consecutive channels of a 256-channel chunk; 4 accumulators (the patch's pixels).
-// Workgroup = 2x2 patches; stripes of 8 patch rows go round-robin to the XCDs (see csr_gather_kernel).
+// Workgroup = 2x2 patches; every XCD owns one 2-D block of the workgroup grid (below).
 // img_h / img_w: pixel size of one image; keys = images x ceil(img_h/2) x ceil(img_w/2) patches.
 // A patch's entries are fetched 64 at a time, one per lane (one coalesced 2 KiB read), and handed round by readlane:
 // no scalar-load latency inside the loop, UNROLL row loads issued back to back (the row loads are L2 latency bound:
@@ -310,10 +310,19 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
   const int php = (img_h + 1) >> 1, pwp = (img_w + 1) >> 1;
   const int bw = (pwp + 1) >> 1;                               // workgroups per row of patches
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int stripe = xcd + 8 * (j / (4 * bw));                 // 4 workgroup rows = 8 patch rows per stripe
-  const int local = j % (4 * bw);
-  const int prow = (stripe * 4 + local / bw) * 2 + (wave >> 1);   // over all images stacked
-  const int pcol = (local % bw) * 2 + (wave & 1);
+  // XCD x owns ONE 2-D block of the workgroup grid (4 x 2 blocks; 8 x 1 for a single column) and walks it in compact
+  // 8 x 8 sub-tiles (32 x 32 pixels): the gradient rows its ~256 workgroups in flight touch belong to the RoIs over a few
+  // such squares instead of over a 16-pixel band across the whole map (rounds 2-4: stripes of 8 patch rows round-robin)
+  const int gr = (n_img * php + 1) >> 1;
+  const int nbc = bw >= 2 ? 2 : 1, nbr = 8 / nbc;
+  const int BR = (gr + nbr - 1) / nbr, BC = (bw + nbc - 1) / nbc;
+  const int tiles_c = (BC + 7) >> 3;
+  const int t = j >> 6, within = j & 63;
+  const int lr = (t / tiles_c) * 8 + (within >> 3), lc = (t % tiles_c) * 8 + (within & 7);
+  if (lr >= BR || lc >= BC) return;
+  const int wg_row = (xcd / nbc) * BR + lr, wg_col = (xcd % nbc) * BC + lc;
+  const int prow = wg_row * 2 + (wave >> 1);                   // over all images stacked
+  const int pcol = wg_col * 2 + (wave & 1);
   if (prow >= n_img * php || pcol >= pwp) return;
   const int p = prow * pwp + pcol;
   const int img = prow / php, py = prow - img * php;
@@ -372,8 +381,12 @@ inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, lon
   hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
                      w.offsets, w.tile_base, w.entries);
   const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
-  const int wg_rows = (n_img * php + 1) / 2, stripes = (wg_rows + 3) / 4;
-  const unsigned blocks = 8u * (unsigned)((stripes + 7) / 8) * 4u * (unsigned)bw;
+  const int wg_rows = (n_img * php + 1) / 2;
+  // XCD x owns one 2-D block of the workgroup grid, walked in 8 x 8 sub-tiles (see the kernel): 77.8 -> 76.3 us for the
+  // whole backward against the stripes of 8 patch rows of rounds 2-4 (A/B pairs on one box, profiles/r05_roi_bwd_notes.md)
+  const int nbc = bw >= 2 ? 2 : 1, nbr = 8 / nbc;
+  const int BR = (wg_rows + nbr - 1) / nbr, BC = (bw + nbc - 1) / nbc;
+  const unsigned blocks = 8u * 64u * (unsigned)(((BR + 7) / 8) * ((BC + 7) / 8));
   hipLaunchKernelGGL((csr_gather_patch_kernel<8>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
                      ntiles, w.entries, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
   return jdet_launch_status();

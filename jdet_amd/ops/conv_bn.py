@@ -37,10 +37,11 @@ from torch import nn
 from jdet_amd import _lib as L
 
 ENABLED = os.environ.get("JDET_BOTTLENECK_FUSED", "1") == "1"
-# Weight gradients of the fused block: "lib" = the library's kernels on the materialised g' tensors (default: measured
-# 10-40 us per layer faster than csrc/conv_wgrad.hip at the backbone's shapes, profiles/r05_conv_bn.md), "own" = the
-# general (R, stride) kernel of this repo accumulating into one zero-filled buffer per block.
-OWN_WGRAD = os.environ.get("JDET_BOTTLENECK_WGRAD", "lib") == "own"
+# Weight gradients of the fused block: "own" (default) = the general (R, stride) kernel of this repo (csrc/conv_wgrad.hip,
+# 64 x 64 tiles) accumulating into ONE zero-filled buffer per backbone and step -- 2-14 us per layer faster than the
+# library's at the layer1-3 shapes of a 2 x 1024^2 step and no zero-fill launch per layer (profiles/r05_conv_bn.md);
+# "lib" = the library's kernels on the same g' tensors (A/B).
+OWN_WGRAD = os.environ.get("JDET_BOTTLENECK_WGRAD", "own") == "own"
 # stride-2 3x3 / 1x1 data gradients: the library's (a strided data gradient is a different kernel, not built here)
 _PLAN = {}           # (N, H, W, Cin, Cout, R, stride) -> (workspace bytes, sums rows with it)
 
@@ -169,6 +170,36 @@ class DgradBank:
         self.buf = self.table = None
         self.views, self.ptrs, self.versions = [], [], []
         self.tiles = 0
+        self.gw_flat, self.gw_claimed = None, set()
+
+    def new_grad_buffer(self):
+        """one zero fill for the weight gradients of every convolution of the bank (the kernels accumulate: the chunks
+        of the position axis meet by atomics); handed out once per convolution by `claim_grad`"""
+        w0 = self.convs[0].weight
+        self.gw_flat = torch.zeros((sum(c.weight.numel() for c in self.convs),), dtype=torch.float32, device=w0.device)
+        self.gw_claimed = set()
+
+    def claim_grad(self, convs):
+        """(Cout, R, R, Cin) views of the step's gradient buffer for these convolutions -- each view is given out ONCE
+        per buffer (a second forward before the next `new_grad_buffer`, or a use outside a prepared backbone, gets its
+        own zero-filled tensors: two autograd nodes must never accumulate into one buffer)"""
+        if self.gw_flat is None or any(id(c) in self.gw_claimed for c in convs):
+            flat = torch.zeros((sum(c.weight.numel() for c in convs),), dtype=torch.float32,
+                               device=convs[0].weight.device)
+            out, off = [], 0
+            for c in convs:
+                Co, Ci, R, _ = c.weight.shape
+                out.append(flat[off:off + c.weight.numel()].view(Co, R, R, Ci))
+                off += c.weight.numel()
+            return out
+        out = []
+        for c in convs:
+            i = self.index[id(c)]
+            off = self._offs[i]
+            Co, Ci, R, _ = c.weight.shape
+            out.append(self.gw_flat[off:off + c.weight.numel()].view(Co, R, R, Ci))
+            self.gw_claimed.add(id(c))
+        return out
 
     def _build(self):
         dev = self.convs[0].weight.device
@@ -189,6 +220,10 @@ class DgradBank:
         self.tiles = tiles
         self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
         self.versions = [None] * len(self.convs)
+        self._offs, off = [], 0
+        for n in sizes:
+            self._offs.append(off)
+            off += n
 
     def refresh(self):
         if self.buf is None or any(c.weight.data_ptr() != p for c, p in zip(self.convs, self.ptrs)):
@@ -227,6 +262,8 @@ def prepare(blocks):
         for b in blocks:
             _BANKS[b] = bank
     bank.refresh()
+    if OWN_WGRAD:
+        bank.new_grad_buffer()
 
 
 def _bank(blk):
@@ -316,6 +353,9 @@ class _BottleneckFunction(torch.autograd.Function):
         xn = x.permute(0, 2, 3, 1)
         y1, y2, y3, idn = _forward(blk, xn)
         ctx.blk = blk
+        # the block's slices of the step's weight-gradient buffer, claimed at forward time: this node's backward is the
+        # only writer of these views
+        ctx.gws = _bank(blk).claim_grad(_block_convs(blk)) if OWN_WGRAD else None
         ctx.save_for_backward(x, y1, y2, y3, idn if blk.downsample is not None else None)
         return y3.permute(0, 3, 1, 2)
 
@@ -333,19 +373,17 @@ class _BottleneckFunction(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         convs = _block_convs(blk)
         gws = [None] * len(convs)
-        if OWN_WGRAD:
-            # one zero-filled buffer for the block's weight gradients (the kernel accumulates: K chunks meet by atomics)
-            sizes = [c.weight.numel() for c in convs]
-            gwbuf = torch.zeros((sum(sizes),), dtype=torch.float32, device=g.device)
-            off = 0
-            for k, (c, n) in enumerate(zip(convs, sizes)):
-                Co, Ci, R, _ = c.weight.shape
-                gws[k] = gwbuf[off:off + n].view(Co, R, R, Ci)
-                off += n
+        own = ctx.gws is not None
+        if own:
+            gws = list(ctx.gws)
+            ctx.gws = None          # a second backward through this node (retain_graph) must not add onto the first's
+        elif OWN_WGRAD:
+            own = True
+            gws = DgradBank(convs).claim_grad(convs)
 
         def wgrad(k, xin, gy, R, stride):
             c = convs[k]
-            if OWN_WGRAD:
+            if own:
                 conv_wgrad_nhwc(xin, gy, R, stride, gws[k])
                 # the parameter's own strides: a 1x1 weight is plain (Cout, Cin, 1, 1) memory, a 3x3 one channels-last
                 gws[k] = gws[k].view(c.weight.shape) if R == 1 else gws[k].permute(0, 3, 1, 2)

@@ -127,8 +127,10 @@ def wgrad():
         wc = torch.randn(Co, R, R, Ci, device=dev).permute(0, 3, 1, 2)
         lib = timeit(lambda: torch.ops.aten.convolution_backward(gyc, xc, wc, None, [s, s], [R // 2, R // 2], [1, 1], False,
                                                                  [0, 0], 1, [False, True, False]))
-        ts = ["%s: %6.1f" % (k or "auto", timeit(lambda: CB.conv_wgrad_nhwc(x, gy, R, s, out, k), 20))
-              for k in (0, 16, 64, 128, 256)]
+        S = 1 << 17            # 64 x 64 tiles
+        ts = ["%s: %6.1f" % (n, timeit(lambda: CB.conv_wgrad_nhwc(x, gy, R, s, out, k), 20))
+              for n, k in (("auto", 0), ("s4", S | 4), ("s8", S | 8), ("s16", S | 16), ("s32", S | 32), ("s64", S | 64),
+                           ("s128", S | 128), ("s256", S | 256), ("big", 1 << 18))]
         print("%-11s lib %7.1f | own %s" % (name, lib, "  ".join(ts)), flush=True)
 
 

@@ -38,8 +38,31 @@ run_d() {   # the side-stream two-rank test with its full report + the one-GPU D
   timeout 600 python bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 8 2> $OUT/plain.err | grep -o '"ms_per_step": [0-9.]*'; grep -c "AccumulateGrad" $OUT/plain.err
 }
 
+run_e() {   # backward gather: 2-D XCD blocks vs stripes (A/B), parity under the new map; weight-gradient tile variants
+  OUT=$R/gpurun_out/r5_e; mkdir -p $OUT
+  for m in 0 1 0 1; do
+    JDET_GATHER_MAP=$m timeout 300 python bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 200 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | sed "s/^/map $m /"
+  done | tee $OUT/bwd_ab.txt
+  JDET_GATHER_MAP=1 timeout 900 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_reference_kernels.py -q -k "back or bwd or grad" 2>&1 | tail -5 | tee $OUT/pytest_bwd.txt
+  cd /tmp
+  for m in 0 1; do
+    JDET_GATHER_MAP=$m rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace$m -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 100 > /dev/null 2>&1
+    k=$(find $OUT/trace$m -name '*kernel_stats.csv' | head -1); grep "csr_\|bwd_patch" $k | cut -d, -f1-4 | cut -c1-160 | sed "s/^/map $m /"
+    rm -rf $OUT/trace$m
+  done | tee $OUT/bwd_kernels.txt
+  cd $R
+  timeout 600 python scripts/conv_bn_timing.py wgrad 2>&1 | grep -v Warning | tee $OUT/wgrad.txt
+}
+
+run_f() {   # own weight gradients (64 x 64 tiles) by default: parity, variants, block times, step A/B
+  OUT=$R/gpurun_out/r5_f; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_conv_bn.py tests/test_gpu_conv_wgrad.py tests/test_gpu_roi_align.py -q 2>&1 | tail -8 | tee $OUT/pytest.txt
+  timeout 600 python scripts/conv_bn_timing.py wgrad blocks 2>&1 | grep -v Warning | tee $OUT/timing.txt
+  bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_WGRAD=own" "JDET_BOTTLENECK_WGRAD=lib" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d} [args]"; exit 2;;
+  a|b|c|d|e|f) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f} [args]"; exit 2;;
 esac
