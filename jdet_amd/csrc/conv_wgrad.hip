@@ -329,10 +329,12 @@ int run_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, in
   const int skip = (ksplit >> 16) & 1;   // bit 16: leave the result out (measurement aid)
   long ks = ksplit & 0xFFFF;
   if (ks == 0 && small) {
-    ks = (2304 + tiles - 1) / tiles;
-    long cap = steps / 32;
-    if (cap < 1) cap = 1;
-    if (ks > cap) ks = cap;
+    // 32 K steps per chunk, in whole rounds over the 8 XCDs (chunk c runs on XCD c % 8: fewer than 8 chunks leave XCDs
+    // idle -- 4 chunks of 32 steps ran 82 us where 8 chunks of 16 ran 48, 512 -> 2048 1x1 at 2 x 32^2) -- best or within
+    // 2 % of the best forced split at all 17 layer shapes; halved while that makes more than ~9000 workgroups
+    ks = ((steps / 32 + 7) / 8) * 8;
+    if (ks < 8) ks = 8;
+    while (ks > 8 && tiles * ks > 9216) ks -= 8;
   } else if (ks == 0) {
     // measured on MI355X (scripts/conv_wgrad_timing.py, profiles/r04_conv_wgrad.md): ~2300 workgroups (the chip holds
     // 1024; the staggered later rounds run denser than one lock-step round), at least 16 K steps each -- small maps

@@ -61,8 +61,15 @@ run_f() {   # own weight gradients (64 x 64 tiles) by default: parity, variants,
   bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_WGRAD=own" "JDET_BOTTLENECK_WGRAD=lib" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
 }
 
+run_g() {   # weight-gradient split in whole XCD rounds: parity, auto vs library, block times, step A/B
+  OUT=$R/gpurun_out/r5_g; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_conv_bn.py -q 2>&1 | tail -8 | tee $OUT/pytest.txt
+  timeout 600 python scripts/conv_bn_timing.py wgrad blocks 2>&1 | grep -v Warning | cut -c1-60 | tee $OUT/timing.txt
+  bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_WGRAD=own" "JDET_BOTTLENECK_WGRAD=lib" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f} [args]"; exit 2;;
+  a|b|c|d|e|f|g) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g} [args]"; exit 2;;
 esac
