@@ -112,28 +112,49 @@ def make_step(workload, d):
             return (step, nbytes / 1e9, "GB", nbytes,
                     "EXPERIMENTAL roi_order_kernel + roi_plan_kernel<ROTATED> + roi_pool_kernel (channels-last output)",
                     "f32")
-        if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = XCD-aware schedule + RoI-stationary kernel
+        if path in ("sliced", "line"):
+            # EXPERIMENTAL (libjdet_experimental.so, not product paths): the channel-sliced plan + pool kernels / the
+            # line-deduplicating kernel of round 4 (profiles/r04_roi_fwd_notes.md)
+            from jdet_amd import _experimental as X
+            xl = X.lib()
+            mode = 2 if path == "sliced" else 3
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
-            lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)      # (for the forward mode in force)
+            wsb = xl.jdet_roi_align_forward_cl_mode_workspace(mode, R, 7, 7)
             ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
             wp = ws.data_ptr()
-            if os.environ.get("JDET_ROI_SLICED_PLANAR", "0") == "1":
+            obuf = torch.empty((2, R), dtype=torch.int32, device=feat.device)
+            o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
+            if path == "sliced" and os.environ.get("JDET_ROI_SLICED_PLANAR", "0") == "1":
                 # EXPERIMENT (L2 channel spread): the map as [slice][pixel][32 channels]; same values, other addresses
                 planar = feat.permute(0, 2, 3, 1).reshape(256 * 256, 8, 32).permute(1, 0, 2).contiguous()
                 d["planar"] = planar
                 fp = planar.data_ptr()
 
             def step():
-                # schedule + per-RoI records are recomputed every step: RoIs arrive in arbitrary order
+                st = L.stream_ptr(feat)
+                if mode == 3:
+                    L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
+                L.check(xl.jdet_roi_align_forward_cl_mode(mode, 0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
+                                                          o0 if mode == 3 else None, op, wp, wsb, st), "fwd_cl_mode")
+            d["out"] = out
+            return (step, nbytes / 1e9, "GB", nbytes,
+                    "EXPERIMENTAL roi_sort_plan_kernel<ROTATED> + roi_pool_sliced_kernel (channels-last out)" if mode == 2
+                    else "EXPERIMENTAL roi_order_kernel + roi_align_fwd_line_kernel<ROTATED> (channels-last out)", "f32")
+        if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = XCD-aware schedule + RoI-stationary kernel
+            out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
+            op = out.data_ptr()
+            wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+            wp = ws.data_ptr()
+
+            def step():
+                # the schedule is recomputed every step: RoIs arrive in arbitrary order
                 L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op, wp, wsb,
                                                       L.stream_ptr(feat)), "fwd_cl")
             d["out"] = out
-            sliced = os.environ.get("JDET_ROI_FWD_SLICED", "0") == "1" or os.environ.get("JDET_ROI_FWD_MODE", "0") == "2"
             return (step, nbytes / 1e9, "GB", nbytes,
-                    "EXPERIMENT roi_sort_plan_kernel<ROTATED> + roi_pool_sliced_kernel (channels-last out)" if sliced
-                    else "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out>", "f32")
+                    "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out>", "f32")
         # path "roi": the RoI-stationary kernels with the reference's (R,C,7,7)-contiguous result
         cl = False
         out = torch.empty((R, 256, 7, 7), device=feat.device)
@@ -141,7 +162,6 @@ def make_step(workload, d):
         op = out.data_ptr()
         o0, o1 = obuf[0].data_ptr(), obuf[1].data_ptr()
         use_order = os.environ.get("JDET_BENCH_NO_ORDER", "0") != "1"
-        lib.jdet_set_roi_forward_mode(int(os.environ.get("JDET_ROI_FWD_MODE", "0")))
 
         def step():
             st = L.stream_ptr(feat)

@@ -34,6 +34,22 @@ int jdet_roi_align_forward_pool(int variant, const float* feat_nhwc, int N, int 
                                 const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
                                 float* out_cl, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
+/* The two measured alternatives of the RoIAlign forward that shipped inside libjdet_hip.so behind a process-wide mode in
+ * round 4 (csrc/experimental/roi_align_modes.hip compiles the product's kernels file with them), channels-last result:
+ *   mode 2: the merged-tap arithmetic through the CHANNEL-SLICED kernels (roi_align_sliced.h): one launch sorts the RoIs
+ *           by the Morton code of their centre and writes the PLAN (per (RoI, bin) the merged tap list), the second
+ *           gives every XCD one 32-channel slice of every RoI.  sample_num == 2, PH*PW >= 16, C % 32 == 0; bit-equal
+ *           to jdet_roi_align_forward_cl.  `order` unused.  workspace: schedule + plan (~136 bytes per (RoI, bin)).
+ *   mode 3: every distinct pixel row of a LINE of bins loaded once (roi_align_line.h); sample_num == 2, PH, PW <= 8
+ *           (elsewhere the product kernels run); values as the product's up to the order of a bin's sum.  `order`: a
+ *           schedule of jdet_roi_spatial_order or NULL; workspace unused.
+ * Both measured slower than the product kernel at the north-star point (profiles/r04_roi_fwd_notes.md). */
+size_t jdet_roi_align_forward_cl_mode_workspace(int mode, int R, int PH, int PW);
+int jdet_roi_align_forward_cl_mode(int mode, int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                                   const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                                   int n_orient, const int32_t* order, float* out_cl, void* workspace,
+                                   size_t workspace_bytes, jdet_stream_t stream);
+
 /* Calibration probe (scripts/gather_probe.py; csrc/experimental/gather_probe.hip): n_blocks workgroups of 4 waves, every
  * wave loads rows_per_wave pseudo-random 1 KiB rows of buf (total_rows x 256 floats), `unroll` (4 / 8 / 16) in flight,
  * drawn from a window of window_rows rows -- one shared window, or one per workgroup (local_windows != 0). */

@@ -84,34 +84,28 @@ int jdet_roi_align_forward_cl_roi(int variant, const float* feat_nhwc, int N, in
 
 /* Forward with the channels-last result out_cl (R, PH, PW, C) and the schedule computed inside; same call sites as
  * jdet_roi_align_forward (roi_align_rotated.py:L265-283, roi_align_rotated_v1.py:L308-326, riroi_align.py:L425-427,
- * roi_align.py:L217-237).  Default: jdet_roi_spatial_order (R >= 64) + the kernels of jdet_roi_align_forward_cl_roi.
- * In forward mode 2 (jdet_set_roi_forward_mode), where sample_num == 2, PH*PW >= 16, C % 32 == 0 and the map is under
- * 2 GiB, the CHANNEL-SLICED kernels run instead: one launch sorts the RoIs by the Morton code of their centre (block 0)
- * and writes the PLAN (other blocks): per (RoI, bin) the merged tap list of its 4 samples, (byte offset, weight) pairs,
- * geometry with double-precision trig once per RoI; the second gives every XCD one 32-channel slice of every RoI
- * (workgroup b -> slice b % (C/32); a group of 8 lanes = one (RoI, bin) x 32 channels), so a pixel is one 128-byte
- * line in exactly one XCD's L2.  Same values either way (merged-tap arithmetic).
- * workspace: jdet_roi_align_forward_cl_workspace(R, PH, PW) bytes FOR THE CURRENT FORWARD MODE (8 R + 256 for the
- * schedule; mode 2: schedule + plan, ~ 136 bytes per (RoI, bin)), any content, 256-byte aligned; a buffer that is too
- * small for the mode in force at the call returns JDET_E_WORKSPACE.
+ * roi_align.py:L217-237): jdet_roi_spatial_order (R >= 64) + the kernels of jdet_roi_align_forward_cl_roi.
+ * workspace: jdet_roi_align_forward_cl_workspace(R, PH, PW) bytes (8 R + 256 for the schedule), any content, 256-byte
+ * aligned; too small a buffer returns JDET_E_WORKSPACE.
  * RoIs with a negative batch index are skipped as in jdet_roi_align_forward. */
 size_t jdet_roi_align_forward_cl_workspace(int R, int PH, int PW);
 int jdet_roi_align_forward_cl(int variant, const float* feat_nhwc, int N, int C, int H, int W, const float* rois,
                               int R, int PH, int PW, float spatial_scale, int sample_num, int n_orient,
                               float* out_cl, void* workspace, size_t workspace_bytes, jdet_stream_t stream);
 
-/* Forward arithmetic mode of the vector RoIAlign kernels (process-wide; returns the previous mode).
- *   0 (default): duplicate taps inside a bin are merged before loading (fewer vector-memory requests);
- *                equals the reference up to fp32 re-association of the bilinear weights.
- *   1          : the reference's operation order (roi_align_rotated.py:L70-118) -- bit-identical to the
- *                CPU oracle; used by the parity tests.
- *   2          : mode 0's arithmetic through the channel-sliced kernels of jdet_roi_align_forward_cl where they apply
- *                (bit-equal to mode 0; measured slower at the north-star point, profiles/r04_roi_fwd_notes.md).
- *   3          : channels-last entries with sample_num == 2 and PH, PW <= 8: every distinct pixel row of a LINE of bins
- *                (a bin row or a bin column, whichever packs tighter) is loaded once and multiplied into the line's
- *                accumulators (csrc/roi_align_line.h); mode 0's values up to the order of a bin's sum (<= 2e-6 on
- *                N(0,1) maps); 45 % fewer rows through the L1, measured slower (same notes).  Elsewhere: mode 0. */
-int jdet_set_roi_forward_mode(int mode);
+/* The reference's OPERATION ORDER (roi_align_rotated.py:L70-118: w1*lt + w2*rt + w3*lb + w4*rb per sample, samples summed
+ * iy-major, then / count) behind its own entry points -- same arguments as jdet_roi_align_forward /
+ * jdet_roi_align_forward_cl, results bit-identical to the CPU oracle: the parity twin the tests and smoke() call.  The
+ * product entry points above merge duplicate taps inside a bin before loading (fewer vector-memory requests; equal to
+ * the reference up to fp32 re-association of the bilinear weights, <= 2e-6 on N(0,1) maps).  The library holds no
+ * process-wide arithmetic mode. */
+int jdet_roi_align_forward_reference(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                                     const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                                     int n_orient, const int32_t* order, float* out, jdet_stream_t stream);
+int jdet_roi_align_forward_cl_reference(int variant, const float* feat_nhwc, int N, int C, int H, int W,
+                                        const float* rois, int R, int PH, int PW, float spatial_scale, int sample_num,
+                                        int n_orient, float* out_cl, void* workspace, size_t workspace_bytes,
+                                        jdet_stream_t stream);
 
 /* XCD-aware spatial schedule for the RoIAlign kernels (no reference counterpart: the reference
  * processes output elements in index order).  Writes a permutation `order` of [0,R): workgroup b

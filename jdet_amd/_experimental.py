@@ -13,6 +13,8 @@ SIGNATURES = {
     "jdet_roi_align_forward_pool_supported": (_i, [_i] * 7),
     "jdet_roi_align_forward_pool_workspace": (_sz, [_i]),
     "jdet_roi_align_forward_pool": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _p, _sz, _p]),
+    "jdet_roi_align_forward_cl_mode_workspace": (_sz, [_i] * 4),
+    "jdet_roi_align_forward_cl_mode": (_i, [_i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p, _sz, _p]),
     "jdet_debug_gather_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_gather_width_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_gather_accumulate_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),

@@ -42,6 +42,8 @@ SIGNATURES = {
     "jdet_roi_align_forward_cl_roi": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
     "jdet_roi_align_forward_cl_workspace": (_sz, [_i, _i, _i]),
     "jdet_roi_align_forward_cl": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
+    "jdet_roi_align_forward_reference": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p]),
+    "jdet_roi_align_forward_cl_reference": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_cl": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _i, _p]),
     "jdet_roi_align_backward_clean_bytes": (_sz, [_i] * 9),
     "jdet_roi_align_backward_workspace": (_sz, [_i] * 9),
@@ -66,7 +68,6 @@ SIGNATURES = {
     "jdet_modulated_deform_col2im_coord": (_i, [_p, _p, _p, _p] + [_i] * 13 + [_p, _p, _p]),
     "jdet_deform_psroi_pool_forward": (_i, [_p, _p, _p] + [_i] * 6 + [_f] + [_i] * 5 + [_f, _i, _p, _p, _p]),
     "jdet_deform_psroi_pool_backward": (_i, [_p, _p, _p, _p, _p] + [_i] * 6 + [_f] + [_i] * 5 + [_f, _i, _p, _p, _p]),
-    "jdet_set_roi_forward_mode": (_i, [_i]),
     "jdet_deform_im2col_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p]),
     "jdet_deform_col2im_nhwc_workspace": (_sz, [_i] * 12),
     "jdet_deform_col2im_nhwc": (_i, [_p, _p] + [_i] * 12 + [_p, _p, _sz, _p]),

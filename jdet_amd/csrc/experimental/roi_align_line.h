@@ -20,8 +20,8 @@
 // Measured (profiles/r04_roi_fwd_notes.md, step 2): rows through the L1 -45 %, L2 requests -37 %, but 71 us against 58 us
 // for the merged-tap kernel: the set-up (table init + hash inserts behind the double-precision trig: 11.7 us per
 // workgroup, every wave waiting) and 14 packed FMAs + 3 LDS reads per row cost more than the saved rows.  Forward
-// mode 3 (jdet_set_roi_forward_mode) selects it; not the default.
-// (Included by roi_align.hip inside its unnamed namespace, after the merged-tap kernel.)
+// jdet_roi_align_forward_cl_mode(3, ...) of libjdet_experimental.so runs it; not a product path.
+// (Included by roi_align_impl.inc (JDET_ROI_EXPERIMENTAL_MODES) inside its unnamed namespace, after the merged-tap kernel.)
 #pragma once
 
 constexpr int kLineSlots = 128;          // >= 8 bins x 16 taps; a power of two (hash: 7 bits)

@@ -23,7 +23,7 @@
 //                          per tap per group), every group walks ITS item's list, BATCH loads in flight; one 128-byte
 //                          store per group into the channels-last row.
 // The plan costs 8 B per merged tap (7 MB at the north-star point), read once per XCD.
-// (Included by roi_align.hip inside its unnamed namespace, after ri_mix<>.)
+// (Included by roi_align_impl.inc (JDET_ROI_EXPERIMENTAL_MODES) inside its unnamed namespace, after ri_mix<>.)
 #pragma once
 #include "roi_geom.h"
 

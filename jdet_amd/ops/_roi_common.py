@@ -36,12 +36,31 @@ SPATIAL_ORDER_MIN_ROIS = 64
 #   "roi_cl"     RoI-stationary kernels (csrc/roi_align.hip), channels-last result stored straight from registers
 #                [default]
 #   "roi"        the same kernels with the reference's (R,C,PH,PW)-contiguous result (transposed through LDS)
-# The arithmetic of the kernels is jdet_set_roi_forward_mode (0 merged taps, 1 reference order).  Shapes the
-# channels-last store does not take (C % 4 != 0, RiRoIAlign with other than 4 / 8 orientations) fall back to "roi".
+# The arithmetic of the kernels is chosen by the ENTRY POINT (`set_arithmetic`: "merged" = the product entry points,
+# "reference" = jdet_roi_align_forward_reference / _cl_reference, the reference's operation order: the parity twin of
+# the tests and of smoke()).  Shapes the channels-last store does not take (C % 4 != 0, RiRoIAlign with other than
+# 4 / 8 orientations) fall back to "roi".
 # Either way the result is the same logical (R, C, PH, PW) tensor; only its strides differ.
 # (Two measured alternatives are not product paths: the tile-stationary kernels of round 2 -- removed, DESIGN.md 3.1 --
 # and the register-cached plan + pool kernels, csrc/experimental/.)
 _FORWARD_PATH = ["roi_cl"]
+
+
+_ARITHMETIC = ["merged"]
+
+
+def set_arithmetic(name):
+    """ "merged" (default, the product kernels) | "reference" (the reference's operation order: bit-identical to the CPU
+    oracle; parity tests / smoke); returns the previous choice.  The C library has no mode of its own."""
+    assert name in ("merged", "reference")
+    prev = _ARITHMETIC[0]
+    _ARITHMETIC[0] = name
+    return prev
+
+
+def _fwd_entry():
+    lib = L.lib()
+    return lib.jdet_roi_align_forward_reference if _ARITHMETIC[0] == "reference" else lib.jdet_roi_align_forward
 
 
 def set_forward_path(name):
@@ -124,18 +143,17 @@ def spatial_order(rois_c, spatial_scale, N, H, W):
 
 
 def forward_cl(variant, feat, rois_c, out, PH, PW, spatial_scale, sample_num, n_orient):
-    """Product forward into a channels-last `out` (jdet_roi_align_forward_cl): the channel-sliced kernels where they
-    apply, otherwise the RoI-stationary ones under the XCD-aware order.  RoIs with a negative batch index are skipped
-    (their rows of `out` stay as they are)."""
+    """Product forward into a channels-last `out` (jdet_roi_align_forward_cl): the RoI-stationary kernels under the
+    XCD-aware order.  RoIs with a negative batch index are skipped (their rows of `out` stay as they are)."""
     N, C, H, W = feat.shape
     R = rois_c.shape[0]
     if R == 0:
         return
     wsb = L.lib().jdet_roi_align_forward_cl_workspace(R, PH, PW)
     ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
-    L.check(L.lib().jdet_roi_align_forward_cl(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                              spatial_scale, sample_num, n_orient, L.ptr(out), L.ptr(ws), wsb,
-                                              L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
+    fn = L.lib().jdet_roi_align_forward_cl_reference if _ARITHMETIC[0] == "reference" else L.lib().jdet_roi_align_forward_cl
+    L.check(fn(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW, spatial_scale, sample_num, n_orient,
+               L.ptr(out), L.ptr(ws), wsb, L.stream_ptr(feat)), "jdet_roi_align_forward_cl")
 
 
 class RoIAlignFunction(torch.autograd.Function):
@@ -161,9 +179,8 @@ class RoIAlignFunction(torch.autograd.Function):
         else:
             out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=feat.device)
             order = spatial_order(rois_c, float(spatial_scale), N, H, W) if R >= SPATIAL_ORDER_MIN_ROIS else None
-            L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW,
-                                                   float(spatial_scale), int(sample_num), int(n_orient),
-                                                   L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
+            L.check(_fwd_entry()(variant, L.ptr(feat), N, C, H, W, L.ptr(rois_c), R, PH, PW, float(spatial_scale),
+                                 int(sample_num), int(n_orient), L.ptr(order), L.ptr(out), L.stream_ptr(feat)),
                     "jdet_roi_align_forward")
         ctx.save_for_backward(rois_c, order)
         ctx.cfg = (variant, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
@@ -209,9 +226,9 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
             if R and roi_cl:
                 forward_cl(variant, fm, r_i, out, PH, PW, float(scales[i]), int(sample_num), int(n_orient))
             elif R:
-                L.check(L.lib().jdet_roi_align_forward(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW,
-                                                       float(scales[i]), int(sample_num), int(n_orient), None,
-                                                       L.ptr(out), L.stream_ptr(fm)), "jdet_roi_align_forward")
+                L.check(_fwd_entry()(variant, L.ptr(fm), N, C, H, W, L.ptr(r_i), R, PH, PW, float(scales[i]),
+                                     int(sample_num), int(n_orient), None, L.ptr(out), L.stream_ptr(fm)),
+                        "jdet_roi_align_forward")
             masked.append(r_i)
             shapes.append((N, C, H, W))
         ctx.save_for_backward(*masked)

@@ -170,7 +170,9 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_align_conv_offset(N, 0, 8, 8, 8.0, 3, N, N) == 0
     assert lib.jdet_deform_im2col_nhwc(N, N, 1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1, N, N) == -2        # C % 4
     assert lib.jdet_deform_col2im_nhwc_workspace(1, 6, 8, 8, 3, 3, 1, 1, 1, 1, 1, 1) == 0
-    assert lib.jdet_set_roi_forward_mode(7) in (0, 1)                                               # ignored value
+    assert not hasattr(ctypes.CDLL(built_lib.LIB_PATH), "jdet_set_roi_forward_mode")   # no process-wide mode in the ABI
+    assert lib.jdet_roi_align_forward_reference(0, N, 1, 8, 8, 8, N, 0, 7, 7, 1.0, 2, 1, N, N, N) == 0    # R = 0
+    assert lib.jdet_roi_align_forward_cl_reference(0, N, 1, 6, 8, 8, N, 0, 7, 7, 1.0, 2, 1, N, N, 0, N) == -2   # C % 4
     # round-2 entry points
     assert lib.jdet_roi_align_forward_cl_roi(2, N, 1, 16, 8, 8, N, 0, 7, 7, 1.0, 2, 3, N, N, N) == -1  # RiRoI: C % nO
     assert lib.jdet_roi_align_forward_cl_roi(2, N, 1, 12, 8, 8, N, 0, 7, 7, 1.0, 2, 2, N, N, N) == -2  # RiRoI nO = 2

@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture
 def reference_order():
     """bit-exact comparisons run the RoIAlign kernels in the reference's operation order"""
-    from jdet_amd import _lib as L
-    prev = L.lib().jdet_set_roi_forward_mode(1)
+    from jdet_amd.ops import _roi_common as RC
+    prev = RC.set_arithmetic("reference")
     yield
-    L.lib().jdet_set_roi_forward_mode(prev)
+    RC.set_arithmetic(prev)
 
 
 def test_oriented_extractor_vs_per_level_oracle(dev, reference_order):

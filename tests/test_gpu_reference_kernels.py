@@ -41,14 +41,15 @@ def _case(rng, kind, C=16, nO=8):
 def _product(variant, feat, rois, hw, scale, s, grad, dev, mode, nO=8):
     from jdet_amd import _lib as L
     from tests.test_gpu_roi_align import _layer
-    prev = L.lib().jdet_set_roi_forward_mode(mode)
+    from jdet_amd.ops import _roi_common as RC
+    prev = RC.set_arithmetic("reference" if mode == 1 else "merged")
     try:
         x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         y = _layer(variant, hw, scale, s, nO)(x, torch.from_numpy(rois).to(dev))
         y.backward(torch.from_numpy(grad).to(dev))
         return y.detach().cpu().numpy(), x.grad.detach().cpu().contiguous().numpy()
     finally:
-        L.lib().jdet_set_roi_forward_mode(prev)
+        RC.set_arithmetic(prev)
 
 
 @pytest.mark.parametrize("kind,variant", KINDS)
@@ -99,8 +100,9 @@ def test_roi_align_full_size_against_the_reference_kernel(dev, R):
     ref_g = RH.roi_align_backward("rot", grad, rois, tuple(feat.shape), 0.25, 2)
     layer = ROIAlignRotated(7, 0.25, 2)
     x = feat.contiguous(memory_format=torch.channels_last)
-    for mode in (1, 0, 2):
-        prev = L.lib().jdet_set_roi_forward_mode(mode)
+    from jdet_amd.ops import _roi_common as RC
+    for mode in (1, 0):
+        prev = RC.set_arithmetic("reference" if mode == 1 else "merged")
         try:
             xg = x.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
             y = layer(xg, rois)
@@ -112,7 +114,7 @@ def test_roi_align_full_size_against_the_reference_kernel(dev, R):
                 scale = max(1.0, float(ref_g.abs().max()))
                 assert float((xg.grad - ref_g).abs().max()) <= 1e-4 * scale
         finally:
-            L.lib().jdet_set_roi_forward_mode(prev)
+            RC.set_arithmetic(prev)
 
 
 @pytest.mark.parametrize("B,C,H,W,k,pad,stride,dil,dg", [(2, 4, 9, 11, 3, 1, 1, 1, 1), (1, 6, 10, 8, 3, 1, 2, 1, 2),

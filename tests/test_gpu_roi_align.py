@@ -11,7 +11,7 @@ from tests import inputs as I
 
 pytestmark = pytest.mark.gpu
 
-FWD_ATOL = 0.0           # jdet_set_roi_forward_mode(1)
+FWD_ATOL = 0.0           # the *_reference entry points (set_arithmetic("reference"))
 FWD_MERGED_ATOL = 2e-6   # default mode
 BWD_ATOL = 2e-5
 
@@ -28,9 +28,9 @@ def fwd_mode(request):
     from jdet_amd.ops import _roi_common as RC
     path, mode, atol = request.param
     prev_path = RC.set_forward_path(path)
-    prev = L.lib().jdet_set_roi_forward_mode(mode)
+    prev = RC.set_arithmetic("reference" if mode == 1 else "merged")
     yield atol
-    L.lib().jdet_set_roi_forward_mode(prev)
+    RC.set_arithmetic(prev)
     RC.set_forward_path(prev_path)
 
 
@@ -153,11 +153,12 @@ def test_riroi_vector_path_vs_oracle(dev, nO, C, hw, s):
     from jdet_amd import _lib as L
     ref = O.roi_align_forward(O.V_RI, feat, rois, hw, scale, s, nO)
     gref = O.roi_align_backward(O.V_RI, grad, rois, feat.shape, scale, s, nO)
-    prev = L.lib().jdet_set_roi_forward_mode(1)          # reference accumulation order: bit-identical
+    from jdet_amd.ops import _roi_common as RC
+    prev = RC.set_arithmetic("reference")                # reference accumulation order: bit-identical
     try:
         y, gi = _run(O.V_RI, feat, rois, hw, scale, s, grad, dev, True, nO)
     finally:
-        L.lib().jdet_set_roi_forward_mode(prev)
+        RC.set_arithmetic(prev)
     assert np.array_equal(y, ref)
     np.testing.assert_allclose(gi, gref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(gref).max()))
     # default mode: merged taps, one orientation mix per bin, channels-last result and gradient
@@ -284,15 +285,13 @@ def _fwd_cl_both(variant, x, rois, hw, scale, nO, rois_legacy=None):
     for sliced in (True, False):
         out = torch.full((R, C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
         if sliced:
-            prev = lib.jdet_set_roi_forward_mode(2)        # the channel-sliced kernels (not the default path)
-            wsb = lib.jdet_roi_align_forward_cl_workspace(R, hw[0], hw[1])     # (the query follows the mode)
+            from jdet_amd import _experimental as X        # the channel-sliced kernels: libjdet_experimental.so
+            xl = X.lib()
+            wsb = xl.jdet_roi_align_forward_cl_mode_workspace(2, R, hw[0], hw[1])
             ws = torch.empty((wsb,), dtype=torch.uint8, device=x.device)
-            try:
-                L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0],
-                                                      hw[1], scale, 2, nO, out.data_ptr(), ws.data_ptr(), wsb,
-                                                      L.stream_ptr(x)), "fwd_cl")
-            finally:
-                lib.jdet_set_roi_forward_mode(prev)
+            L.check(xl.jdet_roi_align_forward_cl_mode(2, variant, x.data_ptr(), N, C, H, W, rois.data_ptr(), R, hw[0],
+                                                      hw[1], scale, 2, nO, None, out.data_ptr(), ws.data_ptr(), wsb,
+                                                      L.stream_ptr(x)), "fwd_cl_mode 2")
         else:
             L.check(lib.jdet_roi_align_forward_cl_roi(variant, x.data_ptr(), N, C, H, W, rois_legacy.data_ptr(), R, hw[0],
                                                       hw[1], scale, 2, nO, None, out.data_ptr(), L.stream_ptr(x)),
@@ -342,11 +341,8 @@ def test_sliced_forward_equals_roi_stationary_kernels(dev, variant, nO, C, hw):
 
 
 def fwd_mode_is_reference():
-    from jdet_amd import _lib as L
-    lib = L.lib()
-    m = lib.jdet_set_roi_forward_mode(0)
-    lib.jdet_set_roi_forward_mode(m)
-    return m == 1
+    from jdet_amd.ops import _roi_common as RC
+    return RC._ARITHMETIC[0] == "reference"
 
 
 def test_sliced_forward_north_star_equals_roi_stationary(dev):
@@ -367,7 +363,7 @@ def test_sliced_forward_north_star_equals_roi_stationary(dev):
 @pytest.mark.parametrize("variant,C", [(O.V_ROT, 256), (O.V_ROT, 96), (O.V_ROT_V1, 64), (O.V_HBB0, 32), (O.V_HBB1, 128)])
 @pytest.mark.parametrize("hw", [(7, 7), (4, 4), (5, 8)])
 def test_line_forward_matches_the_oracle(dev, variant, C, hw):
-    """Forward mode 3 (csrc/roi_align_line.h): every distinct pixel row of a LINE of bins loaded once, per-bin weights
+    """The line kernel (csrc/experimental/roi_align_line.h, libjdet_experimental.so): every distinct pixel row of a LINE of bins loaded once, per-bin weights
     from an LDS table.  Same geometry and the same within-bin merge as mode 0; a bin's sum runs in another order, so
     the bar is the merged-tap tolerance against the oracle (and the same distance from mode 0).  Several images, masked
     RoIs (rows untouched), RoIs over the border, thin and fat RoIs (lines along rows / along columns)."""
@@ -387,15 +383,17 @@ def test_line_forward_matches_the_oracle(dev, variant, C, hw):
     x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
     r = torch.from_numpy(rois).to(dev)
     outs = []
+    from jdet_amd import _experimental as X
     for mode in (3, 0):
         out = torch.full((rois.shape[0], C) + hw, float("nan"), device=x.device).contiguous(memory_format=torch.channels_last)
-        prev = lib.jdet_set_roi_forward_mode(mode)
-        try:
+        if mode == 3:       # the line kernel: libjdet_experimental.so
+            L.check(X.lib().jdet_roi_align_forward_cl_mode(3, variant, x.data_ptr(), N, C, H, W, r.data_ptr(),
+                                                           rois.shape[0], hw[0], hw[1], scale, 2, 1, None, out.data_ptr(),
+                                                           None, 0, L.stream_ptr(x)), "fwd_cl_mode 3")
+        else:
             L.check(lib.jdet_roi_align_forward_cl_roi(variant, x.data_ptr(), N, C, H, W, r.data_ptr(), rois.shape[0],
                                                       hw[0], hw[1], scale, 2, 1, None, out.data_ptr(),
                                                       L.stream_ptr(x)), "fwd_cl_roi")
-        finally:
-            lib.jdet_set_roi_forward_mode(prev)
         outs.append(out.cpu().numpy())
     a, b = outs
     masked = rois[:, 0] < 0
