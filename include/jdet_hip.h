@@ -416,6 +416,14 @@ int jdet_bias_act_backward(const float* grad_y_nhwc, const float* y_nhwc, long P
                            float* grad_pre_nhwc, float* grad_bias, void* workspace, size_t workspace_bytes,
                            jdet_stream_t stream);
 
+/* Per-channel sum over the P rows of a channels-last (P, C) tensor for ANY 1 <= C <= 256: the bias gradient of a
+ * convolution WITHOUT an activation whose channel count jdet_bias_act_backward does not take (the 15- and 5-channel
+ * output convs of the heads, ConvModule, models/utils/modules.py:L91-175).  Deterministic two-stage sum; workspace:
+ * jdet_channel_sum_workspace(P, C) bytes (0 = unsupported). */
+size_t jdet_channel_sum_workspace(long P, int C);
+int jdet_channel_sum(const float* x_nhwc, long P, int C, float* sums, void* workspace, size_t workspace_bytes,
+                     jdet_stream_t stream);
+
 /* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
  * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
  * out (nOut*nRot, nIn*nOri, kH, kW). */

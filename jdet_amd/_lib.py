@@ -97,6 +97,8 @@ SIGNATURES = {
     "jdet_frozen_bn_act_backward_workspace": (_sz, [_l, _i]),
     "jdet_frozen_bn_act_backward": (_i, [_p, _p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "jdet_bias_act_backward": (_i, [_p, _p, _l, _i, _i, _p, _p, _p, _sz, _p]),
+    "jdet_channel_sum_workspace": (_sz, [_l, _i]),
+    "jdet_channel_sum": (_i, [_p, _l, _i, _p, _p, _sz, _p]),
     "jdet_arf_forward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_backward": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),
     "jdet_arf_forward_cl": (_i, [_p, _p] + [_i] * 6 + [_p, _p]),

@@ -318,6 +318,33 @@ __global__ __launch_bounds__(1024) void bias_act_bwd_kernel(const v4f* __restric
   }
 }
 
+// Per-channel sum of channels-last rows (P, C) for ANY channel count up to 256 (the classification / regression
+// output convs of the heads: 15 and 5 channels): the kernels above want C % 4 == 0 with C / 4 dividing 256, and the
+// framework's per-channel reduce those layers fell back to runs 25-60 us per call (12 calls per S2ANet step).  A
+// workgroup has C * floor(256 / C) threads and the grid-stride is a multiple of C, so a thread keeps ONE channel and
+// the loads of a wave are consecutive floats; fixed-order LDS combine; partial rows in sums_finish_kernel's layout.
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ x, size_t n, int C,
+                                                          float* __restrict__ partial) {
+  __shared__ float s_red[256];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {       // 4 independent loads in flight per lane
+    a0 += x[i];
+    a1 += x[i + stride];
+    a2 += x[i + 2 * stride];
+    a3 += x[i + 3 * stride];
+  }
+  for (; i < n; i += stride) a0 += x[i];
+  s_red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if ((int)threadIdx.x < C) {       // threads t, t + C, ... hold channel t (blockDim % C == 0)
+    float acc = 0.f;
+    for (int t = threadIdx.x; t < (int)blockDim.x; t += C) acc += s_red[t];
+    partial[(size_t)blockIdx.x * 2 * C + threadIdx.x] = acc;
+  }
+}
+
 // Second stage of the per-channel sums (BN: dbeta + dgamma; conv bias: dbeta only): workgroup = 32 channels x 32 row
 // groups, every partial row of a thread in flight at once (nblocks <= 256 -> 8 rows per thread), fixed-order LDS
 // combine (deterministic).  History: the first version (256 threads, 8 row groups, 512 partial rows) took 14.5 us per
@@ -582,5 +609,37 @@ JDET_API int jdet_bn_sums_finish(const jdet_bn_sums_job_t* jobs, int njobs, jdet
   for (int j = njobs; j < 5; j++) js.first_block[j] = blocks;
   js.njobs = njobs;
   hipLaunchKernelGGL(bn_sums_finish_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, js);
+  return jdet_launch_status();
+}
+
+/* Per-channel sum over the P rows of a channels-last (P, C) tensor, any 1 <= C <= 256 -- the bias gradient of a
+ * convolution without an activation (the heads' output convs; ConvModule, models/utils/modules.py:L91-175), where
+ * jdet_bias_act_backward's channel counts do not apply.  Deterministic two-stage sum.  workspace:
+ * jdet_channel_sum_workspace(P, C) bytes. */
+JDET_API size_t jdet_channel_sum_workspace(long P, int C) {
+  if (P <= 0 || C <= 0 || C > 256) return 0;
+  const size_t n = (size_t)P * C;
+  const int block = C * (256 / C);
+  size_t grid = (n + (size_t)block * 16 - 1) / ((size_t)block * 16);
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  return sizeof(float) * grid * 2 * C;
+}
+
+JDET_API int jdet_channel_sum(const float* x_nhwc, long P, int C, float* sums, void* workspace, size_t workspace_bytes,
+                              jdet_stream_t stream) {
+  if (P < 0 || C <= 0 || !sums) return JDET_E_BADARG;
+  if (C > 256) return JDET_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 0) return jdet_zero_async(sums, sizeof(float) * (size_t)C, st);
+  if (!x_nhwc) return JDET_E_BADARG;
+  const size_t need = jdet_channel_sum_workspace(P, C);
+  if (!workspace || workspace_bytes < need) return JDET_E_WORKSPACE;
+  const int grid = (int)(need / (sizeof(float) * 2 * C)), block = C * (256 / C);
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(grid), dim3(block), 0, st, x_nhwc, (size_t)P * C, C, (float*)workspace);
+  int e = jdet_launch_status();
+  if (e) return e;
+  hipLaunchKernelGGL((sums_finish_kernel<false>), dim3((C + 31) / 32), dim3(1024), 0, st, (const float*)workspace, grid, C,
+                     (float*)nullptr, sums);
   return jdet_launch_status();
 }

@@ -104,9 +104,7 @@ def conv3x3_wgrad_nhwc(x_nhwc, gy_nhwc, offset=None, out=None, ksplit=0):
         out = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=x_nhwc.device)
     elif tuple(out.shape) != (Cout, 3, 3, Cin) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("out must be a contiguous fp32 (Cout, 3, 3, Cin) tensor")
-    L.check(L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc),
-                                       L.ptr(L.f32c(offset)) if offset is not None else None, N, H, W, Cin, Cout,
-                                       L.ptr(out), int(ksplit), L.stream_ptr(x_nhwc)), "jdet_conv3x3_wgrad")
+    L.check(_wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, L.ptr(out), ksplit), "jdet_conv3x3_wgrad")
     return out
 
 
@@ -124,6 +122,16 @@ def conv3x3_wgrad(x, gy, offset=None, ksplit=0):
 # (312 vs 314-326 us at 2 x 128^2 x 256), but inside the autotuned S2ANet step the library's pick is faster than its
 # stand-alone time: 29.28 ms with this switch on against 29.02-29.06 ms off -- so it is off by default.
 WGRAD = os.environ.get("JDET_CONV_WGRAD", "0") == "1"
+# (measurement) the plain 3x3 form through the backbone's entry point: 64 x 64 tiles, split in whole XCD rounds
+WGRAD_GENERAL = os.environ.get("JDET_CONV_WGRAD_GENERAL", "0") == "1"
+
+
+def _wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, out_ptr, ksplit):
+    if WGRAD_GENERAL and offset is None:
+        return L.lib().jdet_conv_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc), N, H, W, Cin, Cout, 3, 1, out_ptr, int(ksplit),
+                                       L.stream_ptr(x_nhwc))
+    return L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc), L.ptr(L.f32c(offset)) if offset is not None else None,
+                                      N, H, W, Cin, Cout, out_ptr, int(ksplit), L.stream_ptr(x_nhwc))
 _GW_ACC = {}           # weight.data_ptr() -> (backward pass id, device pointer of the (Cout,3,3,Cin) buffer, its shape)
 
 
@@ -139,9 +147,7 @@ def shared_wgrad(weight, x_nhwc, gy_nhwc, offset=None):
     if tid >= 0 and hit is not None and hit[0] == tid and hit[2] == (Cout, Cin, x_nhwc.device):
         N, H, W, _ = x_nhwc.shape
         x_nhwc, gy_nhwc = L.f32c(x_nhwc), L.f32c(gy_nhwc)
-        L.check(L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc),
-                                           L.ptr(L.f32c(offset)) if offset is not None else None, N, H, W, Cin, Cout,
-                                           hit[1], 0, L.stream_ptr(x_nhwc)), "jdet_conv3x3_wgrad")
+        L.check(_wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, hit[1], 0), "jdet_conv3x3_wgrad")
         return None
     buf = conv3x3_wgrad_nhwc(x_nhwc, gy_nhwc, offset)
     if tid >= 0:
@@ -181,6 +187,18 @@ def bias_act_backward(g, y, relu):
     """g, y (N, C, H, W) logical -> (grad of the pre-activation (same logical shape, channels_last), grad_bias (C,)):
     grad_pre = g * [y > 0] when relu, else g itself; grad_bias = grad_pre.sum((0, 2, 3))."""
     N, C, H, W = g.shape
+    if (BIAS_ACT_BWD and not relu and g.is_cuda and g.dtype == torch.float32 and not _bias_bwd_supported(C)
+            and C <= 256 and N * H * W > 0):
+        # channel counts off the vector kernels' grid (the heads' 15- / 5-channel output convs): the any-C column sum
+        # (csrc/frozen_bn.hip: jdet_channel_sum) instead of the framework's per-channel reduce (25-60 us per call)
+        gn = L.f32c(g.permute(0, 2, 3, 1))
+        P = N * H * W
+        nbytes = L.lib().jdet_channel_sum_workspace(P, C)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=g.device)
+        gb = torch.empty((C,), dtype=torch.float32, device=g.device)
+        L.check(L.lib().jdet_channel_sum(L.ptr(gn), P, C, L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr(gn)),
+                "jdet_channel_sum")
+        return g, gb
     if not (BIAS_ACT_BWD and g.is_cuda and g.dtype == torch.float32 and _bias_bwd_supported(C) and N * H * W > 0):
         gp = torch.ops.aten.threshold_backward(g, y, 0) if relu else g
         return gp, gp.sum((0, 2, 3))

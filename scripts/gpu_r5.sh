@@ -68,8 +68,15 @@ run_g() {   # weight-gradient split in whole XCD rounds: parity, auto vs library
   bash scripts/ab_step.sh -n 2 -s 20 "JDET_BOTTLENECK_WGRAD=own" "JDET_BOTTLENECK_WGRAD=lib" "JDET_BOTTLENECK_FUSED=0" 2>&1 | tee $OUT/ab.txt
 }
 
+run_h() {   # any-C channel sum, head weight gradients through the 64-tile kernel (A/B), two-rank graph-mode diagnosis
+  OUT=$R/gpurun_out/r5_h; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_conv_bn.py tests/test_gpu_frozen_bn.py tests/test_gpu_conv_igemm.py tests/test_gpu_conv_wgrad.py -q 2>&1 | tail -6 | tee $OUT/pytest.txt
+  bash scripts/ab_step.sh -n 2 -s 20 "JDET_CONV_WGRAD=0" "JDET_CONV_WGRAD=1 JDET_CONV_WGRAD_GENERAL=1" "JDET_CONV_WGRAD=1" 2>&1 | tee $OUT/ab.txt
+  timeout 1200 python scripts/ddp_graph_diag.py orcnn 12 ${1:-12} 2>&1 | grep "RESULT\|GARBAGE\|== run\|Error\|error" | tee $OUT/diag_own.txt
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h} [args]"; exit 2;;
 esac

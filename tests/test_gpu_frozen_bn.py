@@ -104,3 +104,32 @@ def test_resnet50_train_mode_uses_fused_bn(dev):
     for n in ("layer2.0.bn1.weight", "layer3.5.bn3.bias", "layer4.2.conv3.weight", "layer2.0.downsample.1.weight"):
         s = float(g_r[n].abs().max())
         torch.testing.assert_close(g_f[n], g_r[n], rtol=5e-3, atol=5e-3 * s)
+
+
+@pytest.mark.parametrize("C", [5, 15, 7, 64, 255, 256])
+@pytest.mark.parametrize("P", [1, 333, 2 * 128 * 128])
+def test_channel_sum_any_channel_count(dev, C, P):
+    """jdet_channel_sum: per-channel sum of channels-last rows for channel counts off the vector kernels' grid (the
+    heads' 15- / 5-channel output convs) against the float64 sum; and through the conv module's backward: the bias
+    gradient of such a conv equals autograd's."""
+    from jdet_amd import _lib as L
+    g = torch.Generator().manual_seed(C * 7 + P)
+    x = torch.randn(P, C, generator=g).to(dev)
+    nbytes = L.lib().jdet_channel_sum_workspace(P, C)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    out = torch.empty(C, device=dev)
+    L.check(L.lib().jdet_channel_sum(L.ptr(x), P, C, L.ptr(out), L.ptr(ws), nbytes, L.stream_ptr(x)), "channel_sum")
+    ref = x.double().sum(0)
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(x.abs().sum(0).max())), C
+
+
+def test_small_output_conv_bias_gradient_through_the_any_channel_sum(dev):
+    from jdet_amd.ops import conv_igemm as CI
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 15, 3, padding=1).to(dev).to(memory_format=torch.channels_last)
+    x = torch.randn(2, 64, 24, 20, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = CI.conv_module(conv, x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = conv.bias.grad.clone()
+    assert torch.allclose(got, gy.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=1e-4)
