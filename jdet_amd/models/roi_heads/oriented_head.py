@@ -27,6 +27,8 @@ from jdet_amd.ops.bbox_transforms import get_bbox_dim, obb2poly
 from jdet_amd.utils.general import const_like
 from jdet_amd.utils.registry import BOXES, HEADS, LOSSES, ROI_EXTRACTORS, build_from_cfg
 
+from jdet_amd.ops.linear import Linear
+
 from .roi_feature_linear import RoIFeatureLinear
 
 
@@ -90,13 +92,13 @@ class OrientedHead(nn.Module):
             convs.append(ConvModule(width, self.conv_out_channels, 3, padding=1, conv_cfg=None, norm_cfg=None))
             width = self.conv_out_channels
         for i in range(n_fcs):
-            fcs.append(nn.Linear(width, self.fc_out_channels) if flat else
+            fcs.append(Linear(width, self.fc_out_channels) if flat else
                        RoIFeatureLinear(width, self.roi_feat_area, self.fc_out_channels))
             width, flat = self.fc_out_channels, True
         return convs, fcs, width, flat
 
     def _output_layer(self, width, flat, out):
-        return nn.Linear(width, out) if flat else RoIFeatureLinear(width, self.roi_feat_area, out)
+        return Linear(width, out) if flat else RoIFeatureLinear(width, self.roi_feat_area, out)
 
     def init_weights(self):
         nn.init.normal_(self.fc_cls.weight, 0, 0.01)

@@ -16,6 +16,8 @@ from jdet_amd.ops.bbox_transforms import (best_match_dbbox2delta, choose_best_ob
 from jdet_amd.ops.nms_rotated import multiclass_nms_rotated
 from jdet_amd.utils.registry import HEADS, LOSSES, build_from_cfg
 
+from jdet_amd.ops.linear import Linear
+
 from .roi_feature_linear import RoIFeatureLinear
 
 
@@ -113,7 +115,7 @@ class BBoxHeadRbbox(nn.Module):
         an FC over all C*PH*PW values that reads the channels-last memory in place (RoIFeatureLinear; state dicts
         keep the reference's (c, ph, pw) column order)"""
         if self.with_avg_pool:
-            return nn.Linear(channels, out_features)
+            return Linear(channels, out_features)
         return RoIFeatureLinear(channels, self.roi_feat_area, out_features)
 
     def init_weights(self):

@@ -1,6 +1,7 @@
 """First fully connected layer on pooled RoI features, fed without a layout copy."""
-import torch.nn.functional as F
 from torch import nn
+
+from jdet_amd.ops.linear import linear
 
 
 class RoIFeatureLinear(nn.Linear):
@@ -39,4 +40,4 @@ class RoIFeatureLinear(nn.Linear):
         if x.dim() == 4:
             # (R, C, PH, PW) -> rows in (ph, pw, c) order: a view for channels-last memory, one copy otherwise
             x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
-        return F.linear(x, self.weight, self.bias)
+        return linear(x, self.weight, self.bias)

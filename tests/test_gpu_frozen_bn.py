@@ -133,3 +133,25 @@ def test_small_output_conv_bias_gradient_through_the_any_channel_sum(dev):
     y.backward(gy)
     got = conv.bias.grad.clone()
     assert torch.allclose(got, gy.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(1024, 1024, 1024), (1024, 1024, 16), (300, 96, 80), (7, 64, 5)])
+def test_linear_with_the_own_bias_sum_equals_autograd(dev, rows, cin, cout):
+    """ops/linear.Linear: same output and gradients as nn.Linear; the bias gradient comes from the two-stage column
+    sums (no framework reduce_kernel, whose multi-workgroup path clears its semaphores with a memset node)"""
+    from jdet_amd.ops.linear import Linear
+    torch.manual_seed(rows + cout)
+    a = Linear(cin, cout).to(dev)
+    b = torch.nn.Linear(cin, cout).to(dev)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(rows, cin, device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = a(xa), b(xb)
+    assert torch.allclose(ya, yb, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
+    ref = g.double().sum(0)
+    assert float((a.bias.grad.double() - ref).abs().max()) <= 1e-5 * float(g.abs().sum(0).max()) + 1e-5
