@@ -75,8 +75,79 @@ run_h() {   # any-C channel sum, head weight gradients through the 64-tile kerne
   timeout 1200 python scripts/ddp_graph_diag.py orcnn 12 ${1:-12} 2>&1 | grep "RESULT\|GARBAGE\|== run\|Error\|error" | tee $OUT/diag_own.txt
 }
 
+run_final() {
+# round 5 evidence run: smoke(), the full GPU suite, the default bench line (with `secondary`), the same command under
+# rocprofv3 (steady-state step breakdown + roofline-kernel rows), traffic counters of the roofline kernel (one --pmc set
+# per pass), kernel stats of the RoIAlign forward / backward, MFMA counters of the whole S2ANet step.
+# Output: gpurun_out/r5_final/ (what is judged is copied into profiles/r05_*).
+OUT=$R/gpurun_out/r5_final; mkdir -p $OUT
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-2600
+grep -c "AccumulateGrad" $OUT/bench_default.err
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -o t -- python $R/bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-secondary > $OUT/trace_default.log 2>&1)
+f=$(find $OUT/trace_default -name '*kernel_trace.csv' | head -1)
+python scripts/steady_state.py $f assign_anchor_kernel 4 5 120 > $OUT/steady_state_s2anet.txt 2>&1
+head -3 $OUT/steady_state_s2anet.txt | cut -c1-160
+k=$(find $OUT/trace_default -name '*kernel_stats.csv' | head -1)
+head -1 $k > $OUT/roofline_kernel_stats.csv
+grep "roi_align_fwd_merged_kernel\|roi_order_kernel\|conv_bn_kernel\|conv3x3_wgrad_kernel\|conv3x3_igemm_kernel\|bn_out_bwd_kernel\|bn_sums_finish_kernel\|dgrad_weights_kernel\|channel_sum_kernel" $k >> $OUT/roofline_kernel_stats.csv
+cut -c1-240 $OUT/roofline_kernel_stats.csv
+rm -rf $OUT/trace_default
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_READ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-30)
+  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_fwd_$n -o p -- python $R/bench.py --workload roi_align_rotated --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/pmc_fwd_$n.log 2>&1)
+done
+python - <<PY > $OUT/roi_align_fwd_counters.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_fwd_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, cs in agg.items():
+    if "roi_" in k:
+        for c, v in sorted(cs.items()):
+            print("%-70s %-32s mean %.6g over %d dispatches" % (k, c, sum(v) / len(v), len(v)))
+PY
+cut -c40-200 $OUT/roi_align_fwd_counters.txt
+rm -rf $OUT/pmc_fwd_*/
+for wl in roi_align_rotated roi_align_rotated_bwd; do
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o t -- python $R/bench.py --workload $wl --no-cpu-baseline --no-secondary > $OUT/trace_$wl.log 2>&1)
+  k=$(find $OUT/trace_$wl -name '*kernel_stats.csv' | head -1)
+  [ -n "$k" ] && head -12 $k | cut -c1-220 > $OUT/kernel_stats_$wl.csv
+  grep -o '"ms_per_step": [0-9.]*' $OUT/trace_$wl.log | head -1
+  rm -rf $OUT/trace_$wl
+  echo "== $wl"; cut -c1-150 $OUT/kernel_stats_$wl.csv | head -7
+done
+for c in "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-40)
+  (cd /tmp && timeout 900 rocprofv3 --pmc $c -f csv -d $OUT/mfma_$n -o p -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/mfma_$n.log 2>&1 || echo "pmc $c failed")
+done
+python - <<PY > $OUT/s2anet_mfma_utilisation.txt
+import csv, glob, collections
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob("$OUT/mfma_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"][:90]
+        tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        cnt[k][row["Counter_Name"]] += 1
+rows = sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:25]
+print("# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); sums over the dispatches of 6 steps (3 warm-up + 3 timed)")
+num = den = 0.0
+for k, c in rows:
+    busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+    frac = busy / (act / 8 * 1024) if act else float("nan")
+    num += busy; den += act / 8 * 1024
+    print("%-90s calls %4d  mfma_busy %6.1f %%  MOPS_F32 %.3e" % (k, cnt[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0), 100 * frac, c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)))
+print("cycle-weighted MFMA busy over these kernels: %.1f %%" % (100 * num / den if den else float("nan")))
+PY
+tail -1 $OUT/s2anet_mfma_utilisation.txt
+rm -rf $OUT/mfma_*/
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h|final) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|final} [args]"; exit 2;;
 esac
