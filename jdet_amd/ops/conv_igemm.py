@@ -294,7 +294,12 @@ class _ConvBiasAct(torch.autograd.Function):
                 need[1] = False
             lx, gw, _ = torch.ops.aten.convolution_backward(g, x, weight, None, stride, padding, dilation, False,
                                                             [0, 0], groups, need) if any(need) else (None, None, None)
-            return gx, (gw1 if gw1 is not None else gw), gb, None, None, None, None, None, None, None
+            gw = gw1 if gw1 is not None else gw
+            if gw is not None and gw.stride() != weight.stride() and gw.numel() == weight.numel():
+                # (Cout, Cin, 1, 1) is one memory order under two stride spellings: the parameter's own keeps the
+                # gradient layout contract (DDP's bucket views otherwise copy and warn)
+                gw = gw.as_strided(weight.shape, weight.stride())
+            return gx, gw, gb, None, None, None, None, None, None, None
         if need[0] and igemm and DGRAD and supported(weight.shape[0], weight.shape[1]):
             gx = conv3x3_nhwc(L.f32c(g.permute(0, 2, 3, 1)), dgrad_weight(weight)).permute(0, 3, 1, 2)
             need[0] = False

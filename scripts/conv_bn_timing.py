@@ -111,8 +111,10 @@ def tiles():
         w = torch.randn(Co, R, R, Ci, device=dev) / (R * Ci ** 0.5)
         bn = make_bn(Co)
         out = []
-        for t in (0, 64, 66, 128, 130):
-            out.append("%d: %6.1f" % (t, timeit(lambda: CB.conv_bn_nhwc(x, w, s, bn, None, True, tile=t), 20)))
+        Ho, Wo = CB.out_size(H, R, s), CB.out_size(W, R, s)
+        r = torch.randn(N, Ho, Wo, Co, device=dev) if res else None
+        for t in (0, 64, 65, 66, 67, 128, 130):       # +1: 16-deep K steps, +2: no intra-workgroup K split
+            out.append("%d: %6.1f" % (t, timeit(lambda: CB.conv_bn_nhwc(x, w, s, bn, r, True, tile=t), 20)))
         print("%-11s %s" % (name, "  ".join(out)), flush=True)
 
 

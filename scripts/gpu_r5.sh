@@ -146,8 +146,16 @@ tail -1 $OUT/s2anet_mfma_utilisation.txt
 rm -rf $OUT/mfma_*/
 }
 
+run_i() {   # closing re-validation: two-rank tests, 16-deep K steps on the short reductions, the default bench line
+  OUT=$R/gpurun_out/r5_i; mkdir -p $OUT
+  timeout 900 python -m pytest tests/test_gpu_ddp_detectors.py tests/test_gpu_frozen_bn.py -q 2>&1 | tail -4 | tee $OUT/pytest.txt
+  timeout 600 python scripts/conv_bn_timing.py tiles 2>&1 | grep -v Warning | tee $OUT/tiles.txt
+  timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-400
+  grep -c "AccumulateGrad\|Grad strides" $OUT/bench_default.err
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|final) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|final} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h|i|final) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|final} [args]"; exit 2;;
 esac
