@@ -427,7 +427,10 @@ Plan make_plan(long M, int Cin, int Cout, int taps, int tile, bool workspace) {
   // r05_conv_bn.md), the 64^2 tile without the intra-workgroup K split wins or ties everywhere else (64 -> 256 at
   // 2 x 256^2: 80 vs 103 us; 128 -> 512 at 2 x 128^2: 59 vs 70; 256 -> 256 3x3 at 2 x 64^2: 92 vs 171)
   const bool big = tile ? edge == 128 : (tiles128 >= 512 && Cout > 64 && (long)taps * Cin >= 2304);
-  const bool k32 = Cin % 32 == 0 && !(tile & 1);
+  // 16-deep K steps for the 1x1 layers of at most 128 input channels: four to eight short steps instead of two to four
+  // (and half the LDS per workgroup): 64 -> 256 + residual at 2 x 256^2 89 vs 97 us, 128 -> 512 + residual at 2 x 128^2
+  // 58 vs 65 us; equal elsewhere (scripts/conv_bn_timing.py tiles, profiles/r05_conv_bn.md)
+  const bool k32 = Cin % 32 == 0 && !(tile & 1) && !(tile == 0 && taps == 1 && Cin <= 128);
   const int steps = taps * (Cin / (k32 ? 32 : 16));
   // intra-workgroup K split (8 waves): conv_igemm.hip's rule; not for a K loop of one or two steps (the hand-over
   // through LDS then costs as much as the loop)

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from jdet_amd.ops.conv_igemm import conv_module
 from jdet_amd.models.boxes.anchor_target import anchor_inside_flags
 from jdet_amd.models.boxes.fixed_shape import dense_anchor_targets, proposal_table
 from jdet_amd.models.utils.level_pack import run_levels
@@ -68,7 +69,7 @@ class OrientedRPNHead(nn.Module):
     # ------------------------------------------------------------------ network
     def forward_single(self, x, mask=None):
         x = conv_igemm.conv3x3_module(self.rpn_conv, x, relu=True)      # the 1x1 layers below read no neighbours: a packed input needs no mask
-        return self.rpn_cls(x), self.rpn_reg(x)
+        return conv_module(self.rpn_cls, x), conv_module(self.rpn_reg, x)
 
     @staticmethod
     def _per_anchor(t, width):

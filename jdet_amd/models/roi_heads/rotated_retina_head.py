@@ -4,6 +4,7 @@ loss on DeltaXYWHABBoxCoder targets, top-k -> decode -> multiclass rotated NMS a
 import torch
 from torch import nn
 
+from jdet_amd.ops.conv_igemm import conv_module
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedRetinaNet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
 from jdet_amd.models.utils.level_pack import run_levels
@@ -85,7 +86,7 @@ class RotatedRetinaHead(RotatedAnchorHeadMixin, nn.Module):
             cls_feat = conv(cls_feat)
             if mask is not None:
                 cls_feat = cls_feat * mask
-        return self.retina_cls(cls_feat), self.retina_reg(reg_feat)
+        return conv_module(self.retina_cls, cls_feat), conv_module(self.retina_reg, reg_feat)
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         cfg = self.train_cfg.copy()

@@ -29,6 +29,7 @@ def _side_stream(device):
         s = _SIDE[device] = torch.cuda.Stream(device)
     return s
 from jdet_amd.models.utils.modules import ConvModule
+from jdet_amd.ops.conv_igemm import conv_module
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.ops.dcn_v1 import DeformConv
 from jdet_amd.ops.orn import ORConv2d, RotationInvariantPooling
@@ -165,9 +166,10 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         return x
 
     def _fam(self, x, mask=None, rows=None):
-        fam_bbox_pred = self.fam_reg(self._towers(x, self.fam_reg_convs, mask, rows))
+        # (prediction layers through conv_module: library forward, bias gradient by the own any-C column sum)
+        fam_bbox_pred = conv_module(self.fam_reg, self._towers(x, self.fam_reg_convs, mask, rows))
         # the FAM classification tower only runs in training (L213-220)
-        fam_cls_score = self.fam_cls(self._towers(x, self.fam_cls_convs, mask, rows)) if self.training else None
+        fam_cls_score = conv_module(self.fam_cls, self._towers(x, self.fam_cls_convs, mask, rows)) if self.training else None
         return fam_cls_score, fam_bbox_pred
 
     def _refine(self, x, fam_bbox_pred, stride):
@@ -181,8 +183,8 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         if mask is not None:
             or_feat = or_feat * mask
         odm_cls_feat = self.or_pool(or_feat) if self.with_orconv else or_feat
-        odm_cls_score = self.odm_cls(self._towers(odm_cls_feat, self.odm_cls_convs, mask, rows))
-        odm_bbox_pred = self.odm_reg(self._towers(or_feat, self.odm_reg_convs, mask, rows))
+        odm_cls_score = conv_module(self.odm_cls, self._towers(odm_cls_feat, self.odm_cls_convs, mask, rows))
+        odm_bbox_pred = conv_module(self.odm_reg, self._towers(or_feat, self.odm_reg_convs, mask, rows))
         return odm_cls_score, odm_bbox_pred
 
     def forward_single(self, x, stride):

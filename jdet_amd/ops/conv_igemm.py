@@ -352,10 +352,13 @@ def conv_module(conv, x, relu=False):
     plain = (type(conv).__name__ == "Conv2d" and conv.padding_mode == "zeros" and not isinstance(conv.padding, str)
              and not torch.is_autocast_enabled())
     grad = needs_grad(x, conv.weight, conv.bias)
-    if plain and _is_igemm_conv(conv) and preferred(x, conv.weight) and (TRAIN or not grad):
+    # (prediction layers of 5 / 15 / 18 channels would run a 64-wide output tile three quarters empty: the library's
+    # narrow-tile kernels keep their forward; their bias gradient still comes from the own column sum below)
+    if (plain and _is_igemm_conv(conv) and conv.out_channels >= 32 and preferred(x, conv.weight)
+            and (TRAIN or not grad)):
         return conv3x3_bias_act(x, conv.weight, conv.bias, relu)
     if (plain and grad and BIAS_ACT_BWD and conv.bias is not None and x.is_cuda and x.dtype == torch.float32
-            and _bias_bwd_supported(conv.out_channels)):
+            and (_bias_bwd_supported(conv.out_channels) or (not relu and conv.out_channels <= 256))):
         return _ConvBiasAct.apply(x, conv.weight, conv.bias, relu, conv.stride, conv.padding, conv.dilation,
                                   conv.groups, False)
     y = conv(x)

@@ -154,8 +154,16 @@ run_i() {   # closing re-validation: two-rank tests, 16-deep K steps on the shor
   grep -c "AccumulateGrad\|Grad strides" $OUT/bench_default.err
 }
 
+run_j() {   # prediction convs through conv_module + 16-deep K steps: model suites, the bench line, the step profile
+  OUT=$R/gpurun_out/r5_j; mkdir -p $OUT
+  timeout 1200 python -m pytest tests/test_gpu_s2anet.py tests/test_gpu_head_parity.py tests/test_gpu_oriented_rcnn.py tests/test_gpu_roi_transformer.py tests/test_gpu_conv_bn.py tests/test_gpu_conv_igemm.py tests/test_gpu_configs_full_size.py tests/test_gpu_ddp_detectors.py -q 2>&1 | tail -4 | tee $OUT/pytest.txt
+  timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-400
+  bash scripts/gpu_prof_s2anet.sh > $OUT/prof.txt 2>&1; cp gpurun_out/prof_s2anet/steady_state.txt $OUT/steady_state.txt; head -3 $OUT/steady_state.txt | cut -c1-150
+  rm -rf gpurun_out/prof_s2anet/trace
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|i|final) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|final} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h|i|j|final) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|final} [args]"; exit 2;;
 esac
