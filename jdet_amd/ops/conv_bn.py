@@ -60,6 +60,8 @@ def _plan(N, H, W, Cin, Cout, R, stride):
     key = (N, H, W, Cin, Cout, R, stride)
     hit = _PLAN.get(key)
     if hit is None:
+        if len(_PLAN) >= 512:          # (multi-scale training cycles through a bounded set of shapes; keep the cache so)
+            _PLAN.pop(next(iter(_PLAN)))
         lib = L.lib()
         ws = lib.jdet_conv_bn_workspace(N, H, W, Cin, Cout, R, stride)
         rows = lib.jdet_conv_bn_sums_rows(N, H, W, Cin, Cout, R, stride, 0, 1 if ws else 0)
@@ -295,7 +297,7 @@ def fusable(blk, x):
     """can this Bottleneck run as fused launches on x?"""
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
         return False
-    if not x.is_contiguous(memory_format=torch.channels_last):
+    if not x.is_contiguous(memory_format=torch.channels_last) or x.numel() == 0:
         return False
     ds = blk.downsample
     if ds is not None and not (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d)

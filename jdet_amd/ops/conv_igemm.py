@@ -144,14 +144,20 @@ def shared_wgrad(weight, x_nhwc, gy_nhwc, offset=None):
     key = weight.data_ptr()          # (the saved tensor may come back in a new Python wrapper: the storage names the weight)
     Cout, Cin = weight.shape[0], weight.shape[1]
     hit = _GW_ACC.get(key)
+    # sharing is per STREAM: a use replayed on another stream (the packed levels' side stream) must not add into a
+    # buffer whose hand-over to AccumulateGrad the engine orders only against the first use's stream -- it gets its own
+    # gradient tensor and autograd adds the two (advisor finding, round 4)
+    stream = torch.cuda.current_stream(x_nhwc.device).cuda_stream if x_nhwc.is_cuda else 0
+    if hit is not None and len(hit) > 3 and hit[3] != stream:
+        hit = None
     if tid >= 0 and hit is not None and hit[0] == tid and hit[2] == (Cout, Cin, x_nhwc.device):
         N, H, W, _ = x_nhwc.shape
         x_nhwc, gy_nhwc = L.f32c(x_nhwc), L.f32c(gy_nhwc)
         L.check(_wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, hit[1], 0), "jdet_conv3x3_wgrad")
         return None
     buf = conv3x3_wgrad_nhwc(x_nhwc, gy_nhwc, offset)
-    if tid >= 0:
-        _GW_ACC[key] = (tid, buf.data_ptr(), (Cout, Cin, x_nhwc.device))
+    if tid >= 0 and (_GW_ACC.get(key) is None or _GW_ACC[key][0] != tid):
+        _GW_ACC[key] = (tid, buf.data_ptr(), (Cout, Cin, x_nhwc.device), stream)
     return buf.permute(0, 3, 1, 2)
 
 
