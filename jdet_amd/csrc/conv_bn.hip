@@ -439,6 +439,8 @@ Plan make_plan(long M, int Cin, int Cout, int taps, int tile, bool workspace) {
   p.bk = k32 ? 32 : 16;
   p.kg = split ? 2 : 1;
   p.ksplit = 1;
+  // K steps split over workgroups below 384 tiles, aiming at ~768 workgroups: widening either (below 768 tiles / 1024-2048
+  // workgroups) measured equal or 5-15 % slower at the layer3 / layer4 shapes (profiles/r05_conv_bn.md)
   if (tile == 0 && !big && workspace && Cout % 4 == 0 && tiles64 < 384) {
     int k = (int)(768 / tiles64);                 // aim at ~3 workgroups per CU
     if (k > 8) k = 8;
