@@ -296,3 +296,44 @@ def test_resnet50_fused_equals_the_per_layer_path(dev):
     for n in ga:
         rel = float((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-12))
         assert rel <= 2e-2, (n, rel)
+
+
+def test_fused_bottleneck_replays_as_a_hip_graph(dev):
+    """forward + backward of a fused block captured once and replayed on new input data (written into the static input
+    in place): every replay equals the eager result for that data -- the path allocates its scratch inside the capture,
+    rewrites the data-gradient weights by a captured launch and zero-fills its weight-gradient buffer by a kernel, so
+    nothing of it depends on state outside the graph."""
+    from jdet_amd.ops import conv_bn as CB
+    blk = _make_block(512, 128, 1, False, dev, 5)
+    params = [p for p in blk.parameters()]
+    xs = torch.randn(2, 512, 16, 12, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn(2, 512, 16, 12, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def fwd_bwd():
+        CB.prepare([blk])
+        y = blk(xs)
+        grads = torch.autograd.grad(y, [xs] + params, gy)
+        return [y.detach()] + [g.detach() for g in grads]
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            fwd_bwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_out = fwd_bwd()
+    for seed in (1, 2, 3):
+        gen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            xs.copy_(torch.randn(xs.shape, generator=gen).to(dev).contiguous(memory_format=torch.channels_last))
+            blk.conv2.weight.mul_(1.0 + 0.01 * seed)          # the weights move between steps (the optimizer's update)
+        g.replay()
+        torch.cuda.synchronize()
+        got = [t.clone() for t in static_out]
+        ref = fwd_bwd()
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, seed
