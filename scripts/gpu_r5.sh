@@ -162,8 +162,17 @@ run_j() {   # prediction convs through conv_module + 16-deep K steps: model suit
   rm -rf gpurun_out/prof_s2anet/trace
 }
 
+run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, the default bench line
+  OUT=$R/gpurun_out/r5_z; mkdir -p $OUT
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+  timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+  timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -1 $OUT/bench_default.json | cut -c1-300
+  grep -c "AccumulateGrad\|Grad strides" $OUT/bench_default.err
+  true
+}
+
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|i|j|final) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|final} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h|i|j|z|final) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|z|final} [args]"; exit 2;;
 esac
