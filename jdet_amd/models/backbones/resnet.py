@@ -11,8 +11,6 @@ training mode).  What is left to the library: the 7x7 stem, the stride-2 data gr
 fused path does not take (BasicBlock, training-mode BatchNorm, other dtypes), where the per-layer path below runs the
 library convolution + one fused BatchNorm / ReLU pass (ops/frozen_bn.py).
 """
-import os
-
 import torch
 from torch import nn
 
@@ -30,59 +28,8 @@ def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
     return conv
 
 
-class _Conv1x1Gemm(torch.autograd.Function):
-    """A stride-1 1x1 convolution of a channels-last map IS a GEMM on its (N*H*W, C) matrix view.  Measured against the
-    library convolution at the bottleneck shapes of a 2 x 1024^2 step (scripts/conv1x1_probe.py, profiles/
-    r04_conv1x1_probe.txt): the data gradient as `gy . W` is 18 % faster over the stack, the forward wins from 512 input
-    channels up, the weight gradient `gy^T . x` only on the deep maps (its reduction runs over the positions: 300-400 us
-    at 256^2 against 48 for the library) -- so each direction goes where it measured faster."""
-
-    @staticmethod
-    def forward(ctx, x, weight, gemm_fwd):
-        N, Ci, H, W = x.shape
-        Co = weight.shape[0]
-        if gemm_fwd:
-            y = (x.permute(0, 2, 3, 1).reshape(-1, Ci) @ weight.view(Co, Ci).t()).view(N, H, W, Co).permute(0, 3, 1, 2)
-        else:
-            y = torch.ops.aten.convolution(x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1)
-        ctx.save_for_backward(x, weight)
-        return y
-
-    @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        N, Ci, H, W = x.shape
-        Co = weight.shape[0]
-        g = g.contiguous(memory_format=torch.channels_last)
-        gm = g.permute(0, 2, 3, 1).reshape(-1, Co)
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            gx = (gm @ weight.view(Co, Ci)).view(N, H, W, Ci).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            if N * H * W <= 4096:
-                gw = (gm.t() @ x.permute(0, 2, 3, 1).reshape(-1, Ci)).view(Co, Ci, 1, 1)
-            else:
-                gw = torch.ops.aten.convolution_backward(g, x, weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
-                                                         [False, True, False])[1]
-        return gx, gw, None
-
-
-class Conv1x1(nn.Conv2d):
-    """nn.Conv2d(kernel_size=1, bias=False) -- same parameters / state-dict keys -- routed per direction (see
-    _Conv1x1Gemm) for stride-1 fp32 channels-last maps on the device; everything else is the plain convolution."""
-    GEMM = os.environ.get("JDET_CONV1X1_GEMM", "1") == "1"
-
-    def forward(self, x):
-        if (self.GEMM and x.is_cuda and x.dtype == torch.float32 and self.stride == (1, 1) and x.dim() == 4
-                and x.is_contiguous(memory_format=torch.channels_last) and torch.is_grad_enabled()
-                and (x.requires_grad or self.weight.requires_grad) and not torch.is_autocast_enabled()):
-            M = x.shape[0] * x.shape[2] * x.shape[3]
-            return _Conv1x1Gemm.apply(x, self.weight, self.in_channels >= 256 and M <= 32768)
-        return super().forward(x)
-
-
 def conv1x1(in_planes, out_planes, stride=1):
-    conv = Conv1x1(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+    conv = nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
     nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
     return conv
 

@@ -120,18 +120,14 @@ def conv3x3_wgrad(x, gy, offset=None, ksplit=0):
 # returned: the kernel adds in place, so the engine neither zero-fills per call nor sums the uses afterwards.
 # Measured (profiles/r04_conv_wgrad.md): the kernel runs 91 % MFMA-busy in cycles and ties the library's in isolation
 # (312 vs 314-326 us at 2 x 128^2 x 256), but inside the autotuned S2ANet step the library's pick is faster than its
-# stand-alone time: 29.28 ms with this switch on against 29.02-29.06 ms off -- so it is off by default.
+# stand-alone time: 29.28 ms with this switch on against 29.02-29.06 ms off -- so it is off by default.  (Round 5: the same
+# layers through the backbone's 64 x 64-tile entry point tie the library as well: 27.885 vs 27.904 ms, profiles/r05_conv_bn.md.)
 WGRAD = os.environ.get("JDET_CONV_WGRAD", "0") == "1"
-# (measurement) the plain 3x3 form through the backbone's entry point: 64 x 64 tiles, split in whole XCD rounds
-WGRAD_GENERAL = os.environ.get("JDET_CONV_WGRAD_GENERAL", "0") == "1"
-
-
 def _wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, out_ptr, ksplit):
-    if WGRAD_GENERAL and offset is None:
-        return L.lib().jdet_conv_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc), N, H, W, Cin, Cout, 3, 1, out_ptr, int(ksplit),
-                                       L.stream_ptr(x_nhwc))
     return L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc), L.ptr(L.f32c(offset)) if offset is not None else None,
                                       N, H, W, Cin, Cout, out_ptr, int(ksplit), L.stream_ptr(x_nhwc))
+
+
 _GW_ACC = {}           # weight.data_ptr() -> (backward pass id, device pointer of the (Cout,3,3,Cin) buffer, its shape)
 
 
