@@ -107,7 +107,9 @@ def test_cfg0_micro_vs_oracle(dev, fwd_mode):
     O.set_threads(8)
     np.testing.assert_allclose(y, O.roi_align_forward(O.V_ROT, feat, rois, (7, 7), 0.25, 2), rtol=0, atol=fwd_mode)
     ref = O.roi_align_backward(O.V_ROT, grad, rois, feat.shape, 0.25, 2)
-    np.testing.assert_allclose(gi, ref, rtol=0, atol=1e-4)
+    # measured (round 5): max |err| 2.9e-6 on gradients up to 7.1 (mean 0.16) -- summation order of up to ~40 entries per
+    # pixel, fp32; the bar is the backward tolerance of the rest of this file, 2e-5 x the gradient scale
+    np.testing.assert_allclose(gi, ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("variant", [O.V_ROT, O.V_ROT_V1, O.V_HBB0])
