@@ -171,14 +171,8 @@ run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, 
   true
 }
 
-run_l() {   # the head towers as one autograd node: parity, the S2ANet suites, step A/B
-  OUT=$R/gpurun_out/r5_l; mkdir -p $OUT
-  timeout 900 python -m pytest tests/test_gpu_conv_bn.py tests/test_gpu_s2anet.py tests/test_gpu_head_parity.py -q -k "tower or s2anet or S2ANet or head or packed or graph" 2>&1 | tail -6 | tee $OUT/pytest.txt
-  bash scripts/ab_step.sh -n 2 -s 20 "JDET_TOWER_FUSED=1" "JDET_TOWER_FUSED=0" 2>&1 | tee $OUT/ab.txt
-}
-
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|i|j|l|z|final) run_$run "$@";;
-  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|l|z|final} [args]"; exit 2;;
+  a|b|c|d|e|f|g|h|i|j|z|final) run_$run "$@";;
+  *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|z|final} [args]"; exit 2;;
 esac
