@@ -29,7 +29,6 @@ def _side_stream(device):
         s = _SIDE[device] = torch.cuda.Stream(device)
     return s
 from jdet_amd.models.utils.modules import ConvModule
-from jdet_amd.ops import conv_tower
 from jdet_amd.ops.conv_igemm import conv_module
 from jdet_amd.models.utils.weight_init import bias_init_with_prob, normal_init
 from jdet_amd.ops.dcn_v1 import DeformConv
@@ -156,10 +155,6 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
     def _towers(self, x, convs, mask=None, rows=None):
         """rows: the pack's mask per position of the batch, flat -- the fused conv multiplies it into its finished rows
         (ConvModule.masked); layers it does not apply to are followed by the multiplication"""
-        if (mask is None or rows is not None) and conv_tower.applicable(list(convs), x):
-            # the whole tower as one autograd node: inside it the ReLU mask / bias sum of a layer's gradient ride in the
-            # epilogue of the next layer's data gradient (ops/conv_tower.py)
-            return conv_tower.tower(list(convs), x, rows)
         for conv in convs:
             y = conv.masked(x, rows) if rows is not None and hasattr(conv, "masked") else None
             if y is not None:
@@ -308,8 +303,6 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
     def _level_outputs(self, feats):
         """per level (fam_cls_score, fam_bbox_pred, refine_anchor, odm_cls_score, odm_bbox_pred); the small levels
         go through forward_packed together"""
-        if self.training and torch.is_grad_enabled() and feats[0].is_cuda and conv_tower.ENABLED:
-            conv_tower.prepare([self.fam_reg_convs, self.fam_cls_convs, self.odm_reg_convs, self.odm_cls_convs])
         small = [i for i, f in enumerate(feats)
                  if f.is_cuda and f.shape[-2] * f.shape[-1] <= self.pack_max_positions]
         outs = [None] * len(feats)

@@ -337,40 +337,3 @@ def test_fused_bottleneck_replays_as_a_hip_graph(dev):
         torch.cuda.synchronize()
         for a, b in zip(got, ref):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, seed
-
-
-@pytest.mark.parametrize("cin,masked", [(256, False), (32, False), (256, True)])
-def test_tower_node_equals_the_per_layer_nodes(dev, cin, masked):
-    """ops/conv_tower: a tower of conv + bias + ReLU layers as one autograd node (the ReLU mask / bias sum of layer 1's
-    gradient in the epilogue of layer 2's data gradient) against one node per layer: same output, same gradients for the
-    input, both weights and both biases; with the gap-row mask of a level pack as well."""
-    from jdet_amd.models.utils.modules import ConvModule
-    from jdet_amd.ops import conv_tower as CT
-    torch.manual_seed(cin)
-    mods = [ConvModule(cin, 256, 3, padding=1).to(dev), ConvModule(256, 256, 3, padding=1).to(dev)]
-    for m in mods:
-        m.conv.weight.data = m.conv.weight.data.contiguous(memory_format=torch.channels_last)
-        torch.nn.init.normal_(m.conv.bias, 0, 0.1)
-    N, H, W = 2, 20, 28
-    x = torch.randn(N, cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
-    rows = None
-    if masked:
-        rows = (torch.rand(N * H * W, device=dev) > 0.2).float()
-    gy = torch.randn(N, 256, H, W, device=dev).contiguous(memory_format=torch.channels_last)
-    res = []
-    for fused in (True, False):
-        xa = x.clone().requires_grad_(True)
-        for m in mods:
-            m.zero_grad(set_to_none=True)
-        if fused:
-            assert CT.applicable(mods, xa)
-            CT.prepare([mods])
-            y = CT.tower(mods, xa, rows)
-        else:
-            y = xa
-            for m in mods:
-                y = m.masked(y, rows) if rows is not None else m(y)
-        y.backward(gy)
-        res.append([y.detach()] + [xa.grad] + [p.grad.clone() for m in mods for p in (m.conv.weight, m.conv.bias)])
-    for a, b in zip(*res):
-        assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()) + 1e-5
