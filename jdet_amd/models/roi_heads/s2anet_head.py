@@ -176,7 +176,7 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
         num_level = self.anchor_strides.index(stride)
         init_anchors = self._init_anchors(num_level, tuple(fam_bbox_pred.shape[-2:]), x.device)
         refine_anchor = bbox_decode(fam_bbox_pred.detach(), init_anchors, self.target_means, self.target_stds)
-        return refine_anchor, self.align_conv(x, refine_anchor.clone(), stride)
+        return refine_anchor, self.align_conv(x, refine_anchor, stride)     # (read-only there: no copy needed)
 
     def _odm(self, align_feat, mask=None, rows=None):
         or_feat = self.or_conv(align_feat)
