@@ -21,9 +21,13 @@ struct Entry {
 constexpr int kScanTile = 2048;  // 256 threads x 8
 constexpr int kScanTileLog2 = 11;
 
+// `cap` / `skip_if_zero` (patch-keyed variant below): a row's first `cap` entries live outside the CSR, so the scanned
+// length is max(count - cap, 0); a launch whose *skip_if_zero is 0 (no row went past its cap) has nothing to do.
 static __global__ __launch_bounds__(256) void csr_scan_kernel(const int* __restrict__ counts, int n, int ntiles,
                                                               int* __restrict__ offsets, int* __restrict__ tile_sum,
-                                                              int* __restrict__ tile_base, int* __restrict__ ticket) {
+                                                              int* __restrict__ tile_base, int* __restrict__ ticket,
+                                                              int cap = 0, const int* __restrict__ skip_if_zero = nullptr) {
+  if (skip_if_zero != nullptr && *skip_if_zero == 0) return;
   __shared__ int s_wave[4];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -31,7 +35,7 @@ static __global__ __launch_bounds__(256) void csr_scan_kernel(const int* __restr
   int v[8], sum = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    v[i] = lo + i < n ? counts[lo + i] : 0;
+    v[i] = lo + i < n ? max(counts[lo + i] - cap, 0) : 0;
     sum += v[i];
   }
   int incl = sum;
@@ -246,32 +250,53 @@ struct PatchEntry {
 };
 static_assert(sizeof(TapRec) == 32 && sizeof(PatchEntry) == 32, "32-byte records: aligned vector / scalar accesses");
 
+// Direct rows.  A patch's first `cap` entries (cap = a power of two chosen from the shape, patch_direct_cap) have a
+// fixed home, direct[key * cap + place]: the producer writes them where the gather reads them, and the count -> scan
+// -> fill round trip (5.9 + 9.9 us of the 76 us backward at the north-star point) only runs for what goes past the
+// cap -- rows under clustered RoIs -- with the CSR machinery unchanged (cap = 0 IS the path of rounds 2-5, and runs at
+// its speed: 76.2 us).  A producer workgroup that wrote overflow records raises over_flag (a plain store of 1: a
+// SUM there cost 13 us -- 2000 atomics on one address); the scan and fill launches find 0 and return (~1.6 us each).
+// 76.3 -> 66.5-67.5 us for the whole backward (profiles/r05_roi_bwd_notes.md).
 struct PatchWs {
-  int* counts;      // nkeys row counters, [nkeys] = scan ticket: patch_zero_bytes()
+  int* counts;      // nkeys row counters, [nkeys] = scan ticket, [nkeys + 1] = over_flag: patch_zero_bytes()
   int* offsets;
   int* tile_sum;
   int* tile_base;
-  int* seg_n;       // records per producer segment (one segment per producer workgroup, seg_cap records each)
+  int* seg_n;       // overflow records per producer segment (one per producer workgroup, seg_cap records each)
   TapRec* recs;
-  PatchEntry* entries;
+  PatchEntry* entries;   // CSR of the overflow
+  PatchEntry* direct;    // nkeys x cap
+  int cap;
   size_t bytes;
 };
 
-inline size_t patch_zero_bytes(long nkeys) { return sizeof(int) * (size_t)(nkeys + 1); }
+inline size_t patch_zero_bytes(long nkeys) { return sizeof(int) * (size_t)(nkeys + 2); }
 
-inline PatchWs patch_carve(void* ws, long nkeys, long nsegs, long seg_cap) {
+// cap = the power of two >= 2.5 x the expected row length (about half of the taps survive the merge), 32..256, halved
+// while the direct rows would take more than 256 MiB; 0 = no direct rows
+inline int patch_direct_cap(long nkeys, long max_recs) {
+  const double expect = 0.5 * (double)max_recs / (double)(nkeys > 0 ? nkeys : 1);
+  int cap = 32;
+  while (cap < 256 && (double)cap < 2.5 * expect) cap <<= 1;
+  while (cap >= 16 && (size_t)nkeys * cap * sizeof(PatchEntry) > ((size_t)256 << 20)) cap >>= 1;
+  return cap >= 16 ? cap : 0;
+}
+
+inline PatchWs patch_carve(void* ws, long nkeys, long nsegs, long seg_cap, int cap) {
   const long max_recs = nsegs * seg_cap;
   PatchWs w;
   char* p = (char*)ws;
   size_t off = 0;
   const long ntiles = (nkeys + kScanTile - 1) / kScanTile;
-  w.counts = (int*)(p + off);    off += align256(sizeof(int) * (nkeys + 1));
+  w.cap = cap;
+  w.counts = (int*)(p + off);    off += align256(sizeof(int) * (nkeys + 2));
   w.offsets = (int*)(p + off);   off += align256(sizeof(int) * (nkeys + 1));
   w.tile_sum = (int*)(p + off);  off += align256(sizeof(int) * (ntiles + 1));
   w.tile_base = (int*)(p + off); off += align256(sizeof(int) * (ntiles + 1));
   w.seg_n = (int*)(p + off);     off += align256(sizeof(int) * nsegs);
   w.recs = (TapRec*)(p + off);   off += align256(sizeof(TapRec) * max_recs);
   w.entries = (PatchEntry*)(p + off); off += align256(sizeof(PatchEntry) * max_recs);
+  w.direct = (PatchEntry*)(p + off);  off += align256(sizeof(PatchEntry) * (size_t)nkeys * cap);
   w.bytes = off;
   return w;
 }
@@ -292,21 +317,55 @@ static __global__ __launch_bounds__(256) void csr_fill_patch_kernel(const TapRec
   }
 }
 
+// acc[q] += w[q] * row(src) over `count` entries at `ent`: fetched 64 at a time, one per lane (one coalesced 2 KiB
+// read), and handed round by readlane -- no scalar-load latency inside the loop, UNROLL row loads issued back to back
+// (the row loads are L2 latency bound: with 4 in flight behind a scalar entry load per iteration the gather ran 46 us,
+// patch-keyed or not).
+template <int UNROLL>
+__device__ __forceinline__ void patch_accumulate(const PatchEntry* __restrict__ ent, int count,
+                                                 const float* __restrict__ col, int C, int lane, v4f (&acc)[4]) {
+  for (int base = 0; base < count; base += 64) {
+    const int n = min(64, count - base);
+    // lane l: entry base + l; lanes past the end: the batch's first source row with zero weights (a cached address)
+    const int4 a = reinterpret_cast<const int4*>(ent + base + (lane < n ? lane : 0))[0];
+    const float w3 = reinterpret_cast<const float*>(ent + base + (lane < n ? lane : 0))[4];
+    const int e_src = a.x;
+    const float e_w[4] = {lane < n ? __int_as_float(a.y) : 0.f, lane < n ? __int_as_float(a.z) : 0.f,
+                          lane < n ? __int_as_float(a.w) : 0.f, lane < n ? w3 : 0.f};
+    for (int i = 0; i < n; i += UNROLL) {
+      v4f v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        const int src = __builtin_amdgcn_readlane(e_src, (i + u) & 63);
+        v[u] = *reinterpret_cast<const v4f*>(col + (size_t)src * C);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_w[q]), (i + u) & 63));
+          acc[q] += w * v[u];
+        }
+    }
+  }
+}
+
 // One wave per patch; lane owns 4 consecutive channels of a 256-channel chunk; 4 accumulators (the patch's pixels).
 // Workgroup = 2x2 patches; every XCD owns one 2-D block of the workgroup grid (below).
 // img_h / img_w: pixel size of one image; keys = images x ceil(img_h/2) x ceil(img_w/2) patches.
-// A patch's entries are fetched 64 at a time, one per lane (one coalesced 2 KiB read), and handed round by readlane:
-// no scalar-load latency inside the loop, UNROLL row loads issued back to back (the row loads are L2 latency bound:
-// with 4 in flight behind a scalar entry load per iteration this kernel ran 46 us, patch-keyed or not).
+// A patch's entries: min(count, cap) in its direct row, the rest (count > cap only) in the CSR of the overflow.
+// The row counters and over_flag are handed back zeroed (a patch's counter after its entries were read).
 template <int UNROLL>
 static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const float* __restrict__ gT,
                                                               const int* __restrict__ offsets,
-                                                              const int* __restrict__ tile_base, int ntiles,
-                                                              const PatchEntry* __restrict__ entries, int nkeys,
-                                                              int C, int n_img, int img_h, int img_w,
+                                                              const int* __restrict__ tile_base,
+                                                              const PatchEntry* __restrict__ entries,
+                                                              const PatchEntry* __restrict__ direct, int cap,
+                                                              int nkeys, int C, int n_img, int img_h, int img_w,
                                                               int* __restrict__ counts, float* __restrict__ grad_in) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[nkeys + 1] = 0;   // over_flag: scan and fill have read it
   const int php = (img_h + 1) >> 1, pwp = (img_w + 1) >> 1;
   const int bw = (pwp + 1) >> 1;                               // workgroups per row of patches
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -326,10 +385,11 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
   if (prow >= n_img * php || pcol >= pwp) return;
   const int p = prow * pwp + pcol;
   const int img = prow / php, py = prow - img * php;
-  const int beg = __builtin_amdgcn_readfirstlane(row_begin(offsets, tile_base, p));
-  const int end = __builtin_amdgcn_readfirstlane(p + 1 < nkeys ? row_begin(offsets, tile_base, p + 1)
-                                                               : tile_base[ntiles]);
-  if (lane == 0) counts[p] = 0;
+  const int cnt = __builtin_amdgcn_readfirstlane(counts[p]);
+  const int n_direct = min(cnt, cap), n_over = cnt - n_direct;
+  const PatchEntry* __restrict__ row_d = direct + (size_t)p * cap;
+  const PatchEntry* __restrict__ row_o =
+      entries + (n_over > 0 ? __builtin_amdgcn_readfirstlane(row_begin(offsets, tile_base, p)) : 0);
   const int y0 = py * 2, x0 = pcol * 2;
   const bool has_y1 = y0 + 1 < img_h, has_x1 = x0 + 1 < img_w;
   float* __restrict__ out0 = grad_in + ((size_t)(img * img_h + y0) * img_w + x0) * C;
@@ -338,30 +398,8 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
     const bool ok = c < C;                       // C % 4 == 0 on this path
     const float* __restrict__ col = gT + (ok ? c : 0);
     v4f acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int base = beg; base < end; base += 64) {
-      const int n = min(64, end - base);
-      // lane l: entry base + l; lanes past the end: the batch's first source row with zero weights (a cached address)
-      const int4 a = reinterpret_cast<const int4*>(entries + base + (lane < n ? lane : 0))[0];
-      const float w3 = reinterpret_cast<const float*>(entries + base + (lane < n ? lane : 0))[4];
-      const int e_src = a.x;
-      const float e_w[4] = {lane < n ? __int_as_float(a.y) : 0.f, lane < n ? __int_as_float(a.z) : 0.f,
-                            lane < n ? __int_as_float(a.w) : 0.f, lane < n ? w3 : 0.f};
-      for (int i = 0; i < n; i += UNROLL) {
-        v4f v[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-          const int src = __builtin_amdgcn_readlane(e_src, (i + u) & 63);
-          v[u] = *reinterpret_cast<const v4f*>(col + (size_t)src * C);
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(e_w[q]), (i + u) & 63));
-            acc[q] += w * v[u];
-          }
-      }
-    }
+    patch_accumulate<UNROLL>(row_d, n_direct, col, C, lane, acc);
+    if (n_over > 0) patch_accumulate<UNROLL>(row_o, n_over, col, C, lane, acc);
     if (ok) {
       *reinterpret_cast<v4f*>(out0 + c) = acc[0];
       if (has_x1) *reinterpret_cast<v4f*>(out0 + C + c) = acc[1];
@@ -369,15 +407,18 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
       if (has_y1 && has_x1) *reinterpret_cast<v4f*>(out0 + (size_t)(img_w + 1) * C + c) = acc[3];
     }
   }
+  if (lane == 0) counts[p] = 0;
 }
 
-// counts[] hold the row lengths, segment g of recs its seg_n[g] kept taps, counts[nkeys] (ticket) is zero.
+// counts[] hold the row lengths, direct[] the first `cap` entries of every row, segment g of recs its seg_n[g] overflow
+// records, counts[nkeys + 1] their total; counts[nkeys] (ticket) is zero.
 // On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
 inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
                                    float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
   const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
+  int* over_flag = w.counts + nkeys + 1;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
-                     w.tile_sum, w.tile_base, w.counts + nkeys);
+                     w.tile_sum, w.tile_base, w.counts + nkeys, w.cap, (const int*)over_flag);
   hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
                      w.offsets, w.tile_base, w.entries);
   const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
@@ -388,7 +429,7 @@ inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, lon
   const int BR = (wg_rows + nbr - 1) / nbr, BC = (bw + nbc - 1) / nbc;
   const unsigned blocks = 8u * 64u * (unsigned)(((BR + 7) / 8) * ((BC + 7) / 8));
   hipLaunchKernelGGL((csr_gather_patch_kernel<8>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
-                     ntiles, w.entries, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
+                     w.entries, w.direct, w.cap, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
   return jdet_launch_status();
 }
 

@@ -8,18 +8,19 @@
 // Every contribution is  grad_in[pixel, c] += w * grad_out[roi, c, bin]  with (pixel, w) independent
 // of c.  So the scatter is inverted once per launch on the (roi, sample, tap) index space -- 1.57 M
 // entries instead of 401 M atomics -- and then GATHERED:
-//   K1  tap list, one workgroup per RoI: geometry (double-precision trig) once, then one lane per (bin, sample):
-//       pixel key + weight/count of its 4 taps; integer atomicAdd into a per-pixel counter (CSR row lengths)
-//       whose return value is the tap's place in its row
-//   K2  exclusive scan of the N*H*W counters (one launch; the last workgroup scans the tile totals)
-//   K3  fill: entry = (roi*nbins + bin, w) written at row offset + place (no second round of atomics)
+//   K1  entries, one workgroup per RoI: geometry (double-precision trig) once, then one lane per (bin, sample): the
+//       taps of a bin that fall into one aligned 2x2 pixel PATCH merge into one entry (source row, 4 weights;
+//       csr_gather.h); an integer atomicAdd on the patch's counter returns the entry's place in the patch's row; the
+//       first `cap` entries of a row are written straight to their home (direct rows), the rest become records
+//   K2  (rows past the cap only; returns at once otherwise) exclusive scan of the overflow lengths
+//   K3  (ditto) fill: overflow record -> CSR entry at row offset + place (no second round of atomics)
 //   K4  (only for an (R,C,PH,PW) gradient) grad_out -> gT (R, PH*PW, C): a contribution's channel vector becomes
 //       contiguous; a channels-last gradient (jdet_roi_align_backward_cl) is that matrix already
-//   K5  gather: one wave per pixel, lanes = channels (dwordx4), loop over the pixel's entries,
-//       acc += w * gT[entry]; ONE coalesced store per pixel (zeros for untouched pixels, so no
-//       memset pass).  fp32 adds happen in registers.  2x2 pixel patches per workgroup, 8-row stripes round-robin
-//       over the XCDs (csr_gather.h); the counters are zeroed again on the way out, so a caller that keeps the
-//       workspace (workspace_clean) pays no memset launch.
+//   K5  gather: one wave per patch, lanes = channels (dwordx4), loop over the patch's entries (direct row, then CSR),
+//       acc[pixel] += w[pixel] * gT[entry]; ONE coalesced store per pixel (zeros for untouched pixels, so no memset
+//       pass).  fp32 adds happen in registers.  2x2 patches per workgroup, every XCD owns one 2-D block of the map
+//       (csr_gather.h); the counters are zeroed again on the way out, so a caller that keeps the workspace
+//       (workspace_clean) pays no memset launch.
 // Summation order inside a pixel follows slot order (integer-atomic order), i.e. it is as
 // order-nondeterministic in the last bits as the reference's atomics; values agree to fp32 tolerance.
 // RiRoIAlign runs the same gather on orientation-mixed gradient rows (riroi_mix_rows_kernel); adaptive sampling
@@ -34,16 +35,37 @@ using namespace jdet_csr;
 
 long patch_keys(int N, int H, int W) { return (long)N * ((H + 1) / 2) * ((W + 1) / 2); }
 
+
+// One merged entry (source row, the four weights of a patch's pixels): counted in its patch's row (integer atomic, the
+// return value is its place) and written to its home in the patch's direct row, or -- past the cap -- as a record of the
+// producer's own segment (compacted through the LDS counter) for the scan + fill of the overflow CSR.
+__device__ __forceinline__ void emit_entry(int key, int src_row, float w0, float w1, float w2, float w3,
+                                           int* __restrict__ counts, PatchEntry* __restrict__ direct, int cap,
+                                           TapRec* __restrict__ seg, int* s_n) {
+  const int pos = atomicAdd(&counts[key], 1);
+  if (pos < cap) {
+    int4* dst = reinterpret_cast<int4*>(direct + (size_t)key * cap + pos);
+    dst[0] = make_int4(src_row, __float_as_int(w0), __float_as_int(w1), __float_as_int(w2));
+    dst[1] = make_int4(__float_as_int(w3), 0, 0, 0);
+  } else {
+    const int local = atomicAdd(s_n, 1);
+    int4* dst = reinterpret_cast<int4*>(seg + local);
+    dst[0] = make_int4(key, pos - cap, src_row, __float_as_int(w0));
+    dst[1] = make_int4(__float_as_int(w1), __float_as_int(w2), __float_as_int(w3), 0);
+  }
+}
+
 // One workgroup per RoI: thread 0 does the geometry (double-precision trig included) once, then one lane per
 // (bin, sample) turns its 4 taps into patch entries (csr_gather.h: key = aligned 2x2 pixel patch, 4 weights), merges
-// the entries of its bin that share a patch (the 4 samples of a bin are 4 consecutive lanes), counts the survivors in
-// their patch's row (integer atomic, the return value is the place in the row) and writes them, compacted through an
-// LDS counter, into the RoI's own record segment (no global cursor: the fill launch walks the segments).
+// the entries of its bin that share a patch (the 4 samples of a bin are 4 consecutive lanes) and emits the survivors
+// (emit_entry).  Measured and not kept (profiles/r05_roi_bwd_notes.md): the four counter atomics of a lane issued back
+// to back (+2 us), the merge through LDS hash tables (equal), through fma selects (equal), 8 workgroups per CU (spills).
 template <int VARIANT>
 __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __restrict__ rois, int H, int W, int PH,
                                                             int PW, float spatial_scale, int sample_num,
                                                             TapRec* __restrict__ recs, int* __restrict__ seg_n,
-                                                            int* __restrict__ counts) {
+                                                            int* __restrict__ counts, PatchEntry* __restrict__ direct,
+                                                            int cap, int* __restrict__ over_flag) {
   constexpr int ROI_COLS = (VARIANT == JDET_ROI_HBB_V0 || VARIANT == JDET_ROI_HBB_V1) ? 5 : 6;
   __shared__ RoiGeom s_geom;
   __shared__ int s_n;
@@ -119,17 +141,14 @@ __global__ __launch_bounds__(256) void bwd_patch_taps_kernel(const float* __rest
     for (int k = 0; k < 4; k++) {
       const bool keep = valid && first[k] &&
                         (wv[k][0] != 0.f || wv[k][1] != 0.f || wv[k][2] != 0.f || wv[k][3] != 0.f);
-      if (keep) {
-        const int pos = atomicAdd(&counts[key[k]], 1);
-        const int local = atomicAdd(&s_n, 1);
-        int4* dst = reinterpret_cast<int4*>(seg + local);
-        dst[0] = make_int4(key[k], pos, src_row, __float_as_int(wv[k][0]));
-        dst[1] = make_int4(__float_as_int(wv[k][1]), __float_as_int(wv[k][2]), __float_as_int(wv[k][3]), 0);
-      }
+      if (keep) emit_entry(key[k], src_row, wv[k][0], wv[k][1], wv[k][2], wv[k][3], counts, direct, cap, seg, &s_n);
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) seg_n[r] = s_n;
+  if (threadIdx.x == 0) {
+    seg_n[r] = s_n;
+    if (s_n) *over_flag = 1;     // a flag, not a sum: every writer stores the same value (no serialised atomics)
+  }
 }
 
 // (R, C, nbins) -> (R, nbins, C), 32x32 LDS tiles
@@ -177,14 +196,14 @@ int run_gather(const float* grad_out, const float* rois, int R, int N, int C, in
                hipStream_t st, int n_orient = 0) {
   const int nbins = PH * PW, spb = sample_num * sample_num;
   const long nkeys = patch_keys(N, H, W), seg_cap = (long)nbins * spb * 4;
-  PatchWs w = patch_carve(ws, nkeys, R, seg_cap);
+  PatchWs w = patch_carve(ws, nkeys, R, seg_cap, patch_direct_cap(nkeys, R * seg_cap));
   float* gT = (float*)((char*)ws + w.bytes);
   if (!ws_clean) {   // workspace of unknown content: zero the row counters and the ticket (a clean one is handed back clean)
     int he = jdet_zero_async(w.counts, patch_zero_bytes(nkeys), st);
     if (he) return he;
   }
   hipLaunchKernelGGL((bwd_patch_taps_kernel<VARIANT>), dim3(R), dim3(256), 0, st, rois, H, W, PH, PW, scale,
-                     sample_num, w.recs, w.seg_n, w.counts);
+                     sample_num, w.recs, w.seg_n, w.counts, w.direct, w.cap, w.counts + nkeys + 1);
   const float* rows = grad_out;   // channels-last (R, PH, PW, C) IS the (R, nbins, C) row matrix the gather wants
   if (!grad_out_cl) {
     dim3 tg(jdet_cdiv(nbins, 32), jdet_cdiv(C, 32), R);
@@ -217,7 +236,8 @@ static bool gather_ok(int variant, int R, int N, int C, int H, int W, int PH, in
 JDET_API size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                                  int sample_num) {
   if (!gather_ok(variant, R, N, C, H, W, PH, PW, sample_num)) return 0;
-  return patch_carve(nullptr, patch_keys(N, H, W), R, (long)PH * PW * sample_num * sample_num * 4).bytes +
+  const long nkeys = patch_keys(N, H, W), seg_cap = (long)PH * PW * sample_num * sample_num * 4;
+  return patch_carve(nullptr, nkeys, R, seg_cap, patch_direct_cap(nkeys, R * seg_cap)).bytes +
          align256(sizeof(float) * (size_t)R * PH * PW * C);
 }
 

@@ -86,12 +86,13 @@ def _kept_backward_workspace(dev, map_shape, nbytes):
     """Workspace of the channels-last backward, kept per (device, stream, map size): zero-filled once; the call hands
     its counters back zeroed (`workspace_clean` contract of jdet_roi_align_backward_cl), so no memset launch per
     step.  One buffer per map size: the zeroed region's length depends on it.
-    Under HIP-graph capture nothing is kept: the buffer is allocated (and zero-filled by a captured kernel) per call
-    from the capturing graph's own pool, so its address lives exactly as long as the graph that baked it in -- a
-    cache entry created during one capture could otherwise be evicted (or re-used by the next capture on the same
-    capture stream) while replays of the first graph still write to it."""
+    Under HIP-graph capture nothing is kept: the buffer is allocated per call from the capturing graph's own pool (and
+    passed as scratch of unknown content: the call zeroes its counters itself), so its address lives exactly as long
+    as the graph that baked it in -- a cache entry created during one capture could otherwise be evicted (or re-used by
+    the next capture on the same capture stream) while replays of the first graph still write to it.
+    Returns (workspace, cache key | None = scratch)."""
     if torch.cuda.is_current_stream_capturing():
-        return torch.zeros((nbytes,), dtype=torch.uint8, device=dev), None
+        return torch.empty((nbytes,), dtype=torch.uint8, device=dev), None
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tuple(map_shape))
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -118,7 +119,7 @@ def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_o
         try:
             L.check(L.lib().jdet_roi_align_backward_cl(variant, L.ptr(g_out), L.ptr(rois_c), R, N, C, H, W, PH, PW,
                                                        scale, sample_num, int(n_orient), L.ptr(grad_in), L.ptr(ws),
-                                                       ws.numel(), 1, L.stream_ptr(g_out)),
+                                                       ws.numel(), 1 if key is not None else 0, L.stream_ptr(g_out)),
                     "jdet_roi_align_backward_cl")
         except Exception:
             if key is not None:

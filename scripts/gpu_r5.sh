@@ -162,6 +162,20 @@ run_j() {   # prediction convs through conv_module + 16-deep K steps: model suit
   rm -rf gpurun_out/prof_s2anet/trace
 }
 
+run_k() {   # backward with direct rows (csr_gather.h): parity, time, per-kernel times.  The A/B runs behind
+            # profiles/r05_roi_bwd_notes.md (cap 0 / 16 / 64, counter atomics back to back, LDS merge, fma merge, XCD-sorted
+            # RoIs) used switches that lived in the library for those runs only
+  OUT=$R/gpurun_out/r5_k; mkdir -p $OUT
+  timeout 600 python -m pytest tests/test_gpu_roi_align.py tests/test_gpu_reference_kernels.py -q -x -k "back or bwd or grad or workspace or cap or golden or channels_last or riroi" 2>&1 | tail -2 | tee $OUT/pytest.txt
+  for i in 1 2 3; do
+    timeout 300 python bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 200 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'
+  done | tee $OUT/bwd.txt
+  cd /tmp
+  rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --steps 100 > /dev/null 2>&1
+  k=$(find $OUT/trace -name '*kernel_stats.csv' | head -1); cp $k $OUT/kernel_stats_roi_align_rotated_bwd.csv; rm -rf $OUT/trace
+  cd $R
+}
+
 run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, the default bench line
   OUT=$R/gpurun_out/r5_z; mkdir -p $OUT
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -173,6 +187,6 @@ run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, 
 
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|i|j|z|final) run_$run "$@";;
+  a|b|c|d|e|f|g|h|i|j|k|z|final) run_$run "$@";;
   *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|z|final} [args]"; exit 2;;
 esac

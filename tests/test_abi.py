@@ -183,7 +183,7 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     assert lib.jdet_roi_align_backward_workspace(0, 10, 1, 6, 8, 8, 7, 7, 2) == 0                      # C % 4
     need = lib.jdet_roi_align_backward_workspace(0, 10, 1, 8, 8, 8, 7, 7, 2)
     clean = lib.jdet_roi_align_backward_clean_bytes(0, 10, 1, 8, 8, 8, 7, 7, 2)
-    assert 0 < clean < need and clean == 4 * (16 + 1)                                                  # 4x4 patches + ticket
+    assert 0 < clean < need and clean == 4 * (16 + 2)                                   # 4x4 patches + ticket + overflow total
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 0, 1, N, N, 0, 0, N) == -2   # adaptive
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -3   # workspace
     assert lib.jdet_roi_align_backward_cl(7, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -1   # variant

@@ -204,6 +204,47 @@ def test_backward_cl_kept_workspace_contract(dev):
             assert int(ws_call[:clean].max()) == 0
 
 
+def test_backward_rows_past_the_direct_cap(dev):
+    """Patches whose entry count exceeds the direct rows' cap (csr_gather.h: at most 256 entries of a patch have a fixed
+    home; a tiny RoI puts up to 49 entries -- one per bin -- into one 2x2 patch): 80 near-identical 5-pixel RoIs on top of
+    random ones send several thousand entries through the overflow CSR.  Both entry points, the kept workspace handed
+    back clean, then a call WITHOUT overflow on the same kept workspace (the overflow total was reset)."""
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(11)
+    N, C, H, W, scale = 1, 16, 40, 48, 0.25
+    tiny = np.tile(np.array([[0, 61.0, 83.0, 5.0, 6.0, 0.3]], np.float32), (80, 1))
+    tiny[:, 1:3] += rng.uniform(-0.5, 0.5, size=(80, 2)).astype(np.float32)
+    other = I.rois_from_obbs(I.random_obbs(rng, 70, extent=W / scale, wh=(8.0, 120.0)), np.zeros(70))
+    rois = np.concatenate([tiny, other]).astype(np.float32)
+    R = rois.shape[0]
+    grad = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+    ref = O.roi_align_backward(O.V_ROT, grad, rois, (N, C, H, W), scale, 2)
+    tol = BWD_ATOL * max(1.0, np.abs(ref).max())
+    wsb = lib.jdet_roi_align_backward_workspace(O.V_ROT, R, N, C, H, W, 7, 7, 2)
+    g_nchw, r_dev = torch.from_numpy(grad).to(dev), torch.from_numpy(rois).to(dev)
+    scratch = torch.full((wsb,), 0x5A, dtype=torch.uint8, device=dev)
+    gin0 = torch.full((N, H, W, C), float("nan"), device=dev)
+    L.check(lib.jdet_roi_align_backward(O.V_ROT, L.ptr(g_nchw), L.ptr(r_dev), R, N, C, H, W, 7, 7, scale, 2, 1, None,
+                                        L.ptr(gin0), L.ptr(scratch), wsb, L.stream_ptr(gin0)), "bwd")
+    np.testing.assert_allclose(gin0.permute(0, 3, 1, 2).cpu().numpy(), ref, rtol=0, atol=tol)
+    clean = lib.jdet_roi_align_backward_clean_bytes(O.V_ROT, R, N, C, H, W, 7, 7, 2)
+    ws = torch.zeros((wsb,), dtype=torch.uint8, device=dev)
+    gin = torch.empty((N, H, W, C), device=dev)
+    for rr, gg, want in ((rois, grad, ref), (rois[80:], grad[80:], None), (rois, grad, ref)):
+        if want is None:
+            want = O.roi_align_backward(O.V_ROT, gg, rr, (N, C, H, W), scale, 2)
+        g_cl = torch.from_numpy(np.ascontiguousarray(gg.transpose(0, 2, 3, 1))).to(dev)
+        r = torch.from_numpy(np.ascontiguousarray(rr)).to(dev)
+        gin.fill_(float("nan"))
+        # (the workspace was sized for the larger R: a smaller call on a kept workspace is the FPN heads' normal case)
+        L.check(lib.jdet_roi_align_backward_cl(O.V_ROT, L.ptr(g_cl), L.ptr(r), rr.shape[0], N, C, H, W, 7, 7, scale, 2, 1,
+                                               L.ptr(gin), L.ptr(ws), wsb, 1, L.stream_ptr(gin)), "bwd_cl")
+        np.testing.assert_allclose(gin.permute(0, 3, 1, 2).cpu().numpy(), want, rtol=0,
+                                   atol=BWD_ATOL * max(1.0, np.abs(want).max()))
+        assert int(ws[:clean].max()) == 0
+
+
 def test_full_size_properties(dev):
     """north-star size (1024x1024 tile -> 256x256x256 map, 2000 RoIs): size-independent properties.
     (a) linearity in the feature map, (b) a constant map pools to the constant for RoIs whose samples
