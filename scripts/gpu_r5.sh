@@ -176,6 +176,27 @@ run_k() {   # backward with direct rows (csr_gather.h): parity, time, per-kernel
   cd $R
 }
 
+run_t() {   # traffic counters of the backward's four kernels (direct rows), one --pmc set per pass
+  OUT=$R/gpurun_out/r5_t; mkdir -p $OUT
+  for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+    n=$(echo $c | tr ' ' '_' | cut -c1-30)
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -o p -- python $R/bench.py --workload roi_align_rotated_bwd --no-cpu-baseline --no-secondary --steps 10 --warmup 3 > $OUT/pmc_$n.log 2>&1)
+  done
+  python - <<PY > $OUT/roi_align_bwd_counters.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        agg[row["Kernel_Name"][:70]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, cs in agg.items():
+    if "csr_" in k or "bwd_patch" in k:
+        for c, v in sorted(cs.items()):
+            print("%-70s %-22s mean %.6g over %d dispatches" % (k, c, sum(v) / len(v), len(v)))
+PY
+  cat $OUT/roi_align_bwd_counters.txt | cut -c1-150
+  rm -rf $OUT/pmc_*/
+}
+
 run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, the default bench line
   OUT=$R/gpurun_out/r5_z; mkdir -p $OUT
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -187,6 +208,6 @@ run_z() {   # closing validation of the final tree: smoke, the whole GPU suite, 
 
 run=${1:-}; [ $# -gt 0 ] && shift
 case "$run" in
-  a|b|c|d|e|f|g|h|i|j|k|z|final) run_$run "$@";;
+  a|b|c|d|e|f|g|h|i|j|k|t|z|final) run_$run "$@";;
   *) echo "usage: gpu_r5.sh {a|b|c|d|e|f|g|h|i|j|z|final} [args]"; exit 2;;
 esac
