@@ -122,7 +122,11 @@ int jdet_roi_spatial_order(const float* rois, int R, int roi_cols, float spatial
  * (roi, sample, tap) index space and executed as a sorted GATHER (integer atomics only, one store per
  * pixel); with workspace = NULL, or when the query returns 0 (RiRoIAlign, sample_num <= 0, C % 4 != 0),
  * it is the reference's scheme: zero-fill + hardware fp32 atomics.  Either way the last bits depend on
- * accumulation order, as in the reference. */
+ * accumulation order, as in the reference.
+ * Workspace size: counters and offsets of the 2x2 pixel patches, two record arrays of R * PH * PW * samples * 4 x 32
+ * bytes, the (R, PH*PW, C) transposed gradient, and the patches' direct rows (at most 256 MiB; csr_gather.h) -- 268 MB
+ * at 2000 RoIs on a 256 x 256 x 256 map.  The size grows monotonically with R, so a buffer sized for the largest R of a
+ * map serves every smaller call on it. */
 size_t jdet_roi_align_backward_workspace(int variant, int R, int N, int C, int H, int W, int PH, int PW,
                                          int sample_num);
 int jdet_roi_align_backward(int variant, const float* grad_out, const float* rois, int R, int N,
