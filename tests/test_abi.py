@@ -184,6 +184,9 @@ def test_argument_validation_returns_before_any_launch(built_lib):
     need = lib.jdet_roi_align_backward_workspace(0, 10, 1, 8, 8, 8, 7, 7, 2)
     clean = lib.jdet_roi_align_backward_clean_bytes(0, 10, 1, 8, 8, 8, 7, 7, 2)
     assert 0 < clean < need and clean == 4 * (16 + 2)                                   # 4x4 patches + ticket + overflow total
+    # the workspace grows with R (the header's promise: a buffer sized for the largest R of a map serves smaller calls)
+    sizes = [lib.jdet_roi_align_backward_workspace(0, r, 2, 256, 128, 128, 7, 7, 2) for r in (1, 7, 64, 500, 512, 2000, 5000)]
+    assert all(b >= a_ > 0 for a_, b in zip(sizes, sizes[1:]))
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 0, 1, N, N, 0, 0, N) == -2   # adaptive
     assert lib.jdet_roi_align_backward_cl(0, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -3   # workspace
     assert lib.jdet_roi_align_backward_cl(7, N, N, 10, 1, 8, 8, 8, 7, 7, 1.0, 2, 1, N, N, 0, 0, N) == -1   # variant
