@@ -63,6 +63,14 @@ int jdet_debug_gather_width_probe(const float* buf, long total_rows, int window_
 int jdet_debug_gather_accumulate_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave,
                                        int pairs, int n_blocks, float* out, jdet_stream_t stream);
 
+/* Calibration probe (scripts/dma_probe.py; csrc/experimental/dma_probe.hip), round 6: the gathers of jdet_debug_gather_probe
+ * as LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction into a per-wave LDS ring of `unroll` KiB).
+ * seg = 1: one 1 KiB map row per instruction; 4 / 8: four 256-byte / eight 128-byte pieces of as many rows (a channel
+ * slice of several pixels per instruction, per-lane source addresses).  read != 0: every landed KiB is read back with
+ * one ds_read_b128 per lane.  unroll 4 / 8 / 16 with seg 1 / 4, 8 / 16 with seg 8; window_rows * 1024 < 2 GiB. */
+int jdet_debug_dma_probe(const float* buf, long total_rows, int window_rows, int rows_per_wave, int local_windows,
+                         int n_blocks, int unroll, int seg, int read, float* sink, jdet_stream_t stream);
+
 /* Calibration probe (scripts/mfma_probe.py; csrc/experimental/mfma_probe.hip): shader cycles per wave of `steps` K steps
  * of 32 v_mfma_f32_32x32x2_f32 with the pieces of the conv_wgrad.hip loop added one at a time (variant 0 bare MFMAs, 1 +
  * LDS fragment fetches, 2 + LDS tile writes and the barrier, 3 + buffer loads).  cycles: n_blocks * 4 values. */

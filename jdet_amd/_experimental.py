@@ -18,6 +18,7 @@ SIGNATURES = {
     "jdet_debug_gather_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_gather_width_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_gather_accumulate_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
+    "jdet_debug_dma_probe": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "jdet_debug_mfma_probe": (_i, [_i, _p, _i, _i, _p, _p, _p]),
 }
 

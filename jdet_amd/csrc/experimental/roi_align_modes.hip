@@ -20,7 +20,7 @@ JDET_API int jdet_roi_align_forward_cl_mode(int mode, int variant, const float* 
                                             const float* rois, int R, int PH, int PW, float spatial_scale,
                                             int sample_num, int n_orient, const int32_t* order, float* out_cl,
                                             void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
-  if (mode != kFwdSliced && mode != kFwdLine) return JDET_E_BADARG;
+  if (mode != kFwdSliced && mode != kFwdLine && mode != kFwdStaged) return JDET_E_BADARG;
   int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, n_orient);
   if (e) return e;
   if (C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;
@@ -46,17 +46,18 @@ JDET_API int jdet_roi_align_forward_cl_mode(int mode, int variant, const float* 
     }
   }
   // mode 3: the RoI-stationary launch with the line kernel where it applies (`order`: a schedule of
-  // jdet_roi_spatial_order, or NULL)
+  // jdet_roi_spatial_order, or NULL); mode 4: the footprint-staged kernel (roi_align_stage.h), same launch shape
+  const int lm = mode;
   switch (variant) {
     case JDET_ROI_ROTATED:
-      return launch_fwd<JDET_ROI_ROTATED>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, kFwdLine);
+      return launch_fwd<JDET_ROI_ROTATED>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, lm);
     case JDET_ROI_ROTATED_V1:
-      return launch_fwd<JDET_ROI_ROTATED_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, kFwdLine);
+      return launch_fwd<JDET_ROI_ROTATED_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, lm);
     case JDET_ROI_RIROI:
-      return launch_fwd<JDET_ROI_RIROI>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, n_orient, order, st, true, kFwdLine);
+      return launch_fwd<JDET_ROI_RIROI>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, n_orient, order, st, true, lm);
     case JDET_ROI_HBB_V0:
-      return launch_fwd<JDET_ROI_HBB_V0>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, kFwdLine);
+      return launch_fwd<JDET_ROI_HBB_V0>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, lm);
     default:
-      return launch_fwd<JDET_ROI_HBB_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, kFwdLine);
+      return launch_fwd<JDET_ROI_HBB_V1>(feat, rois, out_cl, R, C, H, W, PH, PW, spatial_scale, sample_num, 1, order, st, true, lm);
   }
 }
