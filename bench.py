@@ -112,12 +112,12 @@ def make_step(workload, d):
             return (step, nbytes / 1e9, "GB", nbytes,
                     "EXPERIMENTAL roi_order_kernel + roi_plan_kernel<ROTATED> + roi_pool_kernel (channels-last output)",
                     "f32")
-        if path in ("sliced", "line"):
+        if path in ("sliced", "line", "staged"):
             # EXPERIMENTAL (libjdet_experimental.so, not product paths): the channel-sliced plan + pool kernels / the
             # line-deduplicating kernel of round 4 (profiles/r04_roi_fwd_notes.md)
             from jdet_amd import _experimental as X
             xl = X.lib()
-            mode = 2 if path == "sliced" else 3
+            mode = {"sliced": 2, "line": 3, "staged": 4}[path]   # staged: round 6, csrc/roi_align_stage.h (LDS-DMA)
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()
             wsb = xl.jdet_roi_align_forward_cl_mode_workspace(mode, R, 7, 7)
@@ -133,14 +133,15 @@ def make_step(workload, d):
 
             def step():
                 st = L.stream_ptr(feat)
-                if mode == 3:
+                if mode >= 3:
                     L.check(lib.jdet_roi_spatial_order(rp, R, 6, 0.25, 1, 256, 256, o0, o1, st), "order")
                 L.check(xl.jdet_roi_align_forward_cl_mode(mode, 0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1,
-                                                          o0 if mode == 3 else None, op, wp, wsb, st), "fwd_cl_mode")
+                                                          o0 if mode >= 3 else None, op, wp, wsb, st), "fwd_cl_mode")
             d["out"] = out
             return (step, nbytes / 1e9, "GB", nbytes,
                     "EXPERIMENTAL roi_sort_plan_kernel<ROTATED> + roi_pool_sliced_kernel (channels-last out)" if mode == 2
-                    else "EXPERIMENTAL roi_order_kernel + roi_align_fwd_line_kernel<ROTATED> (channels-last out)", "f32")
+                    else "EXPERIMENTAL roi_order_kernel + roi_align_fwd_line_kernel<ROTATED> (channels-last out)" if mode == 3
+                    else "EXPERIMENTAL roi_order_kernel + roi_align_fwd_staged_kernel<ROTATED> (LDS-DMA, channels-last out)", "f32")
         if path == "roi_cl":   # default product path: jdet_roi_align_forward_cl = XCD-aware schedule + RoI-stationary kernel
             out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
             op = out.data_ptr()

@@ -35,6 +35,7 @@ using namespace jdet_roi;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int kMaxLines = 8;       // PH, PW <= 8
@@ -67,14 +68,67 @@ __device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b) {
   return __builtin_bit_cast(unsigned, r);
 }
 
-template <int VARIANT, int CPP>
+// DPP lane exchanges (no LDS crossbar round trip): quad_perm xor 1 / xor 2, rotations inside a row of 16 lanes
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+// all-lanes reduction over aligned groups of 32 lanes of a min / max style (idempotent) operator
+template <typename OP>
+__device__ __forceinline__ unsigned reduce32(unsigned v, OP op) {
+  v = op(v, dpp<0xB1>(v));      // quad_perm [1,0,3,2]
+  v = op(v, dpp<0x4E>(v));      // quad_perm [2,3,0,1]
+  v = op(v, dpp<0x124>(v));     // row_ror:4
+  v = op(v, dpp<0x128>(v));     // row_ror:8
+  return op(v, (unsigned)__shfl_xor((int)v, 16, 64));
+}
+// inclusive prefix sum over aligned groups of 32 lanes
+__device__ __forceinline__ int scan32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  return v;
+}
+
+// One LDS-DMA instruction: 64 lanes x 16 bytes from (descriptor, per-lane byte offset + scalar offset) to LDS bytes
+// [lds_dst, lds_dst + 1024).  Inline assembly on purpose: with the builtin, hipcc (ROCm 7.2) orders EVERY later ds_read
+// of the same LDS object behind the DMA with s_waitcnt vmcnt(0), which serialises the fetch of the next step with the
+// compute of the current one; here the kernel counts its own vmcnt.  M0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void dma16(v4i rs, unsigned lds_dst, int voff, int soff) {
+  unsigned keep;
+  asm volatile(
+      "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
+      : "memory");
+}
+
+// s_waitcnt vmcnt(n), n wave-uniform: all but the n youngest vector-memory operations of this wave have completed
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+    case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+    case 1: __builtin_amdgcn_s_waitcnt(0x0f71); break;
+    case 2: __builtin_amdgcn_s_waitcnt(0x0f72); break;
+    case 3: __builtin_amdgcn_s_waitcnt(0x0f73); break;
+    case 4: __builtin_amdgcn_s_waitcnt(0x0f74); break;
+    case 5: __builtin_amdgcn_s_waitcnt(0x0f75); break;
+    case 6: __builtin_amdgcn_s_waitcnt(0x0f76); break;
+    default: __builtin_amdgcn_s_waitcnt(0x0f77); break;   // (more than 7 younger operations: waits for a few of them too)
+  }
+}
+
+// P7: PH == PW == 7 known at compile time (the configuration of every reference config: divisions by constants)
+template <int VARIANT, int CPP, int P7>
 __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
-    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int C, int H, int W, int PH,
-    int PW, float spatial_scale, const int32_t* __restrict__ order) {
+    const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out, int C, int H, int W, int PH_,
+    int PW_, float spatial_scale, const int32_t* __restrict__ order, int abl) {
   using L = Layout<CPP>;
   constexpr int LPB = CPP / 4;         // lanes per slot (DMA) / per bin (compute)
   constexpr int NBW = 64 / LPB;        // slots per DMA instruction, bins per wave step
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object (a second one de-pipelines LDS-DMA)
+  const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY LDS object
   v4f* rec_w = reinterpret_cast<v4f*>(smem + L::kRecW);
   uint2* rec_a = reinterpret_cast<uint2*>(smem + L::kRecA);
   int* slotpix = reinterpret_cast<int*>(smem + L::kSlotPix);
@@ -83,6 +137,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
   float* s_trig = reinterpret_cast<float*>(s_P + 10);
   int4* s_gtab = reinterpret_cast<int4*>(smem + L::kMisc + 64);   // [8] {first line, lines, first flat slot, slots}
   uint2* bm = reinterpret_cast<uint2*>(smem);                    // [8][kLineWords] {bits, prefix}: overlays the buffers
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of smem
 
   const int r = order ? order[blockIdx.x] : blockIdx.x;
   const int nbins = PH * PW;
@@ -92,27 +147,43 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
   constexpr bool kRot = ROI_COLS == 6;
   const float* roi = rois + (size_t)r * ROI_COLS;
   if (kRot && threadIdx.x == 0) {
-    s_trig[0] = (float)cos((double)roi[5]);
-    s_trig[1] = (float)sin((double)roi[5]);
+    if (abl & 32) {   // (profiling: single-precision trig)
+      s_trig[0] = cosf(roi[5]);
+      s_trig[1] = sinf(roi[5]);
+    } else {
+      s_trig[0] = (float)cos((double)roi[5]);
+      s_trig[1] = (float)sin((double)roi[5]);
+    }
   }
+  long long t0 = 0, t1 = 0, t2 = 0;
+  if (abl & 16) t0 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) *s_flag = 0;
   __amdgpu_buffer_rsrc_t rsrc;
   RoiGeom g = vec_prologue<VARIANT, false>(feat, rois, r, C, H, W, PH, PW, spatial_scale, 2, rsrc);
   if (g.batch < 0) return;
+  v4i rs;   // the same descriptor as four SGPRs for the DMA statement
+  {
+    const unsigned long long img_bits = (unsigned long long)(feat + (size_t)g.batch * H * W * C);
+    rs.x = __builtin_amdgcn_readfirstlane((int)(unsigned)img_bits);
+    rs.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(img_bits >> 32) & 0xffffu));
+    rs.z = __builtin_amdgcn_readfirstlane((int)((size_t)H * W * C * 4));
+    rs.w = 0x00020000;
+  }
   __syncthreads();
   if (kRot) {
     g.cosT = s_trig[0];
     g.sinT = s_trig[1];
   }
 
+  if (abl & 16) t1 = __builtin_readcyclecounter();
   // ---- prologue: lane = sample --------------------------------------------------------------------------------------
   // lines along the denser sample direction: bin rows (d == 0: PH lines of PW bins) when bin_w <= bin_h
   const int d = __builtin_amdgcn_readfirstlane(g.bin_w <= g.bin_h ? 0 : 1);
-  const int NL = d == 0 ? PH : PW, NBL = d == 0 ? PW : PH;
+  const int NL = P7 ? 7 : (d == 0 ? PH : PW), NBL = P7 ? 7 : (d == 0 ? PW : PH);
   const int SW = 2 * PW;                                   // samples per sample row
   const int ln = threadIdx.x >> 5, j = threadIdx.x & 31;   // my line, my sample within it
   const bool s_ok = ln < NL && j < 4 * NBL;
-  const int u = s_ok ? j % (2 * NBL) : 0, v = s_ok ? j / (2 * NBL) : 0;
+  const int v = s_ok && j >= 2 * NBL ? 1 : 0, u = s_ok ? j - v * 2 * NBL : 0;
   const int iy = d == 0 ? 2 * (s_ok ? ln : 0) + v : u;
   const int ix = d == 0 ? u : 2 * (s_ok ? ln : 0) + v;
   const int sid = iy * SW + ix;                            // natural sample id
@@ -124,15 +195,10 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
   v4f wq = {hy * hx * inv_count, hy * p.lx * inv_count, p.ly * hx * inv_count, p.ly * p.lx * inv_count};
   if (!live) wq = v4f{0.f, 0.f, 0.f, 0.f};
 
-  // bounding box of the line's taps: (x, y) packed as two u16, min / max butterflies over the line's 32 lanes
-  unsigned mn = live ? pk16(p.x_low, p.y_low) : 0xffffffffu;
-  unsigned mx = live ? pk16(p.x_high, p.y_high) : 0u;
-#pragma unroll
-  for (int m = 1; m < 32; m <<= 1) {
-    mn = pk_min(mn, (unsigned)__shfl_xor((int)mn, m, 64));
-    mx = pk_max(mx, (unsigned)__shfl_xor((int)mx, m, 64));
-  }
-  const bool line_live = mx >= mn && (mx >> 16) >= (mn >> 16) && (mx & 0xffff) >= (mn & 0xffff) && mn != 0xffffffffu;
+  // bounding box of the line's taps: (x, y) packed as two u16, min / max over the line's 32 lanes
+  const unsigned mn = reduce32(live ? pk16(p.x_low, p.y_low) : 0xffffffffu, [](unsigned a, unsigned b) { return pk_min(a, b); });
+  const unsigned mx = reduce32(live ? pk16(p.x_high, p.y_high) : 0u, [](unsigned a, unsigned b) { return pk_max(a, b); });
+  const bool line_live = mn != 0xffffffffu;
   const int x0 = mn & 0xffff, y0 = mn >> 16;
   const int wbits = line_live ? (int)(mx & 0xffff) - x0 + 1 : 0;
   const int rows = line_live ? (int)(mx >> 16) - y0 + 1 : 0;
@@ -174,12 +240,7 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
       bits[k] = wd < nwords ? mybm[wd].x : 0u;
       tot += __builtin_popcount(bits[k]);
     }
-    int incl = tot;
-#pragma unroll
-    for (int m = 1; m < 32; m <<= 1) {
-      const int t = __shfl_up(incl, m, 32);
-      if (j >= m) incl += t;
-    }
+    const int incl = scan32(tot);
     int run = incl - tot;
 #pragma unroll
     for (int k = 0; k < kWordsPerLane; k++) {
@@ -187,28 +248,32 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
       if (wd < nwords) mybm[wd].y = (unsigned)run;
       run += __builtin_popcount(bits[k]);
     }
-    if (j == 31 && ln < kMaxLines) s_P[ln] = ln < NL ? max(incl, 1) : 0;   // an empty line keeps one dummy slot
+    if (j == 31) s_P[ln] = ln < NL ? max(incl, 1) : 0;   // an empty line keeps one dummy slot
   }
   __syncthreads();                                                                   // (C)
   // groups of consecutive lines with at most kCap slots; my line's first flat slot and its base inside its group
   int my_flat = 0, my_gbase = 0, ngroups = 0;
   {
+    const int4 pa = *reinterpret_cast<const int4*>(s_P), pb = *reinterpret_cast<const int4*>(s_P + 4);
+    const int pl[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
     int acc = 0, flat = 0, g0 = 0, gflat = 0, gi = 0;
-    for (int l2 = 0; l2 < NL; l2++) {
-      const int pl = s_P[l2];
-      if (acc + pl > kCap) {
-        if (threadIdx.x == 0) s_gtab[gi] = make_int4(g0, l2 - g0, gflat, acc);
-        gi++;
-        g0 = l2;
-        gflat = flat;
-        acc = 0;
+#pragma unroll
+    for (int l2 = 0; l2 < kMaxLines; l2++) {
+      if (l2 < NL) {
+        if (acc + pl[l2] > kCap) {
+          if (threadIdx.x == 0) s_gtab[gi] = make_int4(g0, l2 - g0, gflat, acc);
+          gi++;
+          g0 = l2;
+          gflat = flat;
+          acc = 0;
+        }
+        if (l2 == ln) {
+          my_flat = flat;
+          my_gbase = acc;
+        }
+        acc += pl[l2];
+        flat += pl[l2];
       }
-      if (l2 == ln) {
-        my_flat = flat;
-        my_gbase = acc;
-      }
-      acc += pl;
-      flat += pl;
     }
     if (threadIdx.x == 0) s_gtab[gi] = make_int4(g0, NL - g0, gflat, acc);
     ngroups = __builtin_amdgcn_readfirstlane(gi + 1);
@@ -238,6 +303,8 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
   }
   __syncthreads();                                                                   // (D)
 
+  if (abl & 16) t2 = __builtin_readcyclecounter();
+  if (abl & 1) return;   // (profiling: prologue only)
   // ---- main loop over (group, channel pass), double buffered -------------------------------------------------------
   const int npass = C / CPP;
   const int nsteps = ngroups * npass;
@@ -255,45 +322,49 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
       poff[i] = sl < f_nslots ? slotpix[gflat + sl] + chl * 16 : -1;
     }
   };
-  auto issue = [&](int step) {      // DMA of step -> buffer step & 1
-    const int pass = step % npass;
+  auto issue = [&](int buf, int pass) {      // DMA of the group in poff[], channel pass `pass` -> buffer buf
+    if (abl & 2) return;
     const int soff = __builtin_amdgcn_readfirstlane(pass * L::kRowB);
-    char* dst = smem + (step & 1) * L::kBufB;
+    const unsigned dst = lds0 + buf * L::kBufB;
 #pragma unroll
     for (int i = 0; i < kMaxDma; i++) {
       const int first = (wave + 4 * i) * NBW;            // wave-uniform
       if (first < f_nslots) {
-        // (a local copy: with `poff[i]` itself as the builtin's argument the HOST pass of hipcc / ROCm 7.2 drops the
-        //  whole kernel instantiation without a message and the launcher is left with an undefined handle)
         const int vo = poff[i];
-        if (vo >= 0)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + first * L::kRowB), 16, vo, soff, 0, 0);
+        if (vo >= 0) dma16(rs, __builtin_amdgcn_readfirstlane(dst + first * L::kRowB), vo, soff);
       }
     }
   };
   load_group_offsets(0);
-  issue(0);
+  issue(0, 0);
   float* __restrict__ out_r = out + (size_t)r * nbins * C;
   int c_l0 = 0, c_nl = 0;                                 // lines of the group being computed
+  int gi = 0, pass = 0;                                   // group / pass of the step being computed
+  int younger = 0;                                        // my stores issued after the DMA of the step about to be computed
   for (int step = 0; step < nsteps; step++) {
-    const int gi = step / npass, pass = step % npass;
-    __builtin_amdgcn_s_waitcnt(0x0f70);                   // my DMA of this step has landed (and my earlier stores)
-    __syncthreads();                                      // everyone's has; everyone is done with the other buffer
+    wait_vmcnt(younger);                                  // my DMA of this step has landed
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();                         // everyone's has; everyone is done with the other buffer
     if (pass == 0) {
       const int4 gt = s_gtab[gi];
       c_l0 = __builtin_amdgcn_readfirstlane(gt.x);
       c_nl = __builtin_amdgcn_readfirstlane(gt.y);
     }
     if (step + 1 < nsteps) {
-      if (pass + 1 == npass) load_group_offsets(gi + 1);
-      issue(step + 1);
+      if (pass + 1 == npass) {
+        load_group_offsets(gi + 1);
+        issue((step + 1) & 1, 0);
+      } else {
+        issue((step + 1) & 1, pass + 1);
+      }
     }
+    younger = 0;
     const char* buf = smem + (step & 1) * L::kBufB + chl * 16;
-    const int nbg = c_nl * NBL;                           // bins of this group
+    const int nbg = (abl & 4) ? 0 : c_nl * NBL;           // bins of this group
     for (int k = wave; k * NBW < nbg; k += 4) {
       const int bi = k * NBW + sub;
       const bool b_ok = bi < nbg;
-      const int bl = b_ok ? bi / NBL : 0, bp = b_ok ? bi % NBL : 0;
+      const int bl = b_ok ? bi / NBL : 0, bp = b_ok ? bi - bl * NBL : 0;
       const int ph = d == 0 ? c_l0 + bl : bp, pw = d == 0 ? bp : c_l0 + bl;
       const int s00 = (2 * ph) * SW + 2 * pw;
       v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -317,10 +388,22 @@ __global__ __launch_bounds__(kThreads) void roi_align_fwd_staged_kernel(
         JDET_STAGE_FMA(t3, w.w)
 #undef JDET_STAGE_FMA
       }
-      if (b_ok)
-        __builtin_nontemporal_store(
-            acc, reinterpret_cast<v4f*>(out_r + (size_t)(ph * PW + pw) * C + pass * CPP + chl * 4));
+      if (!(abl & 8)) {
+        if (b_ok)
+          __builtin_nontemporal_store(
+              acc, reinterpret_cast<v4f*>(out_r + (size_t)(ph * PW + pw) * C + pass * CPP + chl * 4));
+        younger++;
+      }
     }
+    if (++pass == npass) {
+      pass = 0;
+      gi++;
+    }
+  }
+  if ((abl & 16) && threadIdx.x == 0) {   // (profiling: shader-clock stamps of the phases + step count, over the RoI's first row)
+    long long* dbg = reinterpret_cast<long long*>(out_r);
+    dbg[0] = t0; dbg[1] = t1; dbg[2] = t2; dbg[3] = __builtin_readcyclecounter(); dbg[4] = nsteps;
+    dbg[5] = blockIdx.x;
   }
 }
 

@@ -133,5 +133,31 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "parity"
     if what == "parity":
         parity()
+    elif what == "stamps":
+        pass
     else:
         time(int(sys.argv[2]) if len(sys.argv) > 2 else 200)
+
+
+def stamps():
+    """JDET_ROI_STAGE_ABL=16 (+ other bits): per-workgroup shader-clock stamps -> mean phase durations"""
+    feat, rois = north_star()
+    R = rois.shape[0]
+    obuf = torch.empty((2, R), dtype=torch.int32, device=dev)
+    L.check(lib.jdet_roi_spatial_order(rois.data_ptr(), R, 6, 0.25, 1, 256, 256, obuf[0].data_ptr(), obuf[1].data_ptr(),
+                                       L.stream_ptr(feat)), "order")
+    for _ in range(3):
+        a = staged(0, feat, rois, (7, 7), 0.25, obuf[0])
+    torch.cuda.synchronize()
+    raw = a.permute(0, 2, 3, 1).contiguous().view(R, -1)[:, :12].contiguous().view(torch.int64).cpu().numpy()  # (R, 6)
+    t0, t1, t2, t3, steps, blk = raw.T
+    print("workgroups %d  mean steps %.1f" % (R, steps.mean()))
+    print("trig+geom %.0f  prologue %.0f  main loop %.0f  (shader clocks, mean per workgroup); per step %.0f" %
+          ((t1 - t0).mean(), (t2 - t1).mean(), (t3 - t2).mean(), ((t3 - t2) / np.maximum(steps, 1)).mean()))
+    span = t3.max() - t0.min()
+    print("kernel span %.0f clocks; sum of workgroup lifetimes / span = %.1f resident workgroups on average (/256 CUs = %.2f per CU)"
+          % (span, (t3 - t0).sum() / span, (t3 - t0).sum() / span / 256))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps":
+    stamps()
