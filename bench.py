@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--amp", default="none", choices=["none", "bf16", "fp16"])
     p.add_argument("--rois", type=int, default=2000)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-live-traffic", action="store_true",
+                   help="roofline.traffic from profiles/hbm_traffic.json instead of two rocprofv3 --pmc passes run now")
     p.add_argument("--no-secondary", action="store_true",
                    help="leave out the `secondary` object (ms/step of the other BASELINE.json model configs)")
     a = p.parse_args()
@@ -67,7 +69,7 @@ def make_inputs(workload, R, seed, dev):
         rois = I.rois_from_obbs(I.random_obbs(rng, R), np.zeros(R))
         d["rois_np"] = rois
         d["rois"] = torch.from_numpy(rois).to(dev)
-        d["grad"] = torch.randn((R, 256, 7, 7), device=dev) if workload.endswith("bwd") else None
+        d["grad"] = torch.randn((R, 256, 7, 7), device=dev) if ("bwd" in workload or workload.endswith("pair")) else None
         d["feat_cpu"] = feat
     elif workload == "box_iou_rotated":
         b1, b2 = I.random_obbs(rng, 64, wh=(16.0, 256.0)), I.random_obbs(rng, 21824)
@@ -212,6 +214,47 @@ def make_step(workload, d):
                                                     wp, wsb, L.stream_ptr(feat)), "bwd")
         nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
         return step, nbytes / 1e9, "GB", nbytes, "roi_align backward (taps+scan+fill%s+gather | atomic)" % ("" if cl else "+zero+transpose"), "f32"
+    if workload in ("roi_align_rotated_bwd_planned", "roi_align_rotated_pair"):
+        # round 6: the backward's plan (jdet_roi_align_backward_plan: the inversion of the scatter) is built ONCE per RoI
+        # set -- at the forward in training -- and the backward is the gather alone (jdet_roi_align_backward_cl_planned).
+        #   ..._bwd_planned : a step = the gather from a kept plan (the plan's build is outside the timed region)
+        #   ..._pair        : a step = what one training step does with one RoI set: schedule + forward kernel, the plan
+        #                     built beside it on a second stream, then the gather
+        feat, rois = d["feat"], d["rois"]
+        R = rois.shape[0]
+        grad = d["grad"].contiguous(memory_format=torch.channels_last)
+        gin = torch.empty_like(feat)
+        out = torch.empty((R, 256, 7, 7), device=feat.device, memory_format=torch.channels_last)
+        pb = lib.jdet_roi_align_backward_plan_bytes(0, R, 1, 256, 256, 7, 7, 2)
+        plan = torch.empty((pb,), dtype=torch.uint8, device=feat.device)
+        wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=feat.device)
+        fp, rp, gp, ip, op, pp, wp = (feat.data_ptr(), rois.data_ptr(), grad.data_ptr(), gin.data_ptr(), out.data_ptr(),
+                                      plan.data_ptr(), ws.data_ptr())
+        nbytes = 4 * 256 * 256 * 256 + 4 * R * 256 * 49 + 24 * R
+        L.check(lib.jdet_roi_align_backward_plan(0, rp, R, 1, 256, 256, 7, 7, 0.25, 2, pp, pb, L.stream_ptr(feat)), "plan")
+        if workload == "roi_align_rotated_bwd_planned":
+            def step():
+                L.check(lib.jdet_roi_align_backward_cl_planned(0, gp, R, 1, 256, 256, 256, 7, 7, 2, ip, pp, pb,
+                                                               L.stream_ptr(feat)), "bwd_planned")
+            return step, nbytes / 1e9, "GB", nbytes, "csr_gather_patch_kernel<8, keep plan> (plan kept from the forward)", "f32"
+        side = torch.cuda.Stream(feat.device)
+        ev_fork, ev_join = torch.cuda.Event(), torch.cuda.Event()
+
+        def step():
+            cur = torch.cuda.current_stream(feat.device)
+            ev_fork.record(cur)
+            side.wait_event(ev_fork)
+            L.check(lib.jdet_roi_align_backward_plan(0, rp, R, 1, 256, 256, 7, 7, 0.25, 2, pp, pb, side.cuda_stream), "plan")
+            ev_join.record(side)
+            L.check(lib.jdet_roi_align_forward_cl(0, fp, 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op, wp, wsb,
+                                                  cur.cuda_stream), "fwd_cl")
+            cur.wait_event(ev_join)
+            L.check(lib.jdet_roi_align_backward_cl_planned(0, gp, R, 1, 256, 256, 256, 7, 7, 2, ip, pp, pb,
+                                                           cur.cuda_stream), "bwd_planned")
+        d["out"] = out
+        return (step, 2 * nbytes / 1e9, "GB", 2 * nbytes,
+                "forward (roi_order + roi_align_fwd_merged) || plan (bwd_patch_taps + scan + fill), then csr_gather_patch", "f32")
     if workload == "box_iou_rotated":
         from jdet_amd.ops import box_iou_rotated
         b1, b2 = d["b1"], d["b2"]
@@ -451,6 +494,123 @@ def roofline_obj(workload, nbytes, dev_ms, kname, dev=None):
     return out
 
 
+def cold_forward_ms(dev, R, steps=60, warmup=6, n_maps=6):
+    """The forward of the roofline leg with the map EVICTED between launches: `n_maps` distinct 67 MB maps (402 MB, more
+    than the 256 MB Infinity Cache) visited round-robin, so every launch reads its map from HBM; same RoIs, same output
+    buffer.  -> (ms per launch, what was done)"""
+    from jdet_amd import _lib as L
+    lib = L.lib()
+    d = make_inputs("roi_align_rotated", R, 1000, dev)
+    rois = d["rois"]
+    maps = [d["feat"]] + [torch.randn((1, 256, 256, 256), device=dev).contiguous(memory_format=torch.channels_last)
+                          for _ in range(n_maps - 1)]
+    out = torch.empty((R, 256, 7, 7), device=dev, memory_format=torch.channels_last)
+    wsb = lib.jdet_roi_align_forward_cl_workspace(R, 7, 7)
+    ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    ptrs = [m.data_ptr() for m in maps]
+    rp, op, wp = rois.data_ptr(), out.data_ptr(), ws.data_ptr()
+    st = L.stream_ptr(rois)
+    i = [0]
+
+    def step():
+        L.check(lib.jdet_roi_align_forward_cl(0, ptrs[i[0] % n_maps], 1, 256, 256, 256, rp, R, 7, 7, 0.25, 2, 1, op, wp,
+                                              wsb, st), "fwd_cl")
+        i[0] += 1
+    _, ms = timed(step, steps, warmup, None, dev)
+    del maps
+    return ms, ("%d distinct 67 MB maps round-robin (%.0f MB > the 256 MB Infinity Cache): every launch reads its map from "
+                "HBM; %d launches between HIP events" % (n_maps, n_maps * 67.1, steps))
+
+
+def live_traffic(timeout_s=240):
+    """HBM-side bytes per launch of the roofline kernel from two rocprofv3 --pmc passes of this file's roi_align_rotated
+    workload, run NOW in subprocesses (FETCH_SIZE and WRITE_SIZE need separate passes; FETCH_SIZE counts 128-byte requests
+    at 64 bytes on gfx950: doubled, MI355X_MICROARCH.md).  -> (bytes | None, how)"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="jdet_pmc_")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            outd = os.path.join(tmp, c)
+            cmd = [exe, "--pmc", c, "-f", "csv", "-d", outd, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--workload", "roi_align_rotated", "--no-cpu-baseline", "--no-live-traffic", "--steps", "5", "--warmup", "2"]
+            env = dict(os.environ, TMPDIR=tmp)
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            got = []
+            for f in glob.glob(os.path.join(outd, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "roi_align_fwd_merged_kernel" in row["Kernel_Name"] and row["Counter_Name"] == c:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "rocprofv3 --pmc %s gave no rows (exit %d)" % (c, r.returncode)
+            vals[c] = sum(got) / len(got)
+        traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        return traffic, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, run by this bench in "
+                         "subprocesses), FETCH_SIZE %.0f KB x 2 (gfx950: 128-byte requests counted at 64) + WRITE_SIZE %.0f KB, "
+                         "means over the forward kernel's dispatches; the loop re-reads one 67 MB map that stays in the 256 MB "
+                         "Infinity Cache: the reads are fabric / MALL reads, an upper bound of the HBM reads"
+                         % (vals["FETCH_SIZE"], vals["WRITE_SIZE"]))
+    except Exception as e:      # noqa: BLE001 -- reported in the line
+        return None, "live counter passes failed: %s: %s" % (type(e).__name__, str(e)[:160])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_extras(a, dev, line, live):
+    """the rest of the roofline leg: cold-map forward, live traffic, the planned backward and the forward + backward pair,
+    and the reference's true CPU sources (rotated IoU, rotated NMS: kind "reference") beside their device kernels"""
+    rf = line["roofline"]
+    try:
+        ms, how = cold_forward_ms(dev, a.rois)
+        rf["kernel_ms_cold"] = ms
+        rf["achieved_cold"] = rf["algorithmic_bytes"] / 1e9 / (ms / 1e3)
+        rf["frac_cold"] = rf["achieved_cold"] / HBM_PEAK_GBPS
+        if rf.get("peak_measured"):
+            rf["frac_of_measured_cold"] = rf["achieved_cold"] / rf["peak_measured"]
+        rf["cold_how"] = how
+    except Exception as e:      # noqa: BLE001
+        rf["cold_how"] = "failed: %s: %s" % (type(e).__name__, str(e)[:160])
+    if live:
+        t, how = live_traffic()
+        if t is not None:
+            rf["traffic"], rf["traffic_source"] = t, how
+        else:
+            rf["traffic_source"] = "%s; fallback: %s" % (how, rf.get("traffic_source"))
+    also = {}
+    for wl, steps in (("roi_align_rotated_bwd", 100), ("roi_align_rotated_bwd_planned", 100), ("roi_align_rotated_pair", 100)):
+        try:
+            d = make_inputs(wl, a.rois, 1000, dev)
+            step, _, _, nbytes, kname, _ = make_step(wl, d)
+            _, ms = timed(step, steps, 10, None, dev)
+            also[wl] = {"kernel_ms": ms, "algorithmic_bytes": nbytes, "achieved": nbytes / 1e9 / (ms / 1e3),
+                        "frac": nbytes / 1e9 / (ms / 1e3) / HBM_PEAK_GBPS, "kernel": kname}
+            del step, d
+        except Exception as e:      # noqa: BLE001
+            also[wl] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+    rf["also"] = also
+    if not a.no_cpu_baseline:
+        ref = {}
+        for wl, R, steps in (("box_iou_rotated", a.rois, 50), ("nms_rotated", 2000, 30)):
+            try:
+                d = make_inputs(wl, R, 1000, dev)
+                step, units, unit_name, _, kname, _ = make_step(wl, d)
+                t, _ = timed(step, steps, 5, None, dev)
+                cb = cpu_baseline(wl, d, R)
+                cb["device"] = {"value": units * steps / t, "unit": unit_name + "/s", "kernel": kname}
+                ref[wl] = cb
+                del step, d
+            except Exception as e:      # noqa: BLE001
+                ref[wl] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
+        line["cpu_baseline_reference"] = ref
+
+
 def secondary_lines(a, dev):
     """ms/step of the other model configurations of BASELINE.json -- configs[1] RetinaNet-OBB inference, configs[3]
     Oriented R-CNN train step, configs[4] RoI-Transformer R101 train step (4 images) -- 10 timed steps each after the
@@ -578,6 +738,10 @@ def main():
                 cb = cpu_baseline("roi_align_rotated", d, a.rois)
                 cb["sample"] = "rotated RoIAlign forward leg (the roofline kernel), not the whole train step: " + cb["sample"]
                 line["cpu_baseline"] = cb
+            if world == 1:
+                del rstep
+                roofline_extras(a, dev, line, live=not a.no_live_traffic)
+                rstep = None
             if world == 1 and a.workload == "s2anet_train" and a.amp == "none" and not a.no_secondary:
                 del step, runner, rstep, d
                 import gc
@@ -606,6 +770,9 @@ def main():
             line["roofline"] = roofline_obj(a.workload, nbytes, dev_ms, kname, dev)
             if world == 1 and not a.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(a.workload, d, a.rois)
+            if world == 1 and a.workload == "roi_align_rotated" and not a.no_live_traffic and \
+                    os.environ.get("JDET_ROI_FWD_PATH", "roi_cl") == "roi_cl":
+                roofline_extras(a, dev, line, live=True)
             print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

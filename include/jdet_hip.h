@@ -147,6 +147,23 @@ int jdet_roi_align_backward_cl(int variant, const float* grad_out_cl, const floa
                                float* grad_in_nhwc, void* workspace, size_t workspace_bytes, int workspace_clean,
                                jdet_stream_t stream);
 
+/* The PLAN of a backward, separated from the gather (round 6).  jdet_roi_align_backward[_cl] inverts the scatter on every
+ * call (a third of its time at the north-star point) although the inversion depends only on the RoIs, the map size and
+ * the bin grid -- all known at the forward (ROIAlignBackward's arguments besides the gradient, roi_align_rotated.py:L284-308).
+ *   jdet_roi_align_backward_plan       builds the plan into `plan` (jdet_roi_align_backward_plan_bytes() bytes, any
+ *                                      content on entry; 0 bytes = shape served by the atomic path only)
+ *   jdet_roi_align_backward_cl_planned the gather alone from a channels-last gradient (R, PH, PW, C); the plan is left
+ *                                      intact: any number of gathers (any C) per plan.  RiRoIAlign: JDET_E_UNSUPPORTED
+ *                                      (its rows need the orientation mix: use jdet_roi_align_backward_cl).
+ * Same values as jdet_roi_align_backward_cl (same rows, same order of accumulation). */
+size_t jdet_roi_align_backward_plan_bytes(int variant, int R, int N, int H, int W, int PH, int PW, int sample_num);
+int jdet_roi_align_backward_plan(int variant, const float* rois, int R, int N, int H, int W, int PH, int PW,
+                                 float spatial_scale, int sample_num, void* plan, size_t plan_bytes,
+                                 jdet_stream_t stream);
+int jdet_roi_align_backward_cl_planned(int variant, const float* grad_out_cl, int R, int N, int C, int H, int W, int PH,
+                                       int PW, int sample_num, float* grad_in_nhwc, const void* plan, size_t plan_bytes,
+                                       jdet_stream_t stream);
+
 /* Pairwise rotated IoU, ious (n1, n2) row-major.  Replaces box_iou_rotated.py:L507 and
  * box_iou_rotated_v1.py:L512 (the python-side "too small" zeroing L515-523 stays in the
  * host wrapper).  version 0/1 selects the vertex convention; sort_mode 0 reproduces the

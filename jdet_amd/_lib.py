@@ -46,6 +46,9 @@ SIGNATURES = {
     "jdet_roi_align_forward_cl_reference": (_i, [_i, _p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_cl": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _sz, _i, _p]),
     "jdet_roi_align_backward_clean_bytes": (_sz, [_i] * 9),
+    "jdet_roi_align_backward_plan_bytes": (_sz, [_i] * 8),
+    "jdet_roi_align_backward_plan": (_i, [_i, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p, _sz, _p]),
+    "jdet_roi_align_backward_cl_planned": (_i, [_i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "jdet_roi_align_backward_workspace": (_sz, [_i] * 9),
     "jdet_roi_align_backward": (_i, [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _i, _i, _p, _p, _p, _sz, _p]),
     "jdet_roi_spatial_order": (_i, [_p, _i, _i, _f, _i, _i, _i, _p, _p, _p]),

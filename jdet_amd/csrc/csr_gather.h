@@ -355,7 +355,8 @@ __device__ __forceinline__ void patch_accumulate(const PatchEntry* __restrict__ 
 // img_h / img_w: pixel size of one image; keys = images x ceil(img_h/2) x ceil(img_w/2) patches.
 // A patch's entries: min(count, cap) in its direct row, the rest (count > cap only) in the CSR of the overflow.
 // The row counters and over_flag are handed back zeroed (a patch's counter after its entries were read).
-template <int UNROLL>
+// KEEP: the counters / flag stay as they are -- the caller gathers again from the same rows (a plan kept from the forward)
+template <int UNROLL, bool KEEP = false>
 static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const float* __restrict__ gT,
                                                               const int* __restrict__ offsets,
                                                               const int* __restrict__ tile_base,
@@ -365,7 +366,7 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
                                                               int* __restrict__ counts, float* __restrict__ grad_in) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x == 0) counts[nkeys + 1] = 0;   // over_flag: scan and fill have read it
+  if (!KEEP && blockIdx.x == 0 && threadIdx.x == 0) counts[nkeys + 1] = 0;   // over_flag: scan and fill have read it
   const int php = (img_h + 1) >> 1, pwp = (img_w + 1) >> 1;
   const int bw = (pwp + 1) >> 1;                               // workgroups per row of patches
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -407,20 +408,27 @@ static __global__ __launch_bounds__(256) void csr_gather_patch_kernel(const floa
       if (has_y1 && has_x1) *reinterpret_cast<v4f*>(out0 + (size_t)(img_w + 1) * C + c) = acc[3];
     }
   }
-  if (lane == 0) counts[p] = 0;
+  if (!KEEP && lane == 0) counts[p] = 0;
 }
 
 // counts[] hold the row lengths, direct[] the first `cap` entries of every row, segment g of recs its seg_n[g] overflow
 // records, counts[nkeys + 1] their total; counts[nkeys] (ticket) is zero.
 // On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
-inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
-                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
+// overflow records -> CSR (both launches return at once when no row went past the cap)
+inline int patch_finish(const PatchWs& w, long nkeys, long nsegs, long seg_cap, hipStream_t st) {
   const int ntiles = (int)((nkeys + kScanTile - 1) / kScanTile);
   int* over_flag = w.counts + nkeys + 1;
   hipLaunchKernelGGL(csr_scan_kernel, dim3(ntiles), dim3(256), 0, st, w.counts, (int)nkeys, ntiles, w.offsets,
                      w.tile_sum, w.tile_base, w.counts + nkeys, w.cap, (const int*)over_flag);
   hipLaunchKernelGGL(csr_fill_patch_kernel, dim3((unsigned)nsegs), dim3(256), 0, st, w.recs, w.seg_n, (int)seg_cap,
                      w.offsets, w.tile_base, w.entries);
+  return jdet_launch_status();
+}
+
+// keep_plan: counters, direct rows and overflow CSR are left intact (the next gather reads them again); otherwise the
+// first patch_zero_bytes(nkeys) bytes of the workspace are handed back zeroed
+inline int patch_gather(const PatchWs& w, long nkeys, const float* src, int C, float* dst, int n_img, int img_h,
+                        int img_w, bool keep_plan, hipStream_t st) {
   const int php = (img_h + 1) / 2, pwp = (img_w + 1) / 2, bw = (pwp + 1) / 2;
   const int wg_rows = (n_img * php + 1) / 2;
   // XCD x owns one 2-D block of the workgroup grid, walked in 8 x 8 sub-tiles (see the kernel): 77.8 -> 76.3 us for the
@@ -428,9 +436,23 @@ inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, lon
   const int nbc = bw >= 2 ? 2 : 1, nbr = 8 / nbc;
   const int BR = (wg_rows + nbr - 1) / nbr, BC = (bw + nbc - 1) / nbc;
   const unsigned blocks = 8u * 64u * (unsigned)(((BR + 7) / 8) * ((BC + 7) / 8));
-  hipLaunchKernelGGL((csr_gather_patch_kernel<8>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
-                     w.entries, w.direct, w.cap, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
+  if (keep_plan)
+    hipLaunchKernelGGL((csr_gather_patch_kernel<8, true>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
+                       w.entries, w.direct, w.cap, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
+  else
+    hipLaunchKernelGGL((csr_gather_patch_kernel<8, false>), dim3(blocks), dim3(256), 0, st, src, w.offsets, w.tile_base,
+                       w.entries, w.direct, w.cap, (int)nkeys, C, n_img, img_h, img_w, w.counts, dst);
   return jdet_launch_status();
+}
+
+// counts[] hold the row lengths, direct[] the first `cap` entries of every row, segment g of recs its seg_n[g] overflow
+// records, counts[nkeys + 1] their flag; counts[nkeys] (ticket) is zero.
+// On return (stream order) the first patch_zero_bytes(nkeys) bytes of the workspace are zero again.
+inline int patch_finish_and_gather(const PatchWs& w, long nkeys, long nsegs, long seg_cap, const float* src, int C,
+                                   float* dst, int n_img, int img_h, int img_w, hipStream_t st) {
+  const int e = patch_finish(w, nkeys, nsegs, seg_cap, st);
+  if (e) return e;
+  return patch_gather(w, nkeys, src, C, dst, n_img, img_h, img_w, false, st);
 }
 
 }  // namespace jdet_csr

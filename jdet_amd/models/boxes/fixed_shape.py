@@ -42,28 +42,29 @@ def sample_fixed(gt_inds, num, pos_fraction, neg_pos_ub=-1, generator=None):
 
 def sample_rows(gt_inds, num, pos_fraction, neg_pos_ub=-1, generator=None):
     """The sampled set as exactly `num` rows: (rows (num,) indices into the candidates, valid (num,), is_pos (num,)).
-    Valid positives come first, then valid negatives (the order of SamplingResult.bboxes, sampler.py:L36-38); when the
-    candidates run out the tail rows are invalid (valid False; their index is arbitrary but in range)."""
+    Valid positives come first, then valid negatives (the order of SamplingResult.bboxes, sampler.py:L36-38), each in
+    ASCENDING candidate index -- the reference passes both index lists through `.unique()` (sampler.py:L90, L104), which
+    sorts them, so with `add_gt_as_proposals` the sampled gts lead the positives.  When the candidates run out the tail
+    rows are invalid (valid False; their index is arbitrary but in range)."""
     pos_idx, pos_valid, neg_idx, neg_valid = sample_fixed(gt_inds, num, pos_fraction, neg_pos_ub, generator)
-    idx = torch.cat([pos_idx, neg_idx])
-    valid = torch.cat([pos_valid, neg_valid])
-    is_pos = torch.cat([torch.ones_like(pos_valid), torch.zeros_like(neg_valid)])
-    # stable partition: valid rows first, original (positives-then-negatives) order kept.  Two prefix sums and one
-    # scatter instead of a stable device sort (a merge sort of ~25 launches for ~1000 elements)
-    v = valid.to(torch.int64)
-    n_valid = v.sum()
-    dest = torch.where(valid, torch.cumsum(v, 0) - 1, n_valid + torch.cumsum(1 - v, 0) - 1)
-    order = torch.empty_like(dest)
-    order[dest] = torch.arange(dest.numel(), device=dest.device)
-    k = min(int(num), idx.numel())
-    order = order[:k]
-    rows, valid, is_pos = idx[order], valid[order], is_pos[order] & valid[order]
-    if k < num:     # fewer candidates than rows asked for: pad (callers size their buffers by `num`)
-        pad = num - k
-        rows = torch.cat([rows, rows.new_zeros((pad,))])
-        valid = torch.cat([valid, valid.new_zeros((pad,))])
-        is_pos = torch.cat([is_pos, is_pos.new_zeros((pad,))])
-    return rows, valid, is_pos
+    A = gt_inds.numel()
+    dev = gt_inds.device
+    num = int(num)
+    # selection masks over the candidates (slot A takes the invalid draws), then a prefix-sum partition: the k-th
+    # selected candidate in index order goes to row k -- no device sort
+    # (scatter_ with a scalar value: `mask[idx] = 1` copies the scalar from the host -- a synchronising operation)
+    sel_p = torch.zeros((A + 1,), dtype=torch.int64, device=dev)
+    sel_p.scatter_(0, torch.where(pos_valid, pos_idx, torch.full_like(pos_idx, A)), 1)
+    sel_n = torch.zeros((A + 1,), dtype=torch.int64, device=dev)
+    sel_n.scatter_(0, torch.where(neg_valid, neg_idx, torch.full_like(neg_idx, A)), 1)
+    sel_p, sel_n = sel_p[:A], sel_n[:A]
+    n_pos, n_neg = sel_p.sum(), sel_n.sum()
+    dest = torch.where(sel_p > 0, torch.cumsum(sel_p, 0) - 1,
+                       torch.where(sel_n > 0, n_pos + torch.cumsum(sel_n, 0) - 1, torch.full_like(sel_p, num)))
+    rows = torch.zeros((num + 1,), dtype=torch.int64, device=dev)
+    rows.scatter_(0, dest.clamp(max=num), torch.arange(A, device=dev))
+    k = torch.arange(num, device=dev)
+    return rows[:num], k < n_pos + n_neg, k < n_pos
 
 
 def scatter_rows(dst, idx, valid, values):

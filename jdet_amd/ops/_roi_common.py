@@ -104,15 +104,86 @@ def _kept_backward_workspace(dev, map_shape, nbytes):
     return ws, key
 
 
-def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order):
+# The plan of a backward (jdet_roi_align_backward_plan: the inversion of the scatter, a third of the backward's time)
+# depends only on what the forward already knows.  In training it is built at the forward and the backward is the gather
+# alone (jdet_roi_align_backward_cl_planned): 45.6 us instead of 66.5 us at the north-star point.
+# JDET_ROI_BWD_PLAN=0: the self-contained backward; =side: the plan on a second stream beside the forward kernel (what
+# bench.py's roi_align_rotated_pair does by hand) -- measured in the Oriented R-CNN step: same stream 27.57-27.82 ms = the
+# self-contained backward's 27.54-27.57 ms, side stream 29.07-29.18 ms (four plan buffers per step handed between streams
+# cost more than the 4 x 10 us they hide), so the forward's own stream is the default.
+import os
+
+_PLAN_ON = [os.environ.get("JDET_ROI_BWD_PLAN", "1") != "0"]
+_PLAN_SIDE_STREAM = [os.environ.get("JDET_ROI_BWD_PLAN", "1") == "side"]
+_PLAN_STREAMS = {}
+
+
+def set_backward_plan(on):
+    prev = _PLAN_ON[0]
+    _PLAN_ON[0] = bool(on)
+    return prev
+
+
+class BackwardPlan:
+    """device buffer + the event after which it is complete"""
+    __slots__ = ("buf", "event", "key")
+
+    def __init__(self, buf, event, key):
+        self.buf, self.event, self.key = buf, event, key
+
+
+def build_backward_plan(variant, rois_c, shape, PH, PW, scale, sample_num, n_orient=1):
+    """-> BackwardPlan | None (shape served by the unplanned entries: RiRoIAlign, adaptive sampling, C % 4, R == 0)."""
+    N, C, H, W = shape
+    R = rois_c.shape[0]
+    if not _PLAN_ON[0] or variant == V_RI or R == 0 or C % 4 != 0 or sample_num <= 0:
+        return None
+    lib = L.lib()
+    nbytes = lib.jdet_roi_align_backward_plan_bytes(variant, R, N, H, W, PH, PW, sample_num)
+    if nbytes == 0:
+        return None
+    dev = rois_c.device
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    if torch.cuda.is_current_stream_capturing() or not _PLAN_SIDE_STREAM[0]:
+        side = cur          # inside a capture: one stream (the graph's own dependencies order plan and gather)
+    else:
+        side = _PLAN_STREAMS.get(dev.index)
+        if side is None:
+            side = _PLAN_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        side.wait_stream(cur)            # the RoIs (and the buffer's allocation) are ready
+    with torch.cuda.stream(side):
+        L.check(lib.jdet_roi_align_backward_plan(variant, L.ptr(rois_c), R, N, H, W, PH, PW, float(scale),
+                                                 int(sample_num), L.ptr(buf), nbytes, side.cuda_stream),
+                "jdet_roi_align_backward_plan")
+        event = None
+        if side is not cur:
+            event = torch.cuda.Event()
+            event.record(side)
+            buf.record_stream(side)
+            rois_c.record_stream(side)
+    return BackwardPlan(buf, event, (variant, R, N, H, W, PH, PW, int(sample_num)))
+
+
+def _backward_into(variant, g_out, rois_c, shape, PH, PW, scale, sample_num, n_orient, order, plan=None):
     """grad w.r.t. one feature map (NHWC memory).  A channels-last grad_out (what a channels-last forward result
-    gets back from a layout-preserving consumer) feeds the sorted gather directly: no transpose pass."""
+    gets back from a layout-preserving consumer) feeds the sorted gather directly: no transpose pass; with a plan kept
+    from the forward the call is the gather alone."""
     N, C, H, W = shape
     R = rois_c.shape[0]
     grad_in = torch.empty((N, C, H, W), dtype=torch.float32, device=g_out.device,
                           memory_format=torch.channels_last)
     if g_out.dtype != torch.float32:
         g_out = g_out.float()
+    if (plan is not None and plan.key == (variant, R, N, H, W, PH, PW, int(sample_num)) and C % 4 == 0
+            and g_out.is_contiguous(memory_format=torch.channels_last) and not g_out.is_contiguous()):
+        if plan.event is not None:
+            torch.cuda.current_stream(g_out.device).wait_event(plan.event)
+        L.check(L.lib().jdet_roi_align_backward_cl_planned(variant, L.ptr(g_out), R, N, C, H, W, PH, PW,
+                                                           int(sample_num), L.ptr(grad_in), L.ptr(plan.buf),
+                                                           plan.buf.numel(), L.stream_ptr(g_out)),
+                "jdet_roi_align_backward_cl_planned")
+        return grad_in
     wsb = L.lib().jdet_roi_align_backward_workspace(variant, R, N, C, H, W, PH, PW, sample_num)
     if wsb and R and g_out.is_contiguous(memory_format=torch.channels_last) and not g_out.is_contiguous():
         ws, key = _kept_backward_workspace(g_out.device, (N, H, W), wsb)
@@ -185,13 +256,19 @@ class RoIAlignFunction(torch.autograd.Function):
                     "jdet_roi_align_forward")
         ctx.save_for_backward(rois_c, order)
         ctx.cfg = (variant, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num), int(n_orient))
+        ctx.plan = None
+        if ctx.needs_input_grad[0] and out.is_contiguous(memory_format=torch.channels_last) and not out.is_contiguous():
+            ctx.plan = build_backward_plan(variant, rois_c, (N, C, H, W), PH, PW, float(spatial_scale), int(sample_num),
+                                           int(n_orient))
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
         rois_c, order = ctx.saved_tensors
         variant, shape, PH, PW, scale, sample_num, n_orient = ctx.cfg
-        grad_in = _backward_into(variant, grad_output, rois_c, shape, PH, PW, scale, sample_num, n_orient, order)
+        grad_in = _backward_into(variant, grad_output, rois_c, shape, PH, PW, scale, sample_num, n_orient, order,
+                                 ctx.plan)
+        ctx.plan = None
         return grad_in, None, None, None, None, None, None
 
 
@@ -217,7 +294,7 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
         out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=rois_c.device,
                           memory_format=torch.channels_last if roi_cl else torch.contiguous_format)
         lvl = target_lvls.to(rois_c.device)
-        masked, shapes = [], []
+        masked, shapes, plans = [], [], []
         for i, f in enumerate(feats):
             fm = to_nhwc(f)
             N, Ci, H, W = fm.shape
@@ -232,6 +309,10 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
                         "jdet_roi_align_forward")
             masked.append(r_i)
             shapes.append((N, C, H, W))
+            plans.append(build_backward_plan(variant, r_i, (N, C, H, W), PH, PW, float(scales[i]), int(sample_num),
+                                             int(n_orient))
+                         if R and roi_cl and ctx.needs_input_grad[3 + i] else None)
+        ctx.plans = plans
         ctx.save_for_backward(*masked)
         ctx.cfg = (variant, PH, PW, scales, int(sample_num), int(n_orient), shapes)
         return out
@@ -246,7 +327,8 @@ class MultiLevelRoIAlignFunction(torch.autograd.Function):
                 grads.append(None)
                 continue
             grads.append(_backward_into(variant, grad_output, r_i, shape, PH, PW, float(scales[i]), sample_num,
-                                        n_orient, None))
+                                        n_orient, None, ctx.plans[i]))
+        ctx.plans = None
         return (None, None, None, *grads)
 
 

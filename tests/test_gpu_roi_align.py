@@ -445,3 +445,69 @@ def test_line_forward_matches_the_oracle(dev, variant, C, hw):
     ref = O.roi_align_forward(variant, feat, rois[~masked], hw, scale, 2)
     np.testing.assert_allclose(a[~masked], ref, rtol=0, atol=FWD_MERGED_ATOL)
     np.testing.assert_allclose(a[~masked], b[~masked], rtol=0, atol=FWD_MERGED_ATOL)
+
+
+@pytest.mark.parametrize("variant", [O.V_ROT, O.V_ROT_V1, O.V_HBB0, O.V_HBB1])
+def test_planned_backward_equals_the_self_contained_one(dev, variant, fwd_mode):
+    """round 6: jdet_roi_align_backward_plan + jdet_roi_align_backward_cl_planned (the plan built once, the gather alone per
+    gradient) against the oracle's scatter and the self-contained jdet_roi_align_backward_cl; the plan survives a gather
+    (second gradient, other channel count, same plan); masked RoIs and RoIs over the border included."""
+    from jdet_amd import _lib as L
+    if fwd_mode != FWD_MERGED_ATOL:
+        pytest.skip("one arithmetic is enough: the backward has a single one")
+    lib = L.lib()
+    rng = np.random.default_rng(77 + variant)
+    N, H, W, scale = 2, 40, 56, 0.25
+    rois = np.concatenate([I.rois_from_obbs(I.random_obbs(rng, 150, extent=W / scale, wh=(4.0, 200.0)),
+                                            rng.integers(0, N, 150)), I.edge_rois(H, W, scale)], 0)
+    rois[rng.random(rois.shape[0]) < 0.2, 0] = -1.0
+    if variant in (O.V_HBB0, O.V_HBB1):
+        rois = I.obb_to_hbb_rois(rois)
+    R = rois.shape[0]
+    r = torch.from_numpy(rois).to(dev)
+    pb = lib.jdet_roi_align_backward_plan_bytes(variant, R, N, H, W, 7, 7, 2)
+    assert pb > 0
+    plan = torch.empty((pb,), dtype=torch.uint8, device=dev).fill_(0xA5)        # any content on entry
+    L.check(lib.jdet_roi_align_backward_plan(variant, r.data_ptr(), R, N, H, W, 7, 7, scale, 2, plan.data_ptr(), pb,
+                                             L.stream_ptr(r)), "plan")
+    for C in (64, 8, 260):
+        grad = rng.standard_normal((R, C, 7, 7)).astype(np.float32)
+        g = torch.from_numpy(grad).to(dev).contiguous(memory_format=torch.channels_last)
+        gin = torch.full((N, C, H, W), float("nan"), device=dev).contiguous(memory_format=torch.channels_last)
+        L.check(lib.jdet_roi_align_backward_cl_planned(variant, g.data_ptr(), R, N, C, H, W, 7, 7, 2, gin.data_ptr(),
+                                                       plan.data_ptr(), pb, L.stream_ptr(g)), "planned")
+        live = rois[:, 0] >= 0
+        ref = O.roi_align_backward(variant, grad[live], rois[live], (N, C, H, W), scale, 2)
+        np.testing.assert_allclose(gin.cpu().numpy(), ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
+    # too small a plan buffer / RiRoIAlign are refused
+    assert lib.jdet_roi_align_backward_cl_planned(variant, g.data_ptr(), R, N, C, H, W, 7, 7, 2, gin.data_ptr(),
+                                                  plan.data_ptr(), pb - 1, L.stream_ptr(g)) == -3
+    assert lib.jdet_roi_align_backward_cl_planned(O.V_RI, g.data_ptr(), R, N, 256, H, W, 7, 7, 2, gin.data_ptr(),
+                                                  plan.data_ptr(), pb, L.stream_ptr(g)) == -2
+
+
+def test_autograd_uses_the_plan_and_matches_without_it(dev, fwd_mode):
+    """the layer builds the plan at the forward (side stream) and gathers from it in backward; JDET_ROI_BWD_PLAN off gives
+    the same gradient (summation order aside); two backward passes through one graph are refused by autograd as usual"""
+    from jdet_amd.ops import _roi_common as RC
+    if fwd_mode != FWD_MERGED_ATOL or RC._FORWARD_PATH[0] != "roi_cl":
+        pytest.skip("channels-last result only")
+    rng = np.random.default_rng(5)
+    N, C, H, W, scale = 2, 64, 48, 48, 0.25
+    feat = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = I.rois_from_obbs(I.random_obbs(rng, 300, extent=W / scale, wh=(4.0, 160.0)), rng.integers(0, N, 300))
+    grad = torch.from_numpy(rng.standard_normal((300, C, 7, 7)).astype(np.float32)).to(dev).contiguous(
+        memory_format=torch.channels_last)
+    outs = []
+    for on in (True, False):
+        prev = RC.set_backward_plan(on)
+        try:
+            x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = _layer(O.V_ROT, (7, 7), scale, 2)(x, torch.from_numpy(rois).to(dev))
+            y.backward(grad)
+            outs.append(x.grad.cpu().numpy())
+        finally:
+            RC.set_backward_plan(prev)
+    ref = O.roi_align_backward(O.V_ROT, grad.cpu().numpy(), rois, feat.shape, scale, 2)
+    for g in outs:
+        np.testing.assert_allclose(g, ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
