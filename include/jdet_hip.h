@@ -514,6 +514,17 @@ int jdet_anchor_targets_rotated(const float* anchors, const float* gt, const int
  *   gt_labels (K) int32 or NULL; labels (A) int32 or NULL; labels_filled = assigned_labels_filled
  *   out: gt_inds (A) int32 in {-1, 0, 1..K}, max_overlaps (A), labels (A)
  * Column argmax ties resolve to the first gt (Jittor's tie rule is unpinned). */
+/* Top-down step of the FPN (necks/fpn.py:L160-171: `laterals[i-1] += nn.interpolate(laterals[i], mode="nearest")`, then
+ * `/= upsample_div_factor`) as one pass over channels-last maps: out = (lateral + nearest_upsample(top)) / div_factor.
+ *   lateral / out (N, H, W, C), top (N, Ht, Wt, C) float32, 16-byte aligned, C % 4 == 0 (else JDET_E_UNSUPPORTED)
+ *   nearest rule: src = min(floor(dst * in / out), in - 1) in float32 (= dst >> 1 for an exact 2x)
+ * backward: grad_top = sum of grad_out over the pre-image of every coarse pixel, / div_factor (the gradient of `lateral` is
+ * grad_out / div_factor itself: no launch). */
+int jdet_upsample_add_nhwc_forward(const float* lateral, const float* top, int N, int C, int H, int W, int Ht, int Wt,
+                                   float div_factor, float* out, jdet_stream_t stream);
+int jdet_upsample_add_nhwc_backward(const float* grad_out, int N, int C, int H, int W, int Ht, int Wt, float div_factor,
+                                    float* grad_top, jdet_stream_t stream);
+
 /* Input pipeline on the device: uint8 batch (N, Hs, Ws, 3) -> float32 (N, Hs, Ws, 3) = channels-last memory of a
  * (N, 3, Hs, Ws) tensor, (v - mean[c]) / std[c] with the optional channel reversal first (`Normalize`,
  * data/transforms.py:L467-487), zeros outside each image's valid_hw[n] = (height, width) (`collate_batch`,

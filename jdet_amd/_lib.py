@@ -55,6 +55,8 @@ SIGNATURES = {
     "jdet_box_iou_rotated": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "jdet_nms_rotated_workspace": (_sz, [_i]),
     "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),
+    "jdet_upsample_add_nhwc_forward": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "jdet_upsample_add_nhwc_backward": (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     "jdet_normalize_u8_nhwc": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "jdet_feature_refine_forward": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     "jdet_feature_refine_backward_workspace": (_sz, [_i] * 5),

@@ -1,12 +1,22 @@
-"""Feature pyramid network.  Mirrors python/jdet/models/necks/fpn.py:L60-201: 1x1 laterals,
-nearest-upsample top-down add, 3x3 output convs, extra levels by stride-2 conv (`add_extra_convs`
-in {on_input, on_lateral, on_output}) or by stride-2 max-pool."""
+"""Feature pyramid network behind the reference's constructor and parameter names (python/jdet/models/necks/fpn.py:L60-201;
+`lateral_convs.N.*` / `fpn_convs.N.*` are the checkpoint keys).  What it computes: a 1x1 lateral per used backbone level;
+top-down, every level receives the nearest-upsampled sum of the levels above it; a 3x3 output conv per level; levels beyond
+the backbone's by stride-2 3x3 convs fed from the last input / lateral / output (`add_extra_convs`) or, without them, by
+stride-2 subsampling of the last output.
+
+Own structure: three stages (laterals, top-down merge, levels beyond the backbone's), each its own method; the top-down
+step is ONE fused launch per level on channels-last device maps (`ops/upsample_add.py`: (lateral + upsample(top)) / div,
+instead of an upsampled copy plus an add, and one launch instead of two in backward); other layouts / resampling modes
+take the framework's interpolate."""
 import torch.nn.functional as F
 from torch import nn
 
 from jdet_amd.models.utils.modules import ConvModule
 from jdet_amd.models.utils.weight_init import xavier_init
+from jdet_amd.ops import upsample_add as UA
 from jdet_amd.utils.registry import NECKS
+
+_EXTRA_SOURCES = ("on_input", "on_lateral", "on_output")
 
 
 @NECKS.register_module()
@@ -16,45 +26,40 @@ class FPN(nn.Module):
                  norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode="nearest"),
                  init_cfg=dict(type="Xavier", layer="Conv2d", distribution="uniform"), upsample_div_factor=1):
         super().__init__()
-        assert isinstance(in_channels, list)
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.num_ins = len(in_channels)
-        self.num_outs = num_outs
+        if not isinstance(in_channels, list):
+            raise AssertionError("in_channels must be a list")
+        if not isinstance(add_extra_convs, (str, bool)) or (isinstance(add_extra_convs, str)
+                                                            and add_extra_convs not in _EXTRA_SOURCES):
+            raise AssertionError("add_extra_convs: bool or one of %s" % (_EXTRA_SOURCES,))
+        stop = len(in_channels) if end_level == -1 else end_level
+        n_backbone = stop - start_level                       # pyramid levels that have a backbone map under them
+        if end_level == -1:
+            assert num_outs >= n_backbone
+        else:
+            assert end_level <= len(in_channels) and num_outs == n_backbone      # no extra level beyond an explicit end
+        # attributes the reference exposes (heads / tools read some of them)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.start_level, self.end_level, self.backbone_end_level = start_level, end_level, stop
+        self.add_extra_convs = add_extra_convs
         self.relu_before_extra_convs = relu_before_extra_convs
         self.no_norm_on_lateral = no_norm_on_lateral
         self.upsample_cfg = dict(upsample_cfg)
         self.upsample_div_factor = upsample_div_factor
-        if end_level == -1:
-            self.backbone_end_level = self.num_ins
-            assert num_outs >= self.num_ins - start_level
-        else:
-            self.backbone_end_level = end_level
-            assert end_level <= len(in_channels)
-            assert num_outs == end_level - start_level
-        self.start_level = start_level
-        self.end_level = end_level
-        self.add_extra_convs = add_extra_convs
-        assert isinstance(add_extra_convs, (str, bool))
-        if isinstance(add_extra_convs, str):
-            assert add_extra_convs in ("on_input", "on_lateral", "on_output")
-        self.lateral_convs = nn.ModuleList()
-        self.fpn_convs = nn.ModuleList()
-        for i in range(self.start_level, self.backbone_end_level):
-            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, conv_cfg=conv_cfg,
-                                                 norm_cfg=norm_cfg if not self.no_norm_on_lateral else None,
-                                                 act_cfg=act_cfg))
-            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, conv_cfg=conv_cfg,
-                                             norm_cfg=norm_cfg, act_cfg=act_cfg))
-        extra_levels = num_outs - self.backbone_end_level + self.start_level
-        if self.add_extra_convs and extra_levels >= 1:
-            for i in range(extra_levels):
-                if i == 0 and self.add_extra_convs == "on_input":
-                    in_ch = self.in_channels[self.backbone_end_level - 1]
-                else:
-                    in_ch = out_channels
-                self.fpn_convs.append(ConvModule(in_ch, out_channels, 3, stride=2, padding=1, conv_cfg=conv_cfg,
-                                                 norm_cfg=norm_cfg, act_cfg=act_cfg))
+
+        common = dict(conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        lateral_norm = dict(common, norm_cfg=None) if no_norm_on_lateral else common
+        self.lateral_convs = nn.ModuleList(ConvModule(c, out_channels, 1, **lateral_norm)
+                                           for c in in_channels[start_level:stop])
+        self.fpn_convs = nn.ModuleList(ConvModule(out_channels, out_channels, 3, padding=1, **common)
+                                       for _ in range(n_backbone))
+        # levels above the backbone's: fpn_convs[n_backbone + k]; only the first may read a raw backbone map
+        self._n_backbone = n_backbone
+        self._n_extra_convs = (num_outs - n_backbone) if add_extra_convs else 0
+        for k in range(self._n_extra_convs):
+            first_from_input = k == 0 and add_extra_convs == "on_input"
+            self.fpn_convs.append(ConvModule(in_channels[stop - 1] if first_from_input else out_channels, out_channels, 3,
+                                             stride=2, padding=1, **common))
         self.init_weights()
 
     def init_weights(self):
@@ -62,38 +67,48 @@ class FPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution="uniform")
 
+    # -- the three stages of the pyramid --------------------------------------------------------------------------
+    def _merge_down(self, fine, coarse):
+        """one top-down step: (fine + coarse brought to fine's resolution) / upsample_div_factor"""
+        div = self.upsample_div_factor
+        cfg = self.upsample_cfg
+        if cfg.get("mode", "nearest") == "nearest" and "scale_factor" not in cfg and UA.fusable(fine, coarse):
+            return UA.upsample_add(fine, coarse, div)
+        target = {} if "scale_factor" in cfg else {"size": fine.shape[2:]}
+        merged = fine + F.interpolate(coarse, **target, **cfg)
+        return merged if div == 1 else merged / div
+
+    def _top_down(self, laterals):
+        merged = [None] * len(laterals)
+        merged[-1] = laterals[-1]
+        for lvl in range(len(laterals) - 2, -1, -1):          # coarsest to finest: each level sees the merged one above
+            merged[lvl] = self._merge_down(laterals[lvl], merged[lvl + 1])
+        return merged
+
+    def _extend(self, inputs, merged, outs):
+        """levels beyond the backbone's, appended to outs"""
+        missing = self.num_outs - len(outs)
+        if missing <= 0:
+            return
+        if not self.add_extra_convs:
+            for _ in range(missing):
+                outs.append(F.max_pool2d(outs[-1], 1, stride=2))      # kernel 1, stride 2: plain subsampling
+            return
+        source = {"on_input": inputs[self.backbone_end_level - 1], "on_lateral": merged[-1], "on_output": outs[-1]}
+        if self.add_extra_convs not in source:
+            raise NotImplementedError(self.add_extra_convs)
+        feed = source[self.add_extra_convs]
+        for k in range(missing):
+            if k > 0:
+                feed = F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]
+            outs.append(self.fpn_convs[self._n_backbone + k](feed))
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [lateral_conv(inputs[i + self.start_level]) for i, lateral_conv in enumerate(self.lateral_convs)]
-        used_backbone_levels = len(laterals)
-        for i in range(used_backbone_levels - 1, 0, -1):
-            if "scale_factor" in self.upsample_cfg:
-                up = F.interpolate(laterals[i], **self.upsample_cfg)
-            else:
-                up = F.interpolate(laterals[i], size=laterals[i - 1].shape[2:], **self.upsample_cfg)
-            laterals[i - 1] = laterals[i - 1] + up
-            if self.upsample_div_factor != 1:
-                laterals[i - 1] = laterals[i - 1] / self.upsample_div_factor
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(used_backbone_levels)]
-        if self.num_outs > len(outs):
-            if not self.add_extra_convs:
-                for i in range(self.num_outs - used_backbone_levels):
-                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
-            else:
-                if self.add_extra_convs == "on_input":
-                    extra_source = inputs[self.backbone_end_level - 1]
-                elif self.add_extra_convs == "on_lateral":
-                    extra_source = laterals[-1]
-                elif self.add_extra_convs == "on_output":
-                    extra_source = outs[-1]
-                else:
-                    raise NotImplementedError
-                outs.append(self.fpn_convs[used_backbone_levels](extra_source))
-                for i in range(used_backbone_levels + 1, self.num_outs):
-                    if self.relu_before_extra_convs:
-                        outs.append(self.fpn_convs[i](F.relu(outs[-1])))
-                    else:
-                        outs.append(self.fpn_convs[i](outs[-1]))
+        laterals = [conv(inputs[self.start_level + k]) for k, conv in enumerate(self.lateral_convs)]
+        merged = self._top_down(laterals)
+        outs = [self.fpn_convs[k](m) for k, m in enumerate(merged)]
+        self._extend(inputs, merged, outs)
         return tuple(outs)
 
     execute = forward
