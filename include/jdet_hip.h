@@ -225,10 +225,12 @@ int jdet_modulated_deform_col2im_coord(const float* col, const float* im, const 
                                        float* grad_offset, float* grad_mask, jdet_stream_t stream);
 
 /* Deformable position-sensitive RoI pooling.  Replace DeformablePSROIPoolForwardKernel / ...BackwardAccKernel of
- * ops/dcn_v2.py:L855-932, L1007-1116.  input (N,C,H,W) with C = output_dim * group_size^2; rois (R,5)
- * [batch,x1,y1,x2,y2]; trans (R, trans_channels, part, part) or NULL with no_trans; out / top_count
- * (R, output_dim, P, P) (top_count = samples counted per bin, consumed by the backward).  The backward zero-fills
- * grad_input (N,C,H,W) and grad_trans (shape of trans) and accumulates with fp32 atomics. */
+ * ops/dcn_v2.py:L855-932, L1007-1116.  CHANNELS-LAST memory (round 6): input / grad_input (N, H, W, C) with
+ * C = output_dim * group_size^2 [the reference: (N,C,H,W)]; rois (R,5) [batch,x1,y1,x2,y2]; trans
+ * (R, trans_channels, part, part) or NULL with no_trans; out / top_count / grad_out (R, P, P, output_dim) [the reference's
+ * (R, output_dim, P, P) stored channels-last] (top_count = samples counted per bin, consumed by the backward).  One wave
+ * per (RoI, bin, class, channel chunk), output channels across the lanes.  The backward zero-fills grad_input and
+ * grad_trans (shape of trans); grad_input collects lane-contiguous fp32 atomics, grad_trans two atomics per wave. */
 int jdet_deform_psroi_pool_forward(const float* input, const float* rois, const float* trans, int N, int C, int H,
                                    int W, int R, int no_trans, float spatial_scale, int output_dim, int group_size,
                                    int pooled_size, int part_size, int sample_per_part, float trans_std,

@@ -532,8 +532,12 @@ JDET_API int jdet_conv_bn_forward(const float* x_nhwc, int N, int H, int W, int 
   bool ws_ok = workspace && need_ws && workspace_bytes >= need_ws;
   // the finish kernel moves float4s
   if (ws_ok && ((((uintptr_t)y_nhwc) | ((uintptr_t)workspace) | ((uintptr_t)ep.residual) | ((uintptr_t)ep.grad_out) |
-                 ((uintptr_t)ep.act)) & 15))
+                 ((uintptr_t)ep.act)) & 15)) {
+    // dropping the K split here changes the number of partial-sum rows (jdet_conv_bn_sums_rows was asked WITH a
+    // workspace): a caller that sized `sums` for the split plan would be written past its end -- refuse instead
+    if (ep.sums) return JDET_E_BADARG;
     ws_ok = false;
+  }
   const Plan p = make_plan(M, Cin, Cout, R * R, tile, ws_ok);
   CbArgs a{x_nhwc, w_krsc, y_nhwc, nullptr, ep, N, H, W, Cin, Cout, R, stride, Ho, Wo, p.ksplit};
   hipStream_t st = (hipStream_t)stream;

@@ -43,15 +43,38 @@ class BaseSampler:
         self.neg_pos_ub = neg_pos_ub
         self.add_gt_as_proposals = add_gt_as_proposals
 
+    # The reference's extension points (sampler.py:L52-58): a subclass that overrides them (IoU-balanced / OHEM-style
+    # samplers registered from a config) is sampled through them, in the reference's sequence; the stock samplers leave
+    # them alone and draw through the fixed-shape sampler.
+    def _sample_pos(self, assign_result, num_expected, **kwargs):
+        raise NotImplementedError
+
+    def _sample_neg(self, assign_result, num_expected, **kwargs):
+        raise NotImplementedError
+
+    def _hooks_overridden(self):
+        return (type(self)._sample_pos is not BaseSampler._sample_pos
+                or type(self)._sample_neg is not BaseSampler._sample_neg)
+
     def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, generator=None, **kwargs):
         from .fixed_shape import sample_fixed
         gt_bboxes = gt_bboxes.to(bboxes.dtype)
-        bboxes = bboxes.reshape(-1, bboxes.shape[-1])[:, :self.box_dim]
+        if bboxes.dim() < 2:                    # a single box (or none) handed over flat, as the reference accepts it
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :self.box_dim]
         is_gt = torch.zeros((bboxes.shape[0],), dtype=torch.bool, device=bboxes.device)
         if self.add_gt_as_proposals:            # the gts join the candidates, matched to themselves (L92-99)
             assign_result.add_gt_(gt_labels)
             is_gt = torch.cat([is_gt.new_ones((gt_bboxes.shape[0],)), is_gt])
             bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+        if self._hooks_overridden():            # sampler.py:L86-110 through the subclass's hooks
+            pos = torch.unique(self._sample_pos(assign_result, int(self.num * self.pos_fraction), bboxes=bboxes,
+                                                **kwargs))
+            n_neg = self.num - pos.numel()
+            if self.neg_pos_ub >= 0:
+                n_neg = min(n_neg, int(self.neg_pos_ub * max(1, pos.numel())))
+            neg = torch.unique(self._sample_neg(assign_result, n_neg, bboxes=bboxes, **kwargs))
+            return SamplingResult(pos, neg, bboxes, gt_bboxes, assign_result, is_gt)
         pos, pos_ok, neg, neg_ok = sample_fixed(assign_result.gt_inds, self.num, self.pos_fraction, self.neg_pos_ub,
                                                 generator)
         return SamplingResult(pos[pos_ok].sort().values, neg[neg_ok].sort().values, bboxes, gt_bboxes, assign_result,
@@ -75,6 +98,16 @@ class PseudoSampler(BaseSampler):
 class RandomSampler(BaseSampler):
     def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
         super().__init__(num, pos_fraction, neg_pos_ub, add_gt_as_proposals)
+
+    @staticmethod
+    def random_choice(gallery, num):
+        """`num` elements of `gallery` uniformly at random (public in the reference, sampler.py:L145-156; the stock
+        samplers here draw through fixed_shape.sample_fixed and do not call it)"""
+        assert len(gallery) >= num
+        is_tensor = torch.is_tensor(gallery)
+        g = gallery if is_tensor else torch.as_tensor(gallery, dtype=torch.int64)
+        picked = g[torch.randperm(g.numel(), device=g.device)[:num]]
+        return picked if is_tensor else picked.cpu().numpy()
 
 
 @BOXES.register_module()

@@ -10,7 +10,10 @@ import os
 
 import torch
 from torch import nn
-from torch.nn.utils.stateless import _reparametrize_module      # (what torch.func.functional_call is built on)
+try:    # what torch.func.functional_call is built on -- a private name whose signature has moved between releases:
+    from torch.nn.utils.stateless import _reparametrize_module      # without it the packed branch stays on the main stream
+except ImportError:      # pragma: no cover
+    _reparametrize_module = None
 
 from jdet_amd.models.boxes.anchor_generator import AnchorGeneratorRotatedS2ANet
 from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
@@ -312,8 +315,8 @@ class S2ANetHead(RotatedAnchorHeadMixin, nn.Module):
             # launches leave most of the chip idle (57 x 32 positions: 58 output tiles for 256 CUs): they run on a side
             # stream next to the big levels' (autograd replays each branch's backward on its forward stream, so the
             # backward overlaps the same way).  Not under graph capture (one capture stream), JDET_HEAD_STREAMS=0: off.
-            if (HEAD_STREAMS and len(small) < len(feats) and torch.is_grad_enabled()
-                    and not torch.cuda.is_current_stream_capturing()):
+            if (HEAD_STREAMS and _reparametrize_module is not None and len(small) < len(feats)
+                    and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()):
                 side = _side_stream(feats[0].device)
                 main = torch.cuda.current_stream(feats[0].device)
                 side.wait_stream(main)

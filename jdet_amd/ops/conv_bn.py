@@ -25,6 +25,9 @@ separate kernel except for the block's output.  A data gradient is the forward k
 The fused path applies to channels-last fp32 device tensors with eval-mode BatchNorm2d layers whose parameters either all
 train or are all frozen; everything else takes the per-layer path of models/backbones/resnet.py.
 JDET_BOTTLENECK_FUSED=0 switches it off (A/B).
+Determinism: with the own weight gradients (JDET_BOTTLENECK_WGRAD=own, the default) the K chunks of a layer meet in the
+gradient buffer by float atomics, so the backbone's weight gradients differ in the last bits from run to run;
+JDET_BOTTLENECK_WGRAD=lib takes the library's kernels instead (bitwise reproducible where the library is).
 """
 import ctypes
 import os
@@ -251,11 +254,53 @@ def _block_convs(blk):
     return convs
 
 
+# The fused backward never stores a conv output: x-hat is recovered as (y - beta) / gamma wherever y > 0, so the BatchNorm
+# weight gradient carries an error of about ulp(y) / |gamma| per element -- harmless at the usual gammas, unbounded as a
+# gamma approaches 0 (dead channels of a pretrained ResNet, gammas shrunk by weight decay), and the fused gradient clip
+# would then scale EVERY gradient of the model by the poisoned norm (advisor finding, round 5).  Blocks holding a
+# BatchNorm weight under GAMMA_MIN in magnitude take the per-layer path (which keeps the conv outputs).  The check is one
+# device reduction + one host read for the whole backbone, made when the bank is built and every GAMMA_CHECK_EVERY
+# training forwards after that (never inside a graph capture): gammas move by lr * grad per step, not by orders of
+# magnitude.
+GAMMA_MIN = 1e-3
+GAMMA_CHECK_EVERY = 200
+_SMALL_GAMMA = weakref.WeakSet()          # Bottleneck modules currently routed to the per-layer path
+_gamma_clock = [0]
+
+
+def _block_bns(blk):
+    bns = [blk.bn1, blk.bn2, blk.bn3]
+    if blk.downsample is not None:
+        bns.append(blk.downsample[1])
+    return bns
+
+
+def check_gammas(blocks):
+    """refresh _SMALL_GAMMA for these blocks (one host synchronisation)"""
+    blocks = [b for b in blocks if all(isinstance(bn, nn.BatchNorm2d) and bn.affine for bn in _block_bns(b))]
+    if not blocks:
+        return
+    mins = torch.stack([torch.stack([bn.weight.detach().abs().min() for bn in _block_bns(b)]).min() for b in blocks])
+    for b, m in zip(blocks, mins.cpu().tolist()):
+        if m < GAMMA_MIN:
+            _SMALL_GAMMA.add(b)
+        else:
+            _SMALL_GAMMA.discard(b)
+
+
 def prepare(blocks):
     """once per training forward of a backbone: one bank for all fusable trainable blocks, refreshed in one launch"""
     blocks = [b for b in blocks if _trainable(b) is True and all(
         c.weight.is_cuda and c.weight.dtype == torch.float32 and c.weight.permute(0, 2, 3, 1).is_contiguous()
         for c in _block_convs(b))]
+    if not blocks:
+        return
+    if not torch.cuda.is_current_stream_capturing():
+        fresh = _BANKS.get(blocks[0]) is None
+        if fresh or _gamma_clock[0] % GAMMA_CHECK_EVERY == 0:
+            check_gammas(blocks)
+        _gamma_clock[0] += 1
+    blocks = [b for b in blocks if b not in _SMALL_GAMMA]
     if not blocks:
         return
     bank = _BANKS.get(blocks[0])
@@ -326,6 +371,8 @@ def fusable(blk, x):
     grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in _params(blk)))
     if grad and _trainable(blk) is not True:
         return False          # gradients through a frozen or partly frozen block: the per-layer path
+    if grad and blk in _SMALL_GAMMA:
+        return False          # a BatchNorm weight too close to 0 for x-hat = (y - beta) / gamma (see GAMMA_MIN)
     return True
 
 
@@ -355,6 +402,9 @@ class _BottleneckFunction(torch.autograd.Function):
         xn = x.permute(0, 2, 3, 1)
         y1, y2, y3, idn = _forward(blk, xn)
         ctx.blk = blk
+        # the backward reads the weights / BatchNorm tensors LIVE from the module (nothing is copied): remember their
+        # versions so that an in-place update between forward and backward raises as it would for a saved tensor
+        ctx.versions = tuple(p._version for p in params)
         # the block's slices of the step's weight-gradient buffer, claimed at forward time: this node's backward is the
         # only writer of these views
         ctx.gws = _bank(blk).claim_grad(_block_convs(blk)) if OWN_WGRAD else None
@@ -365,6 +415,9 @@ class _BottleneckFunction(torch.autograd.Function):
     def backward(ctx, gout):
         blk = ctx.blk
         x, y1, y2, y3, idn = ctx.saved_tensors
+        if tuple(p._version for p in _params(blk)) != ctx.versions:
+            raise RuntimeError("a parameter of this Bottleneck was modified in place between its forward and its backward "
+                               "(optimizer step / load_state_dict / EMA swap): the fused backward reads the live weights")
         xn = x.permute(0, 2, 3, 1)
         g = gout.permute(0, 2, 3, 1)
         if not g.is_contiguous():

@@ -97,7 +97,8 @@ class DCN_V2_POOLING(torch.autograd.Function):
         L.need_device(input, rois)
         part_size = pooled_size if part_size is None else part_size
         no_trans = int(bool(no_trans))
-        x, r = L.f32c(input), L.f32c(rois)
+        from ._roi_common import to_nhwc
+        x, r = to_nhwc(input), L.f32c(rois)          # channels-last memory: a bin's channels are one contiguous vector
         t = None if no_trans else L.f32c(offset)
         N, C, H, W = x.shape
         R = r.shape[0]
@@ -106,7 +107,8 @@ class DCN_V2_POOLING(torch.autograd.Function):
         tch = 2 if no_trans else t.shape[1]
         if not no_trans and (t.dim() != 4 or t.shape[0] != R or tuple(t.shape[2:]) != (part_size, part_size)):
             raise ValueError("offset must be (R, 2*classes, part, part), got %r" % (tuple(t.shape),))
-        out = torch.empty((R, output_dim, pooled_size, pooled_size), dtype=torch.float32, device=x.device)
+        out = torch.empty((R, output_dim, pooled_size, pooled_size), dtype=torch.float32, device=x.device,
+                          memory_format=torch.channels_last)       # (R, P, P, output_dim) in memory
         cnt = torch.empty_like(out)
         ctx.args = (N, C, H, W, R, no_trans, float(spatial_scale), int(output_dim), int(group_size), int(pooled_size),
                     int(part_size), int(sample_per_part), float(trans_std), int(tch))
@@ -119,8 +121,8 @@ class DCN_V2_POOLING(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         x, r, t, cnt = ctx.saved_tensors
-        go = L.f32c(grad_output)
-        gi = torch.empty_like(x)
+        go = grad_output.float().contiguous(memory_format=torch.channels_last)
+        gi = torch.empty_like(x)                      # channels-last, as x
         gt = torch.empty(ctx.trans_shape, dtype=torch.float32, device=x.device) if ctx.trans_shape else None
         L.check(L.lib().jdet_deform_psroi_pool_backward(L.ptr(go), L.ptr(cnt), L.ptr(x), L.ptr(r), L.ptr(t), *ctx.args,
                                                         L.ptr(gi), L.ptr(gt), L.stream_ptr(x)),

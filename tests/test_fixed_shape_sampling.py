@@ -159,3 +159,32 @@ def test_list_shaped_sampler_interface_draws_through_the_fixed_shape_sampler(cls
     # a gt sampled as a positive carries its own label
     own = out.pos_inds < k
     assert torch.equal(out.pos_gt_labels[own], (out.pos_inds[own] + 100).to(out.pos_gt_labels.dtype))
+
+
+def test_subclass_hooks_and_compatibility_surface():
+    """advisor findings (round 5): a config-registered subclass that overrides `_sample_pos` / `_sample_neg` (the
+    reference's extension points, sampler.py:L52-58) is sampled through them; `RandomSampler.random_choice` exists; a flat
+    (1-D) box is accepted"""
+    from types import SimpleNamespace
+
+    from jdet_amd.models.boxes.sampler import RandomSampler
+
+    class FirstK(RandomSampler):
+        def _sample_pos(self, assign_result, num_expected, **kwargs):
+            return torch.nonzero(assign_result.gt_inds > 0)[:, 0][:num_expected]
+
+        def _sample_neg(self, assign_result, num_expected, **kwargs):
+            return torch.nonzero(assign_result.gt_inds == 0)[:, 0][:num_expected]
+
+    gi = torch.tensor([0, 1, 2, 0, 0, 1, -1, 0, 2, 0])
+    res = SimpleNamespace(gt_inds=gi, labels=None, add_gt_=lambda labels: None)
+    boxes = torch.arange(40, dtype=torch.float32).view(10, 4)
+    s = FirstK(num=4, pos_fraction=0.5, add_gt_as_proposals=False).sample(res, boxes, boxes[:2])
+    assert s.pos_inds.tolist() == [1, 2] and s.neg_inds.tolist() == [0, 3]
+    picked = RandomSampler.random_choice(torch.arange(100), 10)
+    assert picked.numel() == 10 and picked.unique().numel() == 10
+    assert len(RandomSampler.random_choice(list(range(20)), 5)) == 5
+    one = RandomSampler(num=4, pos_fraction=0.5, add_gt_as_proposals=False).sample(
+        SimpleNamespace(gt_inds=torch.tensor([1]), labels=None, add_gt_=lambda labels: None), torch.tensor([1., 2., 3., 4.]),
+        torch.tensor([[1., 2., 3., 4.]]))
+    assert one.pos_inds.tolist() == [0]

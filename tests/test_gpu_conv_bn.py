@@ -337,3 +337,49 @@ def test_fused_bottleneck_replays_as_a_hip_graph(dev):
         torch.cuda.synchronize()
         for a, b in zip(got, ref):
             assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, seed
+
+
+@pytest.mark.parametrize("gamma", [1e-6, 0.0])
+def test_tiny_batchnorm_weight_routes_the_block_to_the_per_layer_path(dev, gamma):
+    """advisor finding (round 5): the fused backward recovers x-hat as (y - beta) / gamma -- a dead channel (gamma ~ 0) would
+    put inf / NaN (or ulp(y) / |gamma|) into dgamma and, through the fused gradient clip, into every gradient of the
+    model.  prepare() looks at the BatchNorm weights when the bank is built (and every GAMMA_CHECK_EVERY forwards) and
+    sends such blocks through the per-layer path: all gradients finite and equal to the per-layer path's."""
+    from jdet_amd.models.backbones.resnet import Resnet50
+    from jdet_amd.ops import conv_bn as CB
+    torch.manual_seed(5)
+    m = Resnet50(return_stages=["layer2", "layer3"], frozen_stages=1, norm_eval=True).to(dev).train()
+    for p in m.parameters():
+        if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+            p.data = p.data.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        m.layer2[1].bn2.weight[7] = gamma            # one dead channel in one block
+        m.layer3[0].bn3.weight[100] = -gamma
+    x = torch.randn(2, 3, 96, 96, device=dev).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        CB.ENABLED = fused
+        CB._gamma_clock[0] = 0                         # the first forward of a run checks
+        try:
+            m.zero_grad(set_to_none=True)
+            outs = m(x)
+            torch.autograd.backward(outs, [torch.ones_like(o) for o in outs])
+            res.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+            if fused:
+                assert m.layer2[1] in CB._SMALL_GAMMA and m.layer3[0] in CB._SMALL_GAMMA
+                assert m.layer2[0] not in CB._SMALL_GAMMA and not CB.fusable(m.layer2[1], outs[0].detach().new_zeros(
+                    (2, 512, 12, 12)).contiguous(memory_format=torch.channels_last).requires_grad_(True))
+        finally:
+            CB.ENABLED = True
+    a, b = res
+    for n in a:
+        assert torch.isfinite(a[n]).all(), n
+        rel = float((a[n] - b[n]).norm() / (b[n].norm() + 1e-12))
+        assert rel <= 2e-2, (n, rel)
+    # the weights recover: the next check hands the blocks back to the fused path
+    with torch.no_grad():
+        m.layer2[1].bn2.weight[7] = 0.5
+        m.layer3[0].bn3.weight[100] = 0.5
+    CB._gamma_clock[0] = 0
+    m(x)
+    assert m.layer2[1] not in CB._SMALL_GAMMA and m.layer3[0] not in CB._SMALL_GAMMA

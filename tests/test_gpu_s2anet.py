@@ -179,3 +179,46 @@ def test_packed_small_levels_equal_the_per_level_path(dev):
     for a, b in zip(got_out + got_grad, ref_out + ref_grad):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+
+def test_side_stream_branch_gives_the_single_stream_gradients(dev, monkeypatch):
+    """advisor finding (round 5): the packed levels run on a side stream under parameter ALIASES (a private torch helper);
+    outputs and every gradient must equal the single-stream execution (JDET_HEAD_STREAMS=0), and a torch without the
+    helper takes the single-stream path instead of failing"""
+    import jdet_amd.models  # noqa: F401
+    from jdet_amd.models.roi_heads import s2anet_head as SH
+    torch.manual_seed(1)
+    head = SH.S2ANetHead(num_classes=16, in_channels=32, feat_channels=32, stacked_convs=2, with_orconv=True,
+                         anchor_strides=[8, 16, 32, 64, 128]).to(dev)
+    head.train()
+    head.pack_max_positions = 1024
+    sizes = [(40, 40), (20, 20), (10, 10), (5, 5), (3, 3)]
+    feats = [torch.randn(2, 32, h, w, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for h, w in sizes]
+
+    def run():
+        for f in feats:
+            f.grad = None
+        head.zero_grad()
+        outs = head._level_outputs(feats)
+        total = sum((o.float() ** 2).sum() * (0.5 + k) for k, group in enumerate(outs) for o in group
+                    if o is not None and o.requires_grad)
+        total.backward()
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for group in outs for o in group if o is not None],
+                [f.grad.clone() for f in feats] + [p.grad.clone() for p in head.parameters() if p.grad is not None])
+
+    monkeypatch.setattr(SH, "HEAD_STREAMS", True)
+    SH._SIDE.clear()
+    a = run()
+    assert len(SH._SIDE) == 1, "the packed levels did not take the side stream"
+    monkeypatch.setattr(SH, "HEAD_STREAMS", False)
+    b = run()
+    monkeypatch.setattr(SH, "HEAD_STREAMS", True)
+    monkeypatch.setattr(SH, "_reparametrize_module", None)      # a torch without the private helper
+    SH._SIDE.clear()
+    c = run()
+    assert len(SH._SIDE) == 0
+    for other in (a, c):
+        for u, v in zip(other[0] + other[1], b[0] + b[1]):
+            torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5 * max(1.0, float(v.abs().max())))
