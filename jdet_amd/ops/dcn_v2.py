@@ -274,7 +274,7 @@ class DCNPooling(DCNv2Pooling):
             return self._pool(input, rois, offset, self.no_trans)
         n = rois.shape[0]
         roi = self._pool(input, rois, offset, True)
-        offset_mask = self.offset_mask_fc(roi.view(n, -1)).view(n, 3, self.pooled_size, self.pooled_size)
+        offset_mask = self.offset_mask_fc(roi.reshape(n, -1)).view(n, 3, self.pooled_size, self.pooled_size)
         o1, o2, mask = torch.chunk(offset_mask, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)
         mask = torch.sigmoid(mask)
