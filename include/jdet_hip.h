@@ -447,6 +447,23 @@ size_t jdet_channel_sum_workspace(long P, int C);
 int jdet_channel_sum(const float* x_nhwc, long P, int C, float* sums, void* workspace, size_t workspace_bytes,
                      jdet_stream_t stream);
 
+/* Graph-safe forms of two framework operations (csrc/graph_safe.hip): plain kernels where the framework records a memset
+ * node into a captured step (memset nodes do not reliably re-execute on replay on this stack).
+ *   jdet_zero_fill   : bytes % 4 == 0, p 4-byte aligned (`tensor.zero_()` / `torch.zeros` of a large tensor)
+ *   jdet_sum_squares : out[0] = sum x[i]^2 (take_sqrt: its square root = the 2-norm) of a 16-byte aligned fp32 buffer --
+ *                      the gradient norm of the clip in optims/optimizer.py:L26-36 (SGD.pre_step); float64 accumulation in
+ *                      a fixed order over at most 1024 partial sums (bitwise reproducible); workspace:
+ *                      jdet_sum_squares_workspace() bytes, 8-byte aligned, any content. */
+int jdet_zero_fill(void* p, size_t bytes, jdet_stream_t stream);
+/* Post-capture pass over a hipGraph_t that has NOT been instantiated yet: every memset node (the framework's reduction
+ * semaphores, the convolution library's zero fills of atomically adding solvers -- whichever its benchmark picked at
+ * capture time) becomes a kernel node with the same destination, pattern, extent, dependencies and dependents.
+ * *n_replaced (optional): how many.  Runner's graph mode runs it on every captured step (keep_graph capture). */
+int jdet_graph_replace_memset_nodes(void* hip_graph, int* n_replaced);
+size_t jdet_sum_squares_workspace(void);
+int jdet_sum_squares(const float* x, size_t n, int take_sqrt, float* out, void* workspace, size_t workspace_bytes,
+                     jdet_stream_t stream);
+
 /* Active rotating filter.  Replace orn.py:L260-269 (arf_forward) and L271-281 (arf_backward).
  * weight (nOut,nIn,nOri,kH,kW); indices (nOri,kH,kW,nRot) uint8 1-based;
  * out (nOut*nRot, nIn*nOri, kH, kW). */

@@ -57,6 +57,10 @@ SIGNATURES = {
     "jdet_nms_rotated": (_i, [_p, _i, _i, _p, _f, _i, _i, _p, _p, _sz, _p]),
     "jdet_upsample_add_nhwc_forward": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
     "jdet_upsample_add_nhwc_backward": (_i, [_p, _i, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "jdet_zero_fill": (_i, [_p, _sz, _p]),
+    "jdet_graph_replace_memset_nodes": (_i, [_p, ctypes.POINTER(ctypes.c_int)]),
+    "jdet_sum_squares_workspace": (_sz, []),
+    "jdet_sum_squares": (_i, [_p, _sz, _i, _p, _p, _sz, _p]),
     "jdet_normalize_u8_nhwc": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "jdet_feature_refine_forward": (_i, [_p, _p, _i, _i, _i, _i, _f, _i, _p, _p]),
     "jdet_feature_refine_backward_workspace": (_sz, [_i] * 5),
@@ -211,3 +215,41 @@ def vecn(v, n):
 
 def ptr(t):
     return t.data_ptr() if t is not None and t.numel() > 0 else None
+
+
+def zero_(t):
+    """t.zero_() as a plain kernel (jdet_zero_fill): the framework's form records a memset node for large tensors, and
+    memset nodes do not reliably re-execute when a captured step is replayed (csrc/graph_safe.hip).  t: a dense fp32 /
+    int32 / ... device tensor whose byte size is a multiple of 4."""
+    need_device(t)
+    nbytes = t.numel() * t.element_size()
+    if nbytes % 4 or not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        return t.zero_()
+    check(lib().jdet_zero_fill(ptr(t), nbytes, stream_ptr(t)), "jdet_zero_fill")
+    return t
+
+
+def norm2(flat, ws=None):
+    """2-norm of a dense fp32 device tensor as a 0-dim tensor (jdet_sum_squares: two plain kernels, fixed summation order)"""
+    need_device(flat)
+    n = flat.numel()
+    wsb = lib().jdet_sum_squares_workspace()
+    if ws is None:
+        ws = torch.empty((wsb,), dtype=torch.uint8, device=flat.device)
+    out = torch.empty((1,), dtype=torch.float32, device=flat.device)
+    check(lib().jdet_sum_squares(ptr(flat), n, 1, ptr(out), ptr(ws), ws.numel(), stream_ptr(flat)), "jdet_sum_squares")
+    return out[0]
+
+
+def new_graph():
+    """a torch CUDAGraph whose hipGraph_t stays editable until its first replay (keep_graph)"""
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def harden_graph(g):
+    """run right after capture, before the first replay: memset nodes -> fill-kernel nodes
+    (jdet_graph_replace_memset_nodes); returns how many were replaced"""
+    n = ctypes.c_int(0)
+    check(lib().jdet_graph_replace_memset_nodes(ctypes.c_void_p(g.raw_cuda_graph()), ctypes.byref(n)),
+          "jdet_graph_replace_memset_nodes")
+    return n.value

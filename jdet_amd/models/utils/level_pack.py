@@ -97,8 +97,12 @@ class LevelPack:
         return self._canvas_like(like.shape[0], channels, like.dtype, like.device, cl)
 
     def _canvas_like(self, batch, channels, dtype, device, channels_last):
-        return torch.empty((batch, channels, self.height, self.width), dtype=dtype, device=device,
-                           memory_format=torch.channels_last if channels_last else torch.contiguous_format).zero_()
+        canvas = torch.empty((batch, channels, self.height, self.width), dtype=dtype, device=device,
+                             memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        if canvas.is_cuda and canvas.element_size() == 4:
+            from jdet_amd import _lib as L
+            return L.zero_(canvas)      # a plain kernel: the framework zero-fills a tensor of this size with a memset (node)
+        return canvas.zero_()
 
     def _slices(self, y):
         return [y[:, :, r0:r0 + h, c0:c0 + w] for (h, w), (r0, c0) in zip(self.sizes, self.places)]

@@ -13,6 +13,8 @@ import time
 
 import numpy as np
 import torch
+
+from jdet_amd import _lib as L
 import torch.distributed as dist
 
 import jdet_amd.models  # noqa: F401  (registers MODELS / BACKBONES / NECKS / HEADS / LOSSES / BOXES)
@@ -83,14 +85,15 @@ class Runner:
         self.scheduler = build_from_cfg(dict(sch_cfg), SCHEDULERS, optimizer=self.optimizer) if sch_cfg else None
         use_ddp = self.world_size > 1 if ddp is None else ddp
         self.train_model = self.model
-        if self.use_graph and self.world_size > 1 and os.environ.get("JDET_TRAIN_GRAPH_MULTI", "0") != "1":
-            # Multi-rank HIP-graph steps are refused (round 4): with two ranks the replayed step
-            # intermittently produced a garbage weight gradient for ONE backbone convolution (the library's split-K
-            # weight-gradient path; every kernel of this repo, the update graph and the all-reduce hand-over were
-            # cleared by scripts/ddp_graph_diag.py / graph_replay_diag.py).  Eager DDP (bucketed, overlapped) is the
-            # multi-rank path; JDET_TRAIN_GRAPH_MULTI=1 re-enables the graph step for diagnosis.
+        if self.use_graph and self.world_size > 1 and os.environ.get("JDET_TRAIN_GRAPH_MULTI", "1") == "0":
+            # Multi-rank HIP-graph steps were refused in rounds 4-5: a replayed step intermittently carried garbage
+            # gradients out of memset NODES that do not reliably re-execute (the library's split-K weight-gradient zero
+            # fills, the framework's reduction semaphores).  Since round 6 every captured graph is stripped of memset
+            # nodes before instantiation (L.harden_graph, csrc/graph_safe.hip) and two-rank graph steps are clean in the
+            # diagnosis runs (profiles/r06_graph_notes.md) and strict in tests/test_gpu_ddp_detectors.py;
+            # JDET_TRAIN_GRAPH_MULTI=0 keeps the old behaviour (eager DDP steps under world_size > 1).
             if self.rank == 0:
-                print("jdet_amd.Runner: HIP-graph mode is single-rank only; %d ranks -> eager DDP steps" % self.world_size)
+                print("jdet_amd.Runner: JDET_TRAIN_GRAPH_MULTI=0 -- %d ranks -> eager DDP steps" % self.world_size)
             self.use_graph = False
         if self.use_graph and self.device.type == "cuda":
             use_ddp = False    # graph mode all-reduces one flat gradient buffer itself
@@ -150,7 +153,7 @@ class Runner:
         clip = opt.grad_clip
 
         def fwd_bwd():
-            flat.zero_()
+            L.zero_(flat)          # a plain kernel, not a memset node
             if self.amp_dtype is not None:
                 with torch.autocast(device_type="cuda", dtype=self.amp_dtype):
                     losses = self.model(st["images"], st["targets"])
@@ -163,7 +166,12 @@ class Runner:
         @torch.no_grad()
         def update():
             if clip is not None:   # torch.nn.utils.clip_grad_norm_ on the flat buffer: two kernels
-                norm = torch.linalg.vector_norm(flat, float(clip.get("norm_type", 2)))
+                if float(clip.get("norm_type", 2)) == 2.0:
+                    # own two-stage sum (csrc/graph_safe.hip): the framework's vector_norm is a multi-workgroup reduce
+                    # whose semaphores are cleared by a memset NODE in the captured graph (scripts/graph_nodes.py)
+                    norm = L.norm2(flat)
+                else:
+                    norm = torch.linalg.vector_norm(flat, float(clip.get("norm_type", 2)))
                 flat.mul_(torch.clamp(clip["max_norm"] / (norm + 1e-6), max=1.0))
             grads = [p.grad for p in params]
             if wd != 0:
@@ -180,11 +188,16 @@ class Runner:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         single = self.world_size == 1
-        g1 = torch.cuda.CUDAGraph()
+        # keep_graph: the captured hipGraph stays editable until its first replay -- every memset node in it (the
+        # framework's reduction semaphores, the convolution library's zero fills of its atomically adding solvers) is
+        # replaced by a fill-KERNEL node before instantiation (L.harden_graph): memset nodes do not reliably re-execute
+        # on replay on this stack, which is what made multi-rank graph steps produce garbage gradients in rounds 4-5
+        g1 = L.new_graph()
         with torch.cuda.graph(g1):
             st["out"] = fwd_bwd()
             if single:
                 update()
+        st["memset_nodes_replaced"] = L.harden_graph(g1)
         st["g1"] = g1
         if not single:
             mode = os.environ.get("JDET_GRAPH_UPDATE", "shared")     # diagnosis switch (scripts/ddp_graph_diag.py)
@@ -192,13 +205,14 @@ class Runner:
                 st["g2"] = None
                 st["update"] = update
             else:
-                g2 = torch.cuda.CUDAGraph()
+                g2 = L.new_graph()
                 if mode == "own":
                     with torch.cuda.graph(g2):
                         update()
                 else:
                     with torch.cuda.graph(g2, pool=g1.pool()):
                         update()
+                st["memset_nodes_replaced"] += L.harden_graph(g2)
                 st["g2"] = g2
         return st
 

@@ -4,8 +4,9 @@ tiles, gradients averaged over ranks before the update).  Asserted per config:
   * DDP eager: parameters bit-identical across ranks after every step, and equal to a single process that averages
     the two ranks' gradients by hand (the definition of the all-reduce) -- NOT to the loss of the concatenated batch:
     the detection losses are normalised per rank (sum over the rank's images of max(#pos, 1)), as in the reference;
-  * a HIP-graph request under world_size 2 falls back to eager DDP steps (graph mode is single-rank only): replicas
-    bit-identical through every step.
+  * HIP-graph steps under world_size 2 (un-refused in round 6: every captured graph is stripped of memset nodes before
+    instantiation, csrc/graph_safe.hip): two eager warm-up steps, one capture, 20 replays -- replicas bit-identical after
+    every step, parameters finite and moving; JDET_TRAIN_GRAPH_MULTI=0 still falls back to eager DDP.
 RCCL with more than one rank needs more than one GPU; the driver's 8-GPU run covers it."""
 import os
 import sys
@@ -34,6 +35,9 @@ def _seed_step(step, rank):
     torch.manual_seed(9000 + 10 * step + rank)       # the samplers' random keys (two-stage heads)
 
 
+REPLAYS = 20
+
+
 def _worker(rank, world, port, name, graph, out, size=SIZE):
     sys.path.insert(0, ROOT)
     import warnings
@@ -48,8 +52,10 @@ def _worker(rank, world, port, name, graph, out, size=SIZE):
         torch.manual_seed(1234)                       # identical replicas
         r = Runner(_cfg(name), device=dev, conv_autotune=False, graph=graph)
         assert r.world_size == world
+        if graph:
+            assert r.use_graph == (os.environ.get("JDET_TRAIN_GRAPH_MULTI", "1") != "0")
         history = [torch.cat([p.detach().reshape(-1) for p in r.model.parameters()])[::97].cpu()]
-        nsteps = STEPS + (3 if graph else 0)          # graph mode: two eager warm-up steps, one capture, replays
+        nsteps = (3 + REPLAYS) if graph else STEPS    # graph mode: two eager warm-up steps, one capture, replays
         for step in range(nsteps):
             _seed_step(step, rank)
             images, targets = _batch(step % STEPS if graph else step, rank, dev, size)
@@ -152,14 +158,26 @@ def test_two_ranks_ddp_with_the_side_stream_on(dev, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["s2anet", "orcnn"])
-def test_two_ranks_graph_request_runs_eager_ddp(dev, tmp_path, name):
-    """Runner(graph=True) under world_size 2: HIP-graph steps are single-rank only (with two ranks a replay
-    intermittently carried a garbage weight gradient out of the library's split-K path for one backbone convolution --
-    localised by scripts/ddp_graph_diag.py, not a kernel of this repo), so the request falls back to eager DDP steps.
-    The replicas must stay bit-identical through every step, as in the eager test."""
+def test_two_ranks_graph_mode_strict(dev, tmp_path, name):
+    """Runner(graph=True) under world_size 2 (round 6): the step is captured per rank, hardened (memset nodes -> kernels)
+    and replayed 20 times with one flat all-reduce between the backward graph and the update graph; the replicas must be
+    bit-identical after EVERY step (a garbage gradient on one rank -- rounds 4-5 -- breaks that at once), finite, and
+    moving."""
     port = 25000 + os.getpid() % 2000 + (7 if name == "orcnn" else 0)
     out = str(tmp_path / "g.pt")
     mp.spawn(_worker, args=(2, port, name, True, out), nprocs=2, join=True)
     got = torch.load(out)
-    assert len(got) == STEPS + 4 and all(torch.isfinite(h).all() for h in got)
+    assert len(got) == REPLAYS + 4 and all(torch.isfinite(h).all() for h in got)
     assert not torch.equal(got[3], got[-1])            # the steps moved the parameters
+    norms = [float(h.norm()) for h in got]
+    assert max(norms) < 1.5 * norms[0]                 # no blown-up update (the 7e4 parameters of round 5's captured update)
+
+
+def test_two_ranks_graph_refused_on_request(dev, tmp_path, monkeypatch):
+    """JDET_TRAIN_GRAPH_MULTI=0: a graph request under world_size 2 runs eager DDP steps (the behaviour of rounds 4-5)"""
+    monkeypatch.setenv("JDET_TRAIN_GRAPH_MULTI", "0")
+    port = 27000 + os.getpid() % 2000
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_worker, args=(2, port, "s2anet", True, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert all(torch.isfinite(h).all() for h in got) and not torch.equal(got[3], got[-1])
