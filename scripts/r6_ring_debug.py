@@ -1,0 +1,35 @@
+import os, subprocess, sys, tempfile
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import r6_ring_check as RC
+K = int(os.environ.get("CASE", "1"))
+def child(path):
+    from jdet_amd import _lib as L
+    lib = L.lib(); dev = torch.device("cuda:0")
+    variant, no, feat, rois, hw, scale = RC.cases()[K]
+    x = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last)
+    r = torch.from_numpy(rois).to(dev)
+    N, C, H, W = x.shape; R = r.shape[0]
+    out = torch.full((R, C) + tuple(hw), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+    wsb = lib.jdet_roi_align_forward_cl_workspace(R, hw[0], hw[1]); ws = torch.empty((wsb,), dtype=torch.uint8, device=dev)
+    L.check(lib.jdet_roi_align_forward_cl(variant, x.data_ptr(), N, C, H, W, r.data_ptr(), R, hw[0], hw[1], scale, 2, no, out.data_ptr(), ws.data_ptr(), wsb, L.stream_ptr(x)), "fwd")
+    torch.cuda.synchronize()
+    torch.save((out.cpu(), torch.from_numpy(rois)), path)
+if len(sys.argv) > 2 and sys.argv[1] == "--child":
+    child(sys.argv[2]); sys.exit(0)
+fs = []
+for gran in ("4", "256"):
+    f = tempfile.mktemp(suffix=".pt")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", f], env=dict(os.environ, JDET_ROI_FWD_GRAN=gran))
+    fs.append(f)
+(a, rois), (b, _) = torch.load(fs[0]), torch.load(fs[1])
+nb = a.shape[2] * a.shape[3]
+a = a.permute(0, 2, 3, 1).reshape(a.shape[0], nb, -1); b = b.permute(0, 2, 3, 1).reshape(b.shape[0], nb, -1)
+nbad = 0
+for r in range(a.shape[0]):
+    bad = [(bin_, int((a[r, bin_] != b[r, bin_]).sum()), float(a[r, bin_, 0]), float(b[r, bin_, 0])) for bin_ in range(nb) if not torch.equal(a[r, bin_], b[r, bin_])]
+    if bad and nbad < 12:
+        nbad += 1
+        print("roi", r, rois[r].tolist(), "bad bins:", len(bad), bad[:6])

@@ -511,3 +511,4 @@ def test_autograd_uses_the_plan_and_matches_without_it(dev, fwd_mode):
     ref = O.roi_align_backward(O.V_ROT, grad.cpu().numpy(), rois, feat.shape, scale, 2)
     for g in outs:
         np.testing.assert_allclose(g, ref, rtol=0, atol=BWD_ATOL * max(1.0, np.abs(ref).max()))
+
