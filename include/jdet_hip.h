@@ -407,6 +407,38 @@ int jdet_smooth_l1_loss(const float* pred, const float* target, const float* wei
                         float* loss_sum, float* grad_pred, void* workspace, size_t workspace_bytes,
                         jdet_stream_t stream);
 
+/* The per-level loss call of a dense head as one node (round 6): what models/roi_heads/s2anet_head.py:L430-508
+ * (loss_fam_single / loss_odm_single) composes per pyramid level from reshape + loss + `/ avg_factor` + `* loss_weight`
+ * (models/losses/focal_loss.py:L50-53, L86-93; smooth_l1_loss.py:L18-22, L47-53).
+ *   - labels / weight / target are read through a BLOCKED row index: logical row r is element
+ *     (r / rows_per_block) * block_stride + r % rows_per_block (in rows) of the array -- a level's column window
+ *     [:, s:e] of the per-image (N, A[, 5]) target arrays is rows_per_block = e - s, block_stride = A, base + s; a
+ *     contiguous array is rows_per_block >= M, any stride.  logits / pred and the gradients are contiguous.
+ *   - avg_factor: DEVICE scalar; *loss = (sum / *avg_factor) * loss_weight; grad_* = d sum / d input (the UNIT gradient).
+ *   - jdet_loss_grad_scale: out[i] = unit_grad[i] * ((*grad_out * loss_weight) / *avg_factor): the backward of the node.
+ * Same operations in the same order as the composition: bit-identical to it.  Workspace: the focal-loss query. */
+int jdet_sigmoid_focal_loss_level(const float* logits, const int32_t* labels, long label_rows_per_block,
+                                  long label_block_stride, const float* weight, long weight_rows_per_block,
+                                  long weight_block_stride, long M, int C, float alpha, float gamma,
+                                  const float* avg_factor, float loss_weight, float* loss, float* grad_logits,
+                                  void* workspace, size_t workspace_bytes, jdet_stream_t stream);
+int jdet_smooth_l1_loss_level(const float* pred, const float* target, long target_rows_per_block,
+                              long target_block_stride, const float* weight, long weight_rows_per_block,
+                              long weight_block_stride, long rows, int E, float beta, const float* avg_factor,
+                              float loss_weight, float* loss, float* grad_pred, void* workspace,
+                              size_t workspace_bytes, jdet_stream_t stream);
+int jdet_loss_grad_scale(const float* unit_grad, long n, const float* grad_out, const float* avg_factor,
+                         float loss_weight, float* out, jdet_stream_t stream);
+
+/* Head glue as a single pass (csrc/level_pack.hip; round 6).
+ * jdet_level_pack_nhwc: the small pyramid levels of a weight-shared tower (S2ANetHead.execute runs its towers per level,
+ *   models/roi_heads/s2anet_head.py:L207-252; here they run once on a packed canvas) -- levels[l] (N, h_l, w_l, C)
+ *   contiguous DEVICE pointers in a HOST array (NULL = a window of zeros), level_hw / level_place HOST arrays of
+ *   (h, w) / (row, col) per level; every word of canvas (N, Hp, Wp, C) is written: the level's value inside its window,
+ *   0 in the gaps.  num_levels <= 8, C % 4 == 0.  Also the backward of the unpacking (level gradients -> canvas gradient). */
+int jdet_level_pack_nhwc(const float* const* levels, const int32_t* level_hw, const int32_t* level_place, int num_levels,
+                         int N, int C, int Hp, int Wp, float* canvas, jdet_stream_t stream);
+
 /* AlignConv.get_offset (models/roi_heads/s2anet_head.py:L676-713): anchors (N, H*W, 5) [xc,yc,w,h,theta] in image
  * coordinates -> offset (N, 2*k*k, H, W), (dy, dx) per tap of the k x k kernel (k odd). */
 int jdet_align_conv_offset(const float* anchors, int N, int H, int W, float stride, int kernel_size,

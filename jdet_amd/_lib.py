@@ -101,6 +101,10 @@ SIGNATURES = {
     "jdet_sigmoid_focal_loss_workspace": (_sz, []),
     "jdet_sigmoid_focal_loss": (_i, [_p, _p, _p, _l, _i, _f, _f, _p, _p, _p, _sz, _p]),
     "jdet_smooth_l1_loss": (_i, [_p, _p, _p, _l, _f, _p, _p, _p, _sz, _p]),
+    "jdet_sigmoid_focal_loss_level": (_i, [_p, _p, _l, _l, _p, _l, _l, _l, _i, _f, _f, _p, _f, _p, _p, _p, _sz, _p]),
+    "jdet_smooth_l1_loss_level": (_i, [_p, _p, _l, _l, _p, _l, _l, _l, _i, _f, _p, _f, _p, _p, _p, _sz, _p]),
+    "jdet_loss_grad_scale": (_i, [_p, _l, _p, _p, _f, _p, _p]),
+    "jdet_level_pack_nhwc": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "jdet_align_conv_offset": (_i, [_p, _i, _i, _i, _f, _i, _p, _p]),
     "jdet_frozen_bn_act_forward": (_i, [_p, _p, _l, _i, _p, _p, _p, _p, _f, _i, _p, _p]),
     "jdet_frozen_bn_act_backward_workspace": (_sz, [_l, _i]),

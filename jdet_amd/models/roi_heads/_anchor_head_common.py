@@ -50,12 +50,19 @@ class RotatedAnchorHeadMixin:
 
     def _loss_single(self, loss_cls_fn, loss_bbox_fn, cls_score, bbox_pred, anchors, labels, label_weights,
                      bbox_targets, bbox_weights, num_total_samples, cfg):
-        labels = labels.reshape(-1)
-        label_weights = label_weights.reshape(-1)
+        # The level's targets are column windows [:, s:e] of the per-image arrays.  FocalLoss / SmoothL1Loss / L1Loss read
+        # such windows in place (one node per level and loss, models/losses/focal_loss.py: _FocalLevel); flattening them
+        # here -- what the reference does, s2anet_head.py:L441-450 -- costs a copy per window (40 per S2ANet step).
+        from jdet_amd.models.losses.focal_loss import FocalLoss
+        from jdet_amd.models.losses.smooth_l1_loss import L1Loss, SmoothL1Loss
+        if not isinstance(loss_cls_fn, FocalLoss):
+            labels = labels.reshape(-1)
+            label_weights = label_weights.reshape(-1)
         cls_score = cls_score.permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
         loss_cls = loss_cls_fn(cls_score, labels, label_weights, avg_factor=num_total_samples)
-        bbox_targets = bbox_targets.reshape(-1, 5)
-        bbox_weights = bbox_weights.reshape(-1, 5)
+        if not isinstance(loss_bbox_fn, (SmoothL1Loss, L1Loss)) or cfg.get("reg_decoded_bbox", False):
+            bbox_targets = bbox_targets.reshape(-1, 5)
+            bbox_weights = bbox_weights.reshape(-1, 5)
         bbox_pred = bbox_pred.permute(0, 2, 3, 1).reshape(-1, 5)
         if cfg.get("reg_decoded_bbox", False):
             bbox_coder_cfg = cfg.get("bbox_coder", "")

@@ -20,7 +20,10 @@ from jdet_amd.models.boxes.anchor_target import anchor_target, images_to_levels
 from jdet_amd.models.boxes.box_ops import delta2bbox_rotated
 from jdet_amd.models.utils.level_pack import LevelPack
 
-HEAD_STREAMS = os.environ.get("JDET_HEAD_STREAMS", "1") == "1"
+# Packed small levels on a side stream next to the big levels.  Default OFF since round 6: the parameter aliases the side
+# branch needs cost 26 gradient-accumulation launches per step, and with the head's glue gone the overlap no longer pays
+# for them (same-box A/B, 3 pairs: 27.26 ms off / 27.37 ms on; profiles/r06_glue.md).  JDET_HEAD_STREAMS=1 switches it on.
+HEAD_STREAMS = os.environ.get("JDET_HEAD_STREAMS", "0") == "1"
 # the pack's gap mask inside the tower convs' epilogue instead of a multiplication per layer and direction (A/B switch)
 FUSED_PACK_MASK = os.environ.get("JDET_PACK_FUSED_MASK", "1") == "1"
 _SIDE = {}

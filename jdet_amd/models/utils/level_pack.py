@@ -10,6 +10,7 @@ import os
 import torch
 
 PACK_FUNCTIONS = os.environ.get("JDET_PACK_FUNCTIONS", "1") == "1"      # A/B switch (see _Pack / _Unpack)
+FUSED_PACK = os.environ.get("JDET_PACK_FUSED_FILL", "1") == "1"          # canvas + windows in one kernel (A/B switch)
 
 
 class LevelPack:
@@ -104,6 +105,34 @@ class LevelPack:
             return L.zero_(canvas)      # a plain kernel: the framework zero-fills a tensor of this size with a memset (node)
         return canvas.zero_()
 
+    def fill(self, xs, batch, channels, dtype, device):
+        """the canvas with level i's window = xs[i] (None: zeros) and zero gaps.  fp32 channels-last device maps with
+        C % 4 == 0: ONE kernel writes every word of the canvas once (csrc/level_pack.hip); otherwise a zero canvas + one
+        window copy per level."""
+        import ctypes
+        canvas = torch.empty((batch, channels, self.height, self.width), dtype=dtype, device=device,
+                             memory_format=torch.channels_last)
+        fused = FUSED_PACK and canvas.is_cuda and dtype == torch.float32 and channels % 4 == 0 and len(self.sizes) <= 8
+        if fused:
+            from jdet_amd import _lib as L
+            keep = []
+            for x in xs:
+                if x is not None and not (x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+                    x = x.to(torch.float32).contiguous(memory_format=torch.channels_last)
+                keep.append(x)
+            n = len(self.sizes)
+            ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() if x is not None else None for x in keep])
+            hw = (ctypes.c_int32 * (2 * n))(*[v for s in self.sizes for v in s])
+            place = (ctypes.c_int32 * (2 * n))(*[v for pl in self.places for v in pl])
+            L.check(L.lib().jdet_level_pack_nhwc(ptrs, hw, place, n, batch, channels, self.height, self.width,
+                                                 canvas.data_ptr(), L.stream_ptr(canvas)), "jdet_level_pack_nhwc")
+            return canvas
+        canvas = self._canvas_like(batch, channels, dtype, device, True)
+        for x, dst in zip(xs, self._slices(canvas)):
+            if x is not None:
+                dst.copy_(x)
+        return canvas
+
     def _slices(self, y):
         return [y[:, :, r0:r0 + h, c0:c0 + w] for (h, w), (r0, c0) in zip(self.sizes, self.places)]
 
@@ -128,7 +157,10 @@ class _Pack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pack, *xs):
         ctx.pack = pack
-        out = pack._canvas(xs[0], xs[0].shape[1])
+        x0 = xs[0]
+        if x0.dim() == 4 and x0.is_contiguous(memory_format=torch.channels_last):
+            return pack.fill(xs, x0.shape[0], x0.shape[1], x0.dtype, x0.device)
+        out = pack._canvas(x0, x0.shape[1])
         for x, dst in zip(xs, pack._slices(out)):
             dst.copy_(x)
         return out
@@ -152,6 +184,8 @@ class _Unpack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         shape, dtype, device, cl = ctx.like
+        if cl:
+            return None, ctx.pack.fill(grads, shape[0], shape[1], dtype, device)
         g = ctx.pack._canvas_like(shape[0], shape[1], dtype, device, cl)
         for gl, dst in zip(grads, ctx.pack._slices(g)):
             if gl is not None:

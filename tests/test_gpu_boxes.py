@@ -251,6 +251,46 @@ def test_fused_smooth_l1_matches_tensor_program(dev):
     torch.testing.assert_close(a, smooth_l1_loss(q.detach(), torch.zeros(10, 5, device=dev), beta=1.0), rtol=1e-5, atol=1e-6)
 
 
+def test_level_loss_nodes_equal_the_composition_bit_for_bit(dev):
+    """Round 6: one autograd node per (pyramid level, loss) -- targets read in place through their column windows of the
+    per-image arrays, `/ avg_factor` and `* loss_weight` inside the finishing launch, one scaling launch in backward
+    (jdet_*_loss_level, jdet_loss_grad_scale) -- against what it replaces: window.reshape(-1) copies + the fused sum +
+    two scalar ops (+ three in backward).  Same operations in the same order: loss and gradient EQUAL."""
+    from jdet_amd.models.losses import focal_loss as FL
+    from jdet_amd.models.losses.smooth_l1_loss import L1Loss, SmoothL1Loss
+    rng = np.random.default_rng(11)
+    N, A, C = 3, 700, 15
+    labels = torch.from_numpy(rng.integers(0, C + 1, (N, A)).astype(np.int32)).to(dev)
+    lw = torch.from_numpy((rng.uniform(0, 1, (N, A)) > 0.2).astype(np.float32)).to(dev)
+    bt = torch.from_numpy((rng.standard_normal((N, A, 5)) * 0.5).astype(np.float32)).to(dev)
+    bw = torch.from_numpy((rng.uniform(0, 1, (N, A, 5)) > 0.7).astype(np.float32)).to(dev)
+    avg = torch.tensor(37.0, device=dev)
+    up = torch.tensor(0.625, device=dev)                  # the gradient arriving from parse_losses' sum
+    for s, e in ((0, 300), (300, 650), (650, 700), (0, 700)):
+        M = N * (e - s)
+        x = torch.from_numpy((rng.standard_normal((M, C)) * 3).astype(np.float32)).to(dev)
+        p = torch.from_numpy(rng.standard_normal((M, 5)).astype(np.float32)).to(dev)
+        got = {}
+        for nodes in (True, False):
+            FL.LEVEL_NODES = nodes
+            try:
+                x1, p1 = x.clone().requires_grad_(True), p.clone().requires_grad_(True)
+                lc = FL.FocalLoss(loss_weight=0.7)(x1, labels[:, s:e], lw[:, s:e], avg_factor=avg)
+                lb = SmoothL1Loss(beta=1.0 / 9.0, loss_weight=1.3)(p1, bt[:, s:e], bw[:, s:e], avg_factor=avg)
+                l1 = L1Loss(loss_weight=0.9)(p1, bt[:, s:e], bw[:, s:e], avg_factor=avg)
+                ((lc + lb + l1) * up).backward()
+                got[nodes] = (lc.detach(), lb.detach(), l1.detach(), x1.grad, p1.grad)
+            finally:
+                FL.LEVEL_NODES = True
+        for a, b in zip(got[True], got[False]):
+            assert torch.equal(a, b)
+    # the node is what ran: no clone of a window, no scalar op (one node per loss)
+    x1 = x.clone().requires_grad_(True)
+    assert type(FL.FocalLoss()(x1, labels, lw, avg_factor=avg).grad_fn).__name__ == "_FocalLevelBackward"
+    # a host avg_factor keeps the composition (the framework divides by a host scalar through its reciprocal)
+    assert type(FL.FocalLoss()(x1, labels, lw, avg_factor=37.0).grad_fn).__name__ != "_FocalLevelBackward"
+
+
 # ---- fused Oriented R-CNN codecs (csrc/box_codec_oriented.hip) vs the numpy restatement -----------------------
 def _obbs(n, seed, regular=True):
     rng = np.random.default_rng(seed)

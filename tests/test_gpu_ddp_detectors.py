@@ -46,6 +46,8 @@ def _worker(rank, world, port, name, graph, out, size=SIZE):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if size != SIZE:      # the side-stream configuration (opt-in since round 6) is what that test is about
+            os.environ["JDET_HEAD_STREAMS"] = "1"
         import jdet_amd.models  # noqa: F401
         from jdet_amd.runner import Runner
         dev = torch.device("cuda", 0)
