@@ -157,7 +157,7 @@ def make_step(workload, d):
                                                       L.stream_ptr(feat)), "fwd_cl")
             d["out"] = out
             return (step, nbytes / 1e9, "GB", nbytes,
-                    "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out>", "f32")
+                    "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out,rolling window>", "f32")
         # path "roi": the RoI-stationary kernels with the reference's (R,C,7,7)-contiguous result
         cl = False
         out = torch.empty((R, 256, 7, 7), device=feat.device)
@@ -190,7 +190,7 @@ def make_step(workload, d):
                                                   L.stream_ptr(feat)), "riroi_fwd_cl")
         d["out"] = out
         return (step, nbytes / 1e9, "GB", nbytes,
-                "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out,nO=8>", "f32")
+                "roi_order_kernel + roi_align_fwd_merged_kernel<ROTATED,4 waves,channels-last out,nO=8,rolling window>", "f32")
     if workload == "roi_align_rotated_bwd":
         feat, rois, grad = d["feat"], d["rois"], d["grad"]
         R = rois.shape[0]

@@ -20,7 +20,7 @@ def child(path):
 if len(sys.argv) > 2 and sys.argv[1] == "--child":
     child(sys.argv[2]); sys.exit(0)
 fs = []
-for gran in ("4", "256"):
+for gran in os.environ.get("GRANS", "4,256").split(","):
     f = tempfile.mktemp(suffix=".pt")
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", f], env=dict(os.environ, JDET_ROI_FWD_GRAN=gran))
     fs.append(f)
