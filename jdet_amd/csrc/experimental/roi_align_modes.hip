@@ -3,6 +3,8 @@
 //   mode 2: merged taps through the channel-sliced kernels (roi_align_sliced.h): XCD x owns channels [32 x, 32 x + 32) of
 //           every RoI; reads beyond the L2 1.34 M -> 0.55 M requests, 63.7-80 us against 58 us (profiles/r04_roi_fwd_notes.md)
 //   mode 3: taps deduplicated over a line of bins (roi_align_line.h): rows through the L1 -45 %, 71 us against 58 us
+//   mode 5: taps merged over PAIRS of neighbouring bins, two accumulators (roi_align_pair.h, round 6): rows -22 %, L1 accesses
+//           -20 %, VALU +46 %: 59.4 us against 56.4 us for the rolling-window product kernel (profiles/r06_roi_fwd_ring.md)
 // -- behind jdet_roi_align_forward_cl_mode.  Kept with their parity tests as the measured answers to "partition the XCDs
 // by channel" and "deduplicate the pixel rows of neighbouring bins"; neither is a product path.
 #define JDET_ROI_EXPERIMENTAL_MODES 1
@@ -20,7 +22,7 @@ JDET_API int jdet_roi_align_forward_cl_mode(int mode, int variant, const float* 
                                             const float* rois, int R, int PH, int PW, float spatial_scale,
                                             int sample_num, int n_orient, const int32_t* order, float* out_cl,
                                             void* workspace, size_t workspace_bytes, jdet_stream_t stream) {
-  if (mode != kFwdSliced && mode != kFwdLine && mode != kFwdStaged) return JDET_E_BADARG;
+  if (mode != kFwdSliced && mode != kFwdLine && mode != kFwdStaged && mode != kFwdPair) return JDET_E_BADARG;
   int e = check_common(variant, feat, rois, out_cl, N, C, H, W, R, PH, PW, n_orient);
   if (e) return e;
   if (C % 4 != 0 || (size_t)H * W * C * 4 >= (1ull << 31)) return JDET_E_UNSUPPORTED;

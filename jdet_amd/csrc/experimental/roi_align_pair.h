@@ -1,5 +1,10 @@
-// Rotated / horizontal RoIAlign forward with the taps of TWO neighbouring bins merged (round 6).  Included by
-// roi_align_impl.inc inside its anonymous namespace.
+// Rotated / horizontal RoIAlign forward with the taps of TWO neighbouring bins merged (round 6).  A MEASURED ALTERNATIVE, not a
+// product path: forward mode 5 of jdet_roi_align_forward_cl_mode (libjdet_experimental.so); included by roi_align_impl.inc
+// inside its anonymous namespace under JDET_ROI_EXPERIMENTAL_MODES.
+// Measured at the north-star point (profiles/r06_roi_fwd_ring.md section 5): rows 979 452 -> 764 512 (-22 %), vector-L1
+// accesses 17.24 M -> 13.80 M, L1 -> L2 requests 5.86 M -> 4.88 M -- and VALU instructions 10.3 M -> 15.05 M: 59.4 us against
+// 56.4 us for the rolling-window product kernel.  The launch is co-limited by VALU issue and the L2 -> L1 row path; the rows
+// this merge saves cost more in the second accumulator and the wider merge than they return.
 //
 // Why (profiles/r06_roi_fwd_ring.md): the forward is bound by the rate at which 1 KiB rows come out of the L2 -> L1 path; its
 // prologue is hidden (the tap loops alone take what the whole kernel takes).  Only fewer rows move it.  The per-bin merge
