@@ -30,6 +30,8 @@
 // Bound: the matrix pipe at the 3x3 layers (2 * M * N * K flop at 157 TFLOP/s); HBM at the 1x1 layers of the big maps
 // (64 <-> 256 channels at 2 x 256^2: ~170-300 MB per layer, where the fused epilogue saves the separate pass's 2-3 tensor
 // round trips).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -71,7 +73,10 @@ __device__ __forceinline__ void bn_affine(const jdet_bn_params_t& p, int n, floa
   }
 }
 
-template <int BT, int BK, int KG>
+// DEPTH (round 6; BT = 64, one wave group): the operand tiles of a K step are requested DEPTH steps ahead into DEPTH
+// register sets instead of one step ahead into one -- a 64 x 64 tile's K step is 16 MFMAs per wave (0.43 us), less than a
+// global round trip under load, so with one step of cover every step ended in a wait for its successor's tiles.
+template <int BT, int BK, int KG, int DEPTH = 1>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(BT == 128 ? (KG == 2 ? 4 : (BK == 32 ? 2 : 4)) : 4)))
 void conv_bn_kernel(CbArgs a) {
@@ -139,22 +144,28 @@ void conv_bn_kernel(CbArgs a) {
         av[p] = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;
     }
   };
-  v4f ra[PASSES], rb[PASSES];
-  auto load_step = [&](int tap, int c) {
+  constexpr int SETS = DEPTH;
+  v4f ra[SETS][PASSES], rb[SETS][PASSES];
+  auto load_set = [&](auto setc, int tap, int c) {
+    constexpr int S = decltype(setc)::value;
     const unsigned sa = (unsigned)(c * 4), sb = (unsigned)((tap * a.Cin + c) * 4);
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      ra[p] = buf_load(rx, av[p], sa);
-      rb[p] = buf_load(rw, wv[p], sb);
+      ra[S][p] = buf_load(rx, av[p], sa);
+      rb[S][p] = buf_load(rw, wv[p], sb);
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_set = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + st_off[p]) = ra[p];
-      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + TILE + st_off[p]) = rb[p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + st_off[p]) = ra[S][p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + TILE + st_off[p]) = rb[S][p];
     }
   };
+  using Set0 = std::integral_constant<int, 0>;
+  auto load_step = [&](int tap, int c) { load_set(Set0{}, tap, c); };
+  auto store_step = [&](int buf) { store_set(Set0{}, buf); };
 
   // ---- compute role ----
   const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
@@ -198,21 +209,15 @@ void conv_bn_kernel(CbArgs a) {
 
   int tap = step0 / spt, c = (step0 - tap * spt) * BK;
   set_tap(tap);
-  load_step(tap, c);
-  store_step(0);
-  __syncthreads();
-  for (int step = 0; step < nsteps; step++) {
-    const int buf = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) {
-      c += BK;
-      if (c == a.Cin) {
-        c = 0;
-        tap++;
-        set_tap(tap);
-      }
-      load_step(tap, c);
+  auto advance = [&]() {          // the load cursor: next K step (next 32 / 16 channels, then the next tap)
+    c += BK;
+    if (c == a.Cin) {
+      c = 0;
+      tap++;
+      set_tap(tap);
     }
+  };
+  auto mfma_step = [&](int buf) {
     const char* sb = s_raw + buf * 2 * TILE;
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) {
@@ -230,8 +235,68 @@ void conv_bn_kernel(CbArgs a) {
           for (int j = 0; j < T; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     }
-    if (more) store_step(buf ^ 1);
+  };
+  if constexpr (DEPTH == 1) {
+    load_step(tap, c);
+    store_step(0);
     __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+      const int buf = step & 1;
+      const bool more = step + 1 < nsteps;
+      if (more) {
+        advance();
+        load_step(tap, c);
+      }
+      mfma_step(buf);
+      if (more) store_step(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    // DEPTH == 2.  At the top of turn s: LDS buffer (s & 1) holds step s; register set (s + 1) & 1 holds step s + 1 (in
+    // flight); set (s & 1) is free and takes step s + 2.  The steady-state turns request unconditionally, so that hipcc's
+    // wait before the LDS stores of step s + 1 leaves the just-issued loads of step s + 2 in flight (vmcnt(7) / (5) / (4)
+    // in the ISA; a conditional request makes it wait for everything).  110 VGPRs, no scratch (a generic DEPTH-turn
+    // formulation with a switch over the last turns spilled: 128 VGPRs + 76 B of scratch at depth 2, 208 B at depth 3).
+    static_assert(DEPTH == 2, "two register sets");
+    using Set1 = std::integral_constant<int, 1>;
+    load_set(Set0{}, tap, c);
+    if (nsteps > 1) {
+      advance();
+      load_set(Set1{}, tap, c);
+    }
+    store_set(Set0{}, 0);
+    __syncthreads();
+    int step = 0;
+    for (; step + 3 < nsteps; step += 2) {
+      advance();
+      load_set(Set0{}, tap, c);        // step + 2
+      mfma_step(0);
+      store_set(Set1{}, 1);            // step + 1
+      __syncthreads();
+      advance();
+      load_set(Set1{}, tap, c);        // step + 3
+      mfma_step(1);
+      store_set(Set0{}, 0);            // step + 2
+      __syncthreads();
+    }
+    while (step < nsteps) {            // the last one to three steps
+      if (step + 2 < nsteps) {
+        advance();
+        load_set(Set0{}, tap, c);
+      }
+      mfma_step(0);
+      if (step + 1 < nsteps) store_set(Set1{}, 1);
+      __syncthreads();
+      if (++step >= nsteps) break;
+      if (step + 2 < nsteps) {
+        advance();
+        load_set(Set1{}, tap, c);
+      }
+      mfma_step(1);
+      if (step + 1 < nsteps) store_set(Set0{}, 0);
+      __syncthreads();
+      ++step;
+    }
   }
 
   if (KG == 2) {
@@ -401,10 +466,22 @@ __global__ __launch_bounds__(256) void conv_bn_finish_kernel(CbArgs a) {
   }
 }
 
+int cb_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 template <int BT, int BK, int KG>
 int launch(const CbArgs& a, hipStream_t st) {
   const long M = (long)a.N * a.Ho * a.Wo;
   const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
+  if constexpr (BT == 64 && KG == 1) {
+    static const int deep = cb_env_int("JDET_CONV_BN_DEEP", 1);     // operand tiles TWO K steps ahead (0: one; A/B switch)
+    if (deep) {
+      hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a);
+      return jdet_launch_status();
+    }
+  }
   hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
   return jdet_launch_status();
 }

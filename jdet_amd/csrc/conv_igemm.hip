@@ -32,6 +32,8 @@
 //     rows (incl. the halo shared by neighbouring tiles) of a band stay in one L2.
 //   * epilogue in registers: + bias, ReLU, x per-position mask (the gap rows of a LevelPack), 128-byte row segments.
 // The matrix pipe is the bound: 2 * M * N * K flop at 157 TFLOP/s (fp32-input MFMA = the fp32 vector rate).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -63,7 +65,9 @@ __device__ __forceinline__ int swz_bytes(int row, int chunk) {
   return (row * BK + ((chunk ^ (BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7)) << 2)) * 4;
 }
 
-template <int BT, int BK, int KG, bool DEFORM>
+// DEPTH = 2 (round 6; 64 x 64 tiles, one wave group, plain taps): operand tiles requested TWO K steps ahead into two
+// register sets -- see conv_bn.hip: a 64 x 64 tile's K step is 0.43 us of MFMAs per wave, less than a global round trip.
+template <int BT, int BK, int KG, bool DEFORM, int DEPTH = 1>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(BT == 128 ? (KG == 2 ? 4 : (BK == 32 ? 2 : (DEFORM ? 3 : 4))) : 4)))
 void conv3x3_igemm_kernel(ConvArgs a) {
@@ -155,29 +159,35 @@ void conv3x3_igemm_kernel(ConvArgs a) {
     }
   };
 
-  v4f ra[PASSES], rb[PASSES];
-  auto load_step = [&](int tap, int c) {     // c: first channel of the K step
+  static_assert(DEPTH == 1 || (DEPTH == 2 && !DEFORM), "two register sets: plain taps only");
+  v4f ra[DEPTH][PASSES], rb[DEPTH][PASSES];
+  auto load_set = [&](auto setc, int tap, int c) {     // c: first channel of the K step
+    constexpr int S = decltype(setc)::value;
     const unsigned sa = (unsigned)(c * 4), sb = (unsigned)((tap * a.Cin + c) * 4);
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      if (!DEFORM) {
-        ra[p] = buf_load(rx, av[p][0], sa);
+      if constexpr (!DEFORM) {
+        ra[S][p] = buf_load(rx, av[p][0], sa);
       } else {
         v4f v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) v[k] = buf_load(rx, av[p][k], sa);
-        ra[p] = aw[p][0] * v[0] + aw[p][1] * v[1] + aw[p][2] * v[2] + aw[p][3] * v[3];
+        ra[S][p] = aw[p][0] * v[0] + aw[p][1] * v[1] + aw[p][2] * v[2] + aw[p][3] * v[3];
       }
-      rb[p] = buf_load(rw, wv[p], sb);
+      rb[S][p] = buf_load(rw, wv[p], sb);
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_set = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + st_off[p]) = ra[p];
-      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + TILE + st_off[p]) = rb[p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + st_off[p]) = ra[S][p];
+      *reinterpret_cast<v4f*>(s_raw + buf * 2 * TILE + TILE + st_off[p]) = rb[S][p];
     }
   };
+  using Set0 = std::integral_constant<int, 0>;
+  auto load_step = [&](int tap, int c) { load_set(Set0{}, tap, c); };
+  auto store_step = [&](int buf) { store_set(Set0{}, buf); };
 
   // ---- compute role: wave (kg, wm, wn) owns outputs [wm*BT/2, +BT/2) x [wn*BT/2, +BT/2) and the 8-deep slices
   // q = qq * KG + kg of every K step ----
@@ -200,21 +210,15 @@ void conv3x3_igemm_kernel(ConvArgs a) {
 
   int tap = step0 / spt, c = (step0 - tap * spt) * BK;
   set_tap(tap);
-  load_step(tap, c);
-  store_step(0);
-  __syncthreads();
-  for (int step = 0; step < nsteps; step++) {
-    const int buf = step & 1;
-    const bool more = step + 1 < nsteps;
-    if (more) {
-      c += BK;
-      if (c == a.Cin) {
-        c = 0;
-        tap++;
-        set_tap(tap);
-      }
-      load_step(tap, c);            // in flight during the MFMAs below
+  auto advance = [&]() {          // the load cursor: next K step (next BK channels, then the next tap)
+    c += BK;
+    if (c == a.Cin) {
+      c = 0;
+      tap++;
+      set_tap(tap);
     }
+  };
+  auto mfma_step = [&](int buf) {
     const char* sb = s_raw + buf * 2 * TILE;
 #pragma unroll
     for (int qq = 0; qq < QN; qq++) {
@@ -232,8 +236,64 @@ void conv3x3_igemm_kernel(ConvArgs a) {
           for (int j = 0; j < T; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     }
-    if (more) store_step(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous step
+  };
+  if constexpr (DEPTH == 1) {
+    load_step(tap, c);
+    store_step(0);
     __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+      const int buf = step & 1;
+      const bool more = step + 1 < nsteps;
+      if (more) {
+        advance();
+        load_step(tap, c);            // in flight during the MFMAs below
+      }
+      mfma_step(buf);
+      if (more) store_step(buf ^ 1);   // the other buffer: its last readers passed the barrier of the previous step
+      __syncthreads();
+    }
+  } else {
+    // At the top of turn s: LDS buffer (s & 1) holds step s, register set (s + 1) & 1 holds step s + 1 (in flight), set
+    // (s & 1) is free and takes step s + 2; steady-state turns request unconditionally (counted waits: conv_bn.hip).
+    using Set1 = std::integral_constant<int, DEPTH - 1>;
+    load_set(Set0{}, tap, c);
+    if (nsteps > 1) {
+      advance();
+      load_set(Set1{}, tap, c);
+    }
+    store_set(Set0{}, 0);
+    __syncthreads();
+    int step = 0;
+    for (; step + 3 < nsteps; step += 2) {
+      advance();
+      load_set(Set0{}, tap, c);
+      mfma_step(0);
+      store_set(Set1{}, 1);
+      __syncthreads();
+      advance();
+      load_set(Set1{}, tap, c);
+      mfma_step(1);
+      store_set(Set0{}, 0);
+      __syncthreads();
+    }
+    while (step < nsteps) {
+      if (step + 2 < nsteps) {
+        advance();
+        load_set(Set0{}, tap, c);
+      }
+      mfma_step(0);
+      if (step + 1 < nsteps) store_set(Set1{}, 1);
+      __syncthreads();
+      if (++step >= nsteps) break;
+      if (step + 2 < nsteps) {
+        advance();
+        load_set(Set1{}, tap, c);
+      }
+      mfma_step(1);
+      if (step + 1 < nsteps) store_set(Set0{}, 0);
+      __syncthreads();
+      ++step;
+    }
   }
 
   // ---- KG = 2: the second group hands its partial tile over through LDS (the operand buffers are free now) ----
@@ -311,10 +371,18 @@ template <int BT, int BK, int KG>
 int launch(const ConvArgs& a, hipStream_t st) {
   const long M = (long)a.N * a.H * a.W;
   const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
-  if (a.offset)
+  if (a.offset) {
     hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, true>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
+    return jdet_launch_status();
+  }
+  if constexpr (BT == 64 && KG == 1) {
+    static const char* e = getenv("JDET_CONV_IGEMM_DEEP");      // operand tiles two K steps ahead (A/B switch; default on)
+    if (!e || atoi(e) != 0) {
+      hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a);
+      return jdet_launch_status();
+    }
+  }
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<BT, BK, KG, false>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
   return jdet_launch_status();
 }
 
