@@ -29,6 +29,8 @@
 //     x, x + 8, ... and runs ALL (Cout tile, Cin tile, tap) workgroups of a chunk back to back: the 9 taps x Cout tiles
 //     that re-read the same positions of X (and the 9 taps x Cin tiles re-reading gY) find them in that XCD's L2.
 // The matrix pipe is the bound: 2 * 9 * Cin * Cout * positions flop at 157 TFLOP/s.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -53,9 +55,10 @@ __device__ __forceinline__ v4f buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff)
 }
 
 // S2: the strided form (stride 2, or any case where the x pixel of a position is not at a constant distance from it)
-template <int TM, int TN, bool DEFORM, bool WIDE, bool S2>
+template <int TM, int TN, bool DEFORM, bool WIDE, bool S2, int DEPTH = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DEFORM ? 3 : 4)))
 void conv3x3_wgrad_kernel(WgradArgs a) {
+  static_assert(DEPTH == 1 || ((DEPTH == 2 || DEPTH == 4) && !DEFORM), "several register sets: plain form only");
   constexpr int BM = 64 * TM, BN = 64 * TN;
   constexpr int SA = BM + 32, SB = BN + 32;             // LDS row strides in floats
   constexpr int TILE_A = BK * SA * 4, TILE_B = BK * SB * 4;
@@ -165,17 +168,23 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
     if (DEFORM) fetch_offsets(p); else plain_off(p);
   }
 
-  v4f ra[PA], rb[PB][NC];
-  auto load_step = [&]() {
+  // Round 6: the plain form requests its rows SEVERAL K steps ahead into that many register sets (a 64 x 64 tile's K step is
+  // 8 MFMAs per wave, 0.2 us -- far less than a global round trip under load; see conv_bn.hip; a set is 8 VGPRs here):
+  // S2ANet step 26.55 (one step ahead) -> 26.48 (two) -> 26.36 (four, same-box pairs).  The deformable form keeps one (its
+  // bilinear weights belong to the loads in flight).
+  constexpr int D = DEPTH;
+  v4f ra[D][PA], rb[D][PB][NC];
+  auto load_step = [&](auto setc) {
+    constexpr int S = decltype(setc)::value;
 #pragma unroll
     for (int p = 0; p < PA; p++) {
-      ra[p] = buf_load(rg, a_off[p]);          // past the last position: out of range -> 0
+      ra[S][p] = buf_load(rg, a_off[p]);          // past the last position: out of range -> 0
       a_off[p] += a_step;
     }
 #pragma unroll
     for (int p = 0; p < PB; p++) {
-      if (!DEFORM) {
-        rb[p][0] = buf_load(rx, b_off[p][0]);
+      if constexpr (!DEFORM) {
+        rb[S][p][0] = buf_load(rx, b_off[p][0]);
       } else {
         // dcn_v1.py:L132-166 (deformable_im2col), the same sampling rule as conv_igemm.hip's gathered operand
         const bool ok = b_cok && bp[p] < M;
@@ -189,25 +198,26 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
         for (int k = 0; k < NC; k++) {
           const bool kin = in && (unsigned)cy[k] < (unsigned)a.H && (unsigned)cx[k] < (unsigned)a.W;
           wt[p][k] = w4[k];
-          rb[p][k] = buf_load(rx, kin ? ((unsigned)(((bi[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin + n0 + b_chunk * 4)) * 4u
-                                      : kOob);
+          rb[S][p][k] = buf_load(rx, kin ? ((unsigned)(((bi[p] * a.H + cy[k]) * a.W + cx[k]) * a.Cin + n0 + b_chunk * 4)) * 4u
+                                         : kOob);
         }
         advance(p);
         fetch_offsets(p);
       }
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](auto setc, int buf) {
+    constexpr int S = decltype(setc)::value;
     char* base = s_raw + buf * (TILE_A + TILE_B);
 #pragma unroll
-    for (int p = 0; p < PA; p++) *reinterpret_cast<v4f*>(base + a_st[p]) = ra[p];
+    for (int p = 0; p < PA; p++) *reinterpret_cast<v4f*>(base + a_st[p]) = ra[S][p];
 #pragma unroll
     for (int p = 0; p < PB; p++) {
-      if (!DEFORM)
-        *reinterpret_cast<v4f*>(base + b_st[p]) = rb[p][0];
+      if constexpr (!DEFORM)
+        *reinterpret_cast<v4f*>(base + b_st[p]) = rb[S][p][0];
       else
         *reinterpret_cast<v4f*>(base + b_st[p]) =
-            wt[p][0] * rb[p][0] + wt[p][1] * rb[p][1] + wt[p][2] * rb[p][2] + wt[p][3] * rb[p][3];
+            wt[p][0] * rb[S][p][0] + wt[p][1] * rb[S][p][1] + wt[p][2] * rb[S][p][2] + wt[p][3] * rb[S][p][3];
     }
   };
 
@@ -224,18 +234,36 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-  load_step();
+  using Set0 = std::integral_constant<int, 0>;
+  load_step(Set0{});
   if (!DEFORM) {
 #pragma unroll
     for (int p = 0; p < PB; p++) advance(p);
   }
-  store_step(0);
+  if constexpr (D >= 2) {
+    load_step(std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int p = 0; p < PB; p++) advance(p);
+  }
+  if constexpr (D == 4) {
+    load_step(std::integral_constant<int, 2>{});
+#pragma unroll
+    for (int p = 0; p < PB; p++) advance(p);
+    load_step(std::integral_constant<int, 3>{});
+#pragma unroll
+    for (int p = 0; p < PB; p++) advance(p);
+  }
+  store_step(Set0{}, 0);
   __syncthreads();
-  // Every step loads the next one's rows (the step past the chunk's end too: its rows are read -- in range or as
-  // zeros -- stored and never used, which keeps the loop free of branches).
-  for (int step = 0; step < nsteps; step++) {
-    const int buf = step & 1;
-    load_step();
+  // Every step loads a later one's rows (the steps past the chunk's end too: their rows are read -- in range or as
+  // zeros -- stored and never used, which keeps the loop free of branches).  Before the turn of step s (LDS buffer
+  // B = s & 1 holds it): with two sets, set B ^ 1 holds step s + 1 (in flight) and set B is free for step s + 2.
+  auto turn = [&](auto kc) {      // turn k of a trip: LDS buffer k & 1 holds its step, set k % D is free, set (k + 1) % D is next
+    constexpr int K = decltype(kc)::value;
+    constexpr int buf = K & 1;
+    using LoadSet = std::integral_constant<int, K % D>;
+    using StoreSet = std::integral_constant<int, (K + 1) % D>;
+    load_step(LoadSet{});
     const char* sb = s_raw + buf * (TILE_A + TILE_B);
     float fa[2][TM], fb[2][TN];          // fragments of K pair q + 1 are fetched behind the MFMAs of pair q
     auto frags = [&](int q) {
@@ -257,10 +285,27 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
       // behind the MFMAs just issued: the offsets of the step after next (one B row per K pair), then -- late, the
       // loads have had six K pairs to land -- the LDS writes of the next step
       if (!DEFORM && q < PB) advance(q);
-      if (q == BK / 2 - 2) store_step(buf ^ 1);
+      if (q == BK / 2 - 2) store_step(StoreSet{}, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+  };
+  {
+    constexpr int LOOP = D == 4 ? 4 : 2;
+    int step = 0;
+    for (; step + LOOP - 1 < nsteps; step += LOOP) {
+      turn(std::integral_constant<int, 0>{});
+      turn(std::integral_constant<int, 1>{});
+      if constexpr (LOOP == 4) {
+        turn(std::integral_constant<int, 2>{});
+        turn(std::integral_constant<int, 3>{});
+      }
+    }
+    if (step < nsteps) turn(std::integral_constant<int, 0>{});
+    if constexpr (LOOP == 4) {
+      if (step + 1 < nsteps) turn(std::integral_constant<int, 1>{});
+      if (step + 2 < nsteps) turn(std::integral_constant<int, 2>{});
+    }
   }
 
   if (a.skip_epilogue) {                 // measurement aid: the cost of the atomics = the difference
@@ -295,14 +340,22 @@ int launch(const WgradArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)(mt * nt * a.R * a.R * ((a.ksplit + 7) & ~7));
   const bool wide = a.Wo >= BK;
   const bool s2 = a.stride != 1 || a.Ho != a.H || a.Wo != a.W;
+  static const char* deep_env = getenv("JDET_CONV_WGRAD_DEEP");      // rows 4 (wide stride-1 form) / 2 K steps ahead; 0 / 2 / 4: A/B
+  const int deep_n = deep_env ? atoi(deep_env) : 4;
+  const bool deep = deep_n != 0, deep4 = deep_n == 4;
   if (a.offset) {
     if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, true, false>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, false, false>), dim3(grid), dim3(256), 0, st, a);
   } else if (s2) {
-    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true>), dim3(grid), dim3(256), 0, st, a);
+    if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true>), dim3(grid), dim3(256), 0, st, a);
+    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true, 2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false>), dim3(grid), dim3(256), 0, st, a);
+    if (wide && deep4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false>), dim3(grid), dim3(256), 0, st, a);
+    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false, 2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return jdet_launch_status();
