@@ -170,7 +170,7 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
 
   // Round 6: the plain form requests its rows SEVERAL K steps ahead into that many register sets (a 64 x 64 tile's K step is
   // 8 MFMAs per wave, 0.2 us -- far less than a global round trip under load; see conv_bn.hip; a set is 8 VGPRs here):
-  // S2ANet step 26.55 (one step ahead) -> 26.48 (two) -> 26.36 (four, same-box pairs).  The deformable form keeps one (its
+  // S2ANet step 26.55 (one step ahead) -> 26.48 (two); 26.64 (two) -> 26.52 (four; same-box pairs).  The deformable form keeps one (its
   // bilinear weights belong to the loads in flight).
   constexpr int D = DEPTH;
   v4f ra[D][PA], rb[D][PB][NC];
