@@ -341,21 +341,26 @@ int launch(const WgradArgs& a, hipStream_t st) {
   const bool wide = a.Wo >= BK;
   const bool s2 = a.stride != 1 || a.Ho != a.H || a.Wo != a.W;
   static const char* deep_env = getenv("JDET_CONV_WGRAD_DEEP");      // rows 4 (wide stride-1 form) / 2 K steps ahead; 0 / 2 / 4: A/B
-  const int deep_n = deep_env ? atoi(deep_env) : 4;
+  // the 64 x 64 tile only: the wider tiles' K step is long enough for one step of cover, and several register sets on top
+  // of their accumulators spill (<2, 2, ..., 4>: 124 VGPRs to scratch -- the head towers' gradients through this kernel
+  // ran 3.4 ms per step slower with it)
+  const int deep_n = (TM == 1 && TN == 1) ? (deep_env ? atoi(deep_env) : 4) : 0;
   const bool deep = deep_n != 0, deep4 = deep_n == 4;
   if (a.offset) {
     if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, true, false>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, false, false>), dim3(grid), dim3(256), 0, st, a);
   } else if (s2) {
-    if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true, 2>), dim3(grid), dim3(256), 0, st, a);
+    constexpr int D2 = (TM == 1 && TN == 1) ? 2 : 1;
+    if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true, D2>), dim3(grid), dim3(256), 0, st, a);
     else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true>), dim3(grid), dim3(256), 0, st, a);
-    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true, D2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    if (wide && deep4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, 4>), dim3(grid), dim3(256), 0, st, a);
-    else if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, 2>), dim3(grid), dim3(256), 0, st, a);
+    constexpr int D2 = (TM == 1 && TN == 1) ? 2 : 1, D4 = (TM == 1 && TN == 1) ? 4 : 1;
+    if (wide && deep4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, D4>), dim3(grid), dim3(256), 0, st, a);
+    else if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, D2>), dim3(grid), dim3(256), 0, st, a);
     else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false>), dim3(grid), dim3(256), 0, st, a);
-    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false, D2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, false>), dim3(grid), dim3(256), 0, st, a);
   }
   return jdet_launch_status();

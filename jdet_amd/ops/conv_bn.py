@@ -45,6 +45,20 @@ ENABLED = os.environ.get("JDET_BOTTLENECK_FUSED", "1") == "1"
 # library's at the layer1-3 shapes of a 2 x 1024^2 step and no zero-fill launch per layer (profiles/r05_conv_bn.md);
 # "lib" = the library's kernels on the same g' tensors (A/B).
 OWN_WGRAD = os.environ.get("JDET_BOTTLENECK_WGRAD", "own") == "own"
+# The block's weight gradients on a SIDE stream, concurrent with its data gradients (JDET_BOTTLENECK_WGRAD_STREAM=1): both
+# kernel families run at ~60 % MFMA busy with two workgroups per CU on the deep layers, the weight gradient of layer k
+# needs only g_k' and the saved input, and nothing reads it before the block's backward returns.  The side stream waits
+# for an event behind the kernel that produced g_k'; the main stream waits for the side stream once, at the end of the
+# block's backward (the gradients are handed to autograd -- and to DDP's bucket hooks -- only after that).
+WGRAD_STREAM = os.environ.get("JDET_BOTTLENECK_WGRAD_STREAM", "0") == "1"
+_SIDE = {}           # device index -> the side stream
+
+
+def _side_stream(device):
+    s = _SIDE.get(device.index)
+    if s is None:
+        s = _SIDE[device.index] = torch.cuda.Stream(device=device)
+    return s
 # stride-2 3x3 / 1x1 data gradients: the library's (a strided data gradient is a different kernel, not built here)
 _PLAN = {}           # (N, H, W, Cin, Cout, R, stride) -> (workspace bytes, sums rows with it)
 
@@ -436,10 +450,18 @@ class _BottleneckFunction(torch.autograd.Function):
             own = True
             gws = DgradBank(convs).claim_grad(convs)
 
+        side = _side_stream(g.device) if (own and WGRAD_STREAM and g.is_cuda) else None
+        main = torch.cuda.current_stream(g.device) if side is not None else None
+
         def wgrad(k, xin, gy, R, stride):
             c = convs[k]
             if own:
-                conv_wgrad_nhwc(xin, gy, R, stride, gws[k])
+                if side is not None:
+                    side.wait_stream(main)          # behind the kernel that wrote gy (and the step's zero fill)
+                    with torch.cuda.stream(side):
+                        conv_wgrad_nhwc(xin, gy, R, stride, gws[k])
+                else:
+                    conv_wgrad_nhwc(xin, gy, R, stride, gws[k])
                 # the parameter's own strides: a 1x1 weight is plain (Cout, Cin, 1, 1) memory, a 3x3 one channels-last
                 gws[k] = gws[k].view(c.weight.shape) if R == 1 else gws[k].permute(0, 3, 1, 2)
             else:
@@ -453,13 +475,15 @@ class _BottleneckFunction(torch.autograd.Function):
                 gws[k] = gw
         # block output: y3 = relu(bn3(c3) + identity)
         g3p, s3 = bn_backward_from_output(g, y3, blk.bn3, identity=idn if ds is not None else xn)
-        g2p, s2 = conv_bn_nhwc(g3p, bank.get(blk.conv3), 1, blk.bn2, mode=L.EPI_MASK, act=y2, want_sums=True)
+        # (each weight gradient is launched BEFORE the data gradient that reads the same g_k': with WGRAD_STREAM the two run
+        #  side by side; on one stream the order is immaterial)
         wgrad(2, y2, g3p, 1, 1)
+        g2p, s2 = conv_bn_nhwc(g3p, bank.get(blk.conv3), 1, blk.bn2, mode=L.EPI_MASK, act=y2, want_sums=True)
+        wgrad(1, y1, g2p, 3, st)
         if st == 1:
             g1p, s1 = conv_bn_nhwc(g2p, bank.get(blk.conv2), 1, blk.bn1, mode=L.EPI_MASK, act=y1, want_sums=True)
         else:
             g1p, s1 = bn_backward_from_output(_lib_dgrad(g2p, y1, blk.conv2.weight, st, 1), y1, blk.bn1)
-        wgrad(1, y1, g2p, 3, st)
         wgrad(0, xn, g1p, 1, 1)
         sums = [(s1, blk.bn1), (s2, blk.bn2), (s3, blk.bn3)]
         gx = None
@@ -477,6 +501,10 @@ class _BottleneckFunction(torch.autograd.Function):
                     gxd = _lib_dgrad(gdp, xn, ds[0].weight, st, 0)
                 gx = conv_bn_nhwc(g1p, bank.get(blk.conv1), 1, None, residual=gxd)
         bn_grads = bn_sums_finish(sums)
+        if side is not None:
+            # the temporaries the side kernels read (g_k', allocated on the main stream) go back to the main stream's pool
+            # when this function returns: every later use of that memory is ordered behind this wait
+            main.wait_stream(side)
         out = [gx.permute(0, 3, 1, 2) if gx is not None else None, None]
         for k in range(len(convs)):
             out += [gws[k], bn_grads[k][0], bn_grads[k][1]]
