@@ -475,10 +475,10 @@ template <int BT, int BK, int KG>
 int launch(const CbArgs& a, hipStream_t st) {
   const long M = (long)a.N * a.Ho * a.Wo;
   const long tiles = ((M + BT - 1) / BT) * ((a.Cout + BT - 1) / BT);
-  if constexpr (BT == 64 && KG == 1) {
+  if constexpr (BT == 64) {
     static const int deep = cb_env_int("JDET_CONV_BN_DEEP", 1);     // operand tiles TWO K steps ahead (0: one; A/B switch)
     if (deep) {
-      hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
       return jdet_launch_status();
     }
   }
@@ -507,7 +507,10 @@ Plan make_plan(long M, int Cin, int Cout, int taps, int tile, bool workspace) {
   // 16-deep K steps for the 1x1 layers of at most 128 input channels: four to eight short steps instead of two to four
   // (and half the LDS per workgroup): 64 -> 256 + residual at 2 x 256^2 89 vs 97 us, 128 -> 512 + residual at 2 x 128^2
   // 58 vs 65 us; equal elsewhere (scripts/conv_bn_timing.py tiles, profiles/r05_conv_bn.md)
-  const bool k32 = Cin % 32 == 0 && !(tile & 1) && !(tile == 0 && taps == 1 && Cin <= 128);
+  static const int k16_rule = cb_env_int("JDET_CONV_BN_K16", 0);   // measurement aid: 1 = 16-deep steps wherever no K split over
+                                                                     // workgroups follows, 2 = everywhere
+  const bool k16_env = tile == 0 && (k16_rule == 2 || (k16_rule == 1 && !(workspace && tiles64 < 384)));
+  const bool k32 = Cin % 32 == 0 && !(tile & 1) && !(tile == 0 && taps == 1 && Cin <= 128) && !k16_env;
   const int steps = taps * (Cin / (k32 ? 32 : 16));
   // intra-workgroup K split (8 waves): conv_igemm.hip's rule; not for a K loop of one or two steps (the hand-over
   // through LDS then costs as much as the loop)

@@ -43,4 +43,8 @@ JDET_BOTTLENECK_WGRAD_STREAM=1 timeout 900 python -m pytest tests/test_gpu_conv_
 export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29511
 bash scripts/ab_step.sh -n 2 "JDET_BOTTLENECK_WGRAD_STREAM=0" "JDET_BOTTLENECK_WGRAD_STREAM=1" "JDET_CONV_WGRAD=1" "JDET_BENCH_FORCE_DIST=1" "JDET_BENCH_FORCE_DIST=1 JDET_BOTTLENECK_WGRAD_STREAM=1" 2>&1 | tee $R/gpurun_out/r6_ab_wgrad_stream.txt
 }
+run_k16() {   # 16-deep K steps under the two-steps-ahead operand requests: per layer, then the step
+for k in 0 1 2; do echo "== JDET_CONV_BN_K16=$k"; JDET_CONV_BN_K16=$k timeout 600 python scripts/conv_bn_timing.py layers 2>&1 | grep -v Warn; done | tee $R/gpurun_out/r6_conv_bn_k16_layers.txt | grep "==\|sum"
+bash scripts/ab_step.sh -n 2 "JDET_CONV_BN_K16=0" "JDET_CONV_BN_K16=1" "JDET_CONV_BN_K16=2" 2>&1 | tee $R/gpurun_out/r6_ab_k16.txt
+}
 for s in "$@"; do run_$s; done

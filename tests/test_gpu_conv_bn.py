@@ -212,11 +212,14 @@ BLOCKS = [
 
 @pytest.mark.parametrize("inplanes,planes,stride,downsample,N,H,W", BLOCKS)
 @pytest.mark.parametrize("need_gx", [True, False])
-@pytest.mark.parametrize("own_wgrad", [False, True])
+@pytest.mark.parametrize("own_wgrad", [False, True, "side stream"])
 def test_bottleneck_forward_and_every_gradient(dev, monkeypatch, inplanes, planes, stride, downsample, N, H, W, need_gx,
                                                own_wgrad):
     from jdet_amd.ops import conv_bn as CB
-    monkeypatch.setattr(CB, "OWN_WGRAD", own_wgrad)
+    monkeypatch.setattr(CB, "OWN_WGRAD", bool(own_wgrad))
+    # "side stream": the block's weight gradients run on a second stream beside its data gradients (the opt-in
+    # JDET_BOTTLENECK_WGRAD_STREAM=1); the values read after backward() must be the same as on one stream
+    monkeypatch.setattr(CB, "WGRAD_STREAM", own_wgrad == "side stream")
     blk = _make_block(inplanes, planes, stride, downsample, dev, inplanes + planes + stride)
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, inplanes, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
