@@ -344,19 +344,21 @@ int launch(const WgradArgs& a, hipStream_t st) {
   // the 64 x 64 tile only: the wider tiles' K step is long enough for one step of cover, and several register sets on top
   // of their accumulators spill (<2, 2, ..., 4>: 124 VGPRs to scratch -- the head towers' gradients through this kernel
   // ran 3.4 ms per step slower with it)
-  const int deep_n = (TM == 1 && TN == 1) ? (deep_env ? atoi(deep_env) : 4) : 0;
+  static const char* mid_env = getenv("JDET_CONV_WGRAD_DEEP_MID");   // the 128 x 64 / 64 x 128 tiles: 0 (default) / 2
+  const int deep_n = (TM == 1 && TN == 1) ? (deep_env ? atoi(deep_env) : 4)
+                                          : ((TM + TN == 3 && mid_env) ? (atoi(mid_env) ? 2 : 0) : 0);
   const bool deep = deep_n != 0, deep4 = deep_n == 4;
   if (a.offset) {
     if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, true, false>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, true, false, false>), dim3(grid), dim3(256), 0, st, a);
   } else if (s2) {
-    constexpr int D2 = (TM == 1 && TN == 1) ? 2 : 1;
+    constexpr int D2 = (TM + TN <= 3) ? 2 : 1;
     if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true, D2>), dim3(grid), dim3(256), 0, st, a);
     else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, true>), dim3(grid), dim3(256), 0, st, a);
     else if (deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true, D2>), dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else {
-    constexpr int D2 = (TM == 1 && TN == 1) ? 2 : 1, D4 = (TM == 1 && TN == 1) ? 4 : 1;
+    constexpr int D2 = (TM + TN <= 3) ? 2 : 1, D4 = (TM == 1 && TN == 1) ? 4 : 1;
     if (wide && deep4) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, D4>), dim3(grid), dim3(256), 0, st, a);
     else if (wide && deep) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false, D2>), dim3(grid), dim3(256), 0, st, a);
     else if (wide) hipLaunchKernelGGL((conv3x3_wgrad_kernel<TM, TN, false, true, false>), dim3(grid), dim3(256), 0, st, a);
@@ -380,7 +382,13 @@ int run_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, in
   if ((M + BK) * Cout >= (1L << 30) || (Mx + BK) * Cin >= (1L << 30)) return JDET_E_UNSUPPORTED;     // 32-bit byte offsets
   // bit 17: 64 x 64 tiles whatever the channel counts, bit 18: 128-wide tiles where the channels allow (measurement aids)
   const int small = ((ksplit >> 17) & 1) || (general && !((ksplit >> 18) & 1));
-  const int tm = (Cout > 64 && !small) ? 2 : 1, tn = (Cin > 64 && !small) ? 2 : 1;
+  int tm = (Cout > 64 && !small) ? 2 : 1, tn = (Cin > 64 && !small) ? 2 : 1;
+  // Round 6: 128 x 64 instead of 128 x 128 for the plain form -- the head towers' shape (2 x 128^2, 256 -> 256): 310 us
+  // against 360 (128 x 128: 128 VGPRs, three of them spilled), 332 (64 x 64) and the library's 326 incl. its zero fill
+  // (scripts/wgrad_tiles_p3.sh, profiles/r06_conv_prefetch.md).  Bit 21 keeps the 128 x 128 tile (A/B).
+  if (tm == 2 && tn == 2 && !offset && !((ksplit >> 21) & 1)) tn = 1;
+  if ((ksplit >> 19) & 1) tn = 1;        // bit 19: 128 x 64 tiles, bit 20: 64 x 128 (measurement aids)
+  if ((ksplit >> 20) & 1) tm = 1;
   const int mt = (Cout + 64 * tm - 1) / (64 * tm), nt = (Cin + 64 * tn - 1) / (64 * tn);
   const long tiles = (long)mt * nt * R * R;
   const long steps = (M + BK - 1) / BK;

@@ -13,6 +13,7 @@ Measured on MI355X, 256 -> 256 channels, batch 2 (scripts/conv_igemm_timing.py, 
 32^2 / 16^2 / 8^2 maps 37 / 18 / 16 us vs 55 / 29 / 26 us (K steps split over workgroups through a scratch buffer).
 """
 import os
+import weakref
 
 import torch
 
@@ -163,9 +164,42 @@ _FLIPPED = {}          # id(weight) -> (data_ptr, version, tensor): the data-gra
 DGRAD = os.environ.get("JDET_CONV_IGEMM_DGRAD", "0") == "1"
 
 
+class _WeightRef:
+    """what conv_bn.DgradBank reads of a "convolution": its weight (held weakly: the bank must not keep a model alive)"""
+
+    def __init__(self, w):
+        self.ref = weakref.ref(w)
+
+    @property
+    def weight(self):
+        return self.ref()
+
+
+_DGRAD_BANKS = {}      # device -> {"items": {id(weight): _WeightRef}, "bank": DgradBank}
+
+
 def dgrad_weight(weight):
-    """(Cout, Cin, 3, 3) -> (Cin, 3, 3, Cout) contiguous with the taps flipped: grad_x = conv3x3(grad_y, this).  Cached
-    per weight version (a tower's weight serves three pyramid calls per step)."""
+    """(Cout, Cin, 3, 3) -> (Cin, 3, 3, Cout) contiguous with the taps flipped: grad_x = conv3x3(grad_y, this).  The
+    weights seen so far on a device live in ONE bank (conv_bn.DgradBank: one launch rewrites all of them when a version
+    moved, i.e. once per training step -- the per-weight flip + copy pair was 2 launches x 19 weights per S2ANet step);
+    weights that are not channels-last fp32 device tensors take the per-weight form."""
+    st = None
+    if weight.is_cuda and weight.dtype == torch.float32 and weight.permute(0, 2, 3, 1).is_contiguous() \
+            and not torch.cuda.is_current_stream_capturing():
+        from jdet_amd.ops.conv_bn import DgradBank
+        st = _DGRAD_BANKS.setdefault(weight.device, {"items": {}, "bank": None})
+        it = st["items"].get(id(weight))
+        if it is None or it.weight is not weight or any(v.weight is None for v in st["items"].values()):
+            live = {k: v for k, v in st["items"].items() if v.weight is not None}
+            it = live[id(weight)] = _WeightRef(weight)
+            st["items"] = live
+            st["bank"] = DgradBank(list(live.values()))
+        return st["bank"].get(it)
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        st = _DGRAD_BANKS.get(weight.device)
+        it = st["items"].get(id(weight)) if st else None
+        if it is not None and it.weight is weight and st["bank"].buf is not None:
+            return st["bank"].get(it)          # (built by the eager warm-up steps: a refresh is one kernel, capturable)
     key, stamp = id(weight), (weight.data_ptr(), weight._version)
     hit = _FLIPPED.get(key)
     if hit is None or hit[0] != stamp:

@@ -47,4 +47,14 @@ run_k16() {   # 16-deep K steps under the two-steps-ahead operand requests: per 
 for k in 0 1 2; do echo "== JDET_CONV_BN_K16=$k"; JDET_CONV_BN_K16=$k timeout 600 python scripts/conv_bn_timing.py layers 2>&1 | grep -v Warn; done | tee $R/gpurun_out/r6_conv_bn_k16_layers.txt | grep "==\|sum"
 bash scripts/ab_step.sh -n 2 "JDET_CONV_BN_K16=0" "JDET_CONV_BN_K16=1" "JDET_CONV_BN_K16=2" 2>&1 | tee $R/gpurun_out/r6_ab_k16.txt
 }
+run_ab3() {   # the towers' weight gradient on the own kernel's 128 x 64 tile (new rule) / data gradient on the own kernel
+timeout 900 python -m pytest tests/test_gpu_conv_wgrad.py tests/test_gpu_conv_igemm.py -q -x 2>&1 | tail -3
+bash scripts/ab_step.sh -n 3 "JDET_CONV_WGRAD=0" "JDET_CONV_WGRAD=1" "JDET_CONV_WGRAD=1 JDET_CONV_IGEMM_DGRAD=1" 2>&1 | tee $R/gpurun_out/r6_ab_wgrad_mid.txt
+JDET_CONV_WGRAD=1 bash scripts/gpu_prof_s2anet.sh > /dev/null 2>&1; cp gpurun_out/prof_s2anet/steady_state.txt gpurun_out/r6_steady_wgrad_own.txt; head -3 gpurun_out/r6_steady_wgrad_own.txt | cut -c1-150; rm -rf gpurun_out/prof_s2anet/trace
+}
+run_ab4() {   # the towers' data gradient on the own kernel with the flipped weights from one bank launch
+timeout 900 python -m pytest tests/test_gpu_conv_igemm.py -q -x 2>&1 | tail -3
+bash scripts/ab_step.sh -n 3 "JDET_CONV_WGRAD=0" "JDET_CONV_WGRAD=1" "JDET_CONV_WGRAD=1 JDET_CONV_IGEMM_DGRAD=1" "JDET_CONV_WGRAD=0 JDET_CONV_IGEMM_DGRAD=1" 2>&1 | tee $R/gpurun_out/r6_ab_dgrad_bank.txt
+JDET_CONV_WGRAD=1 JDET_CONV_IGEMM_DGRAD=1 bash scripts/gpu_prof_s2anet.sh > /dev/null 2>&1; cp gpurun_out/prof_s2anet/steady_state.txt gpurun_out/r6_steady_own_grads.txt; head -3 gpurun_out/r6_steady_own_grads.txt | cut -c1-150; rm -rf gpurun_out/prof_s2anet/trace
+}
 for s in "$@"; do run_$s; done

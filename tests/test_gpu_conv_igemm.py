@@ -136,6 +136,33 @@ def test_conv_module_fused_path_matches_library_path(act, dgrad):
     assert not act or (outs[0][0] == 0).float().mean().item() > 0.2     # the ReLU is active
 
 
+def test_dgrad_weights_of_the_towers_live_in_one_bank():
+    """conv_igemm.dgrad_weight: channels-last weights are rewritten by ONE launch for all of them (conv_bn.DgradBank);
+    a new version refreshes, a dead weight leaves the bank, other layouts take the per-weight form -- always
+    weight.flip(2, 3).permute(1, 2, 3, 0)"""
+    import gc
+    from jdet_amd.ops import conv_igemm as CI
+    torch.manual_seed(11)
+    ws = [torch.nn.Parameter((torch.randn(co, ci, 3, 3, device="cuda") * 0.1).contiguous(memory_format=torch.channels_last))
+          for co, ci in ((64, 32), (48, 64), (256, 256))]
+    ref = lambda w: w.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+    for w in ws:
+        assert torch.equal(CI.dgrad_weight(w), ref(w))
+    bank = CI._DGRAD_BANKS[ws[0].device]["bank"]
+    assert all(any(v.weight is w for v in bank.convs) for w in ws)            # one bank holds the three
+    with torch.no_grad():
+        ws[1].mul_(3.0)
+    for w in ws:
+        assert torch.equal(CI.dgrad_weight(w), ref(w))                        # refreshed after the in-place update
+    plain = torch.randn(16, 8, 3, 3, device="cuda")                           # NCHW-contiguous: per-weight form
+    assert torch.equal(CI.dgrad_weight(plain), ref(plain))
+    keep = ws[0]
+    del ws, w
+    gc.collect()
+    assert torch.equal(CI.dgrad_weight(keep), ref(keep))                      # the dead weights are dropped on the way
+    assert all(v.weight is not None for v in CI._DGRAD_BANKS[keep.device]["bank"].convs)
+
+
 def test_deform_conv_inference_takes_the_fused_kernel():
     from jdet_amd.ops import conv_igemm as CI
     from jdet_amd.ops import dcn_v1
