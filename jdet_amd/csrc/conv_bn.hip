@@ -76,7 +76,7 @@ __device__ __forceinline__ void bn_affine(const jdet_bn_params_t& p, int n, floa
 // DEPTH (round 6; BT = 64, one wave group): the operand tiles of a K step are requested DEPTH steps ahead into DEPTH
 // register sets instead of one step ahead into one -- a 64 x 64 tile's K step is 16 MFMAs per wave (0.43 us), less than a
 // global round trip under load, so with one step of cover every step ended in a wait for its successor's tiles.
-template <int BT, int BK, int KG, int DEPTH = 1>
+template <int BT, int BK, int KG, int DEPTH = 1, int SCHED = 0>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(BT == 128 ? (KG == 2 ? 4 : (BK == 32 ? 2 : 4)) : 4)))
 void conv_bn_kernel(CbArgs a) {
@@ -90,6 +90,10 @@ void conv_bn_kernel(CbArgs a) {
   static_assert(PASSES >= 1 && QN >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) char s_raw[4 * TILE];     // [buffer][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // SCHED & 16: workgroup time stamps (scripts/r6_conv_stamps.py): start, K loop entered / left, end, placement -- written
+  // over the first words of the tile's first output row (a profiling build: that row is garbage afterwards)
+  long long stamp[4] = {0, 0, 0, 0}, stamp_x[3] = {0, 0, 0};     // _x: requests issued | first tile landed | epilogue operands read
+  if constexpr (SCHED & 16) stamp[0] = wall_clock64();
   const long M = (long)a.N * a.Ho * a.Wo;
   const long Min = (long)a.N * a.H * a.W;
   const int taps = a.R * a.R, pad = a.R >> 1;
@@ -98,9 +102,13 @@ void conv_bn_kernel(CbArgs a) {
   const int total = gridDim.x;
   int logical = blockIdx.x;
   if ((total & 7) == 0) logical = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-  const int mtile = logical / NT;
+  // (32-bit unsigned index arithmetic throughout the prologue: the host refuses positions * channels >= 2^30.  Round 6,
+  //  workgroup time stamps -- scripts/r6_conv_stamps.py -- showed 7-8.6 us between a workgroup's start and its first operand
+  //  request on the layers that fill the chip four workgroups per CU: the 64-bit divisions below, ~200 VALU instructions
+  //  each, run by sixteen waves per CU at once)
+  const int mtile = (int)((unsigned)logical / (unsigned)NT);
   const long m0 = (long)mtile * BT;
-  const int n0 = (logical % NT) * BT;
+  const int n0 = (logical - mtile * NT) * BT;
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)(Min * a.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw =
@@ -118,19 +126,21 @@ void conv_bn_kernel(CbArgs a) {
     m_ok[p] = lm < M;
     img[p] = py[p] = px[p] = 0;
     if (m_ok[p]) {
-      img[p] = (int)(lm / ((long)a.Ho * a.Wo));
-      const int rem = (int)(lm - (long)img[p] * a.Ho * a.Wo);
-      const int oy = rem / a.Wo;
-      py[p] = oy * a.stride;
-      px[p] = (rem - oy * a.Wo) * a.stride;
+      const unsigned hw = (unsigned)(a.Ho * a.Wo), ulm = (unsigned)lm;
+      const unsigned im = ulm / hw;
+      const unsigned rem = ulm - im * hw;
+      const unsigned oy = rem / (unsigned)a.Wo;
+      img[p] = (int)im;
+      py[p] = (int)oy * a.stride;
+      px[p] = (int)(rem - oy * (unsigned)a.Wo) * a.stride;
     }
     wv[p] = n0 + row < a.Cout ? ((unsigned)((n0 + row) * taps * a.Cin + lchunk * 4)) * 4u : kOob;
     st_off[p] = swz_bytes<BK>(row, lchunk);
   }
   const int spt = a.Cin / BK;               // K steps per tap (host: BK = 32 only when Cin % 32 == 0)
   const int all_steps = taps * spt;
-  const int step0 = (int)((long)all_steps * blockIdx.y / a.ksplit);
-  const int nsteps = (int)((long)all_steps * (blockIdx.y + 1) / a.ksplit) - step0;
+  const int step0 = (int)((unsigned)all_steps * blockIdx.y / (unsigned)a.ksplit);
+  const int nsteps = (int)((unsigned)all_steps * (blockIdx.y + 1u) / (unsigned)a.ksplit) - step0;
 
   unsigned av[PASSES];
   auto set_tap = [&](int tap) {
@@ -184,6 +194,10 @@ void conv_bn_kernel(CbArgs a) {
     for (int j = 0; j < T; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+  constexpr bool DUAL = T == 1 && (SCHED & 8) != 0;
+  v16f acc_b;
+#pragma unroll
+  for (int e = 0; e < 16; e++) acc_b[e] = 0.f;
 
   // ---- the neighbour tile(s) of the epilogue (residual | grad_out + act | act): with one 32 x 32 tile per wave (BT = 64)
   // they are requested HERE, ahead of the K loop -- the 1x1 layers of the big maps run two to eight K steps, and a
@@ -195,7 +209,34 @@ void conv_bn_kernel(CbArgs a) {
   const float* p1 = mode == JDET_EPI_ADD ? ep.act : nullptr;
   constexpr bool PRE = T == 1;
   float pre0[PRE ? 16 : 1], pre1[PRE ? 16 : 1];
-  if (PRE && !a.partial && kg == 0) {
+  // Round 6 (workgroup time stamps, scripts/r6_conv_stamps.py): ~900 instructions ran between a workgroup's start and its
+  // first operand request -- 6-8 us with sixteen waves per CU issuing them at once -- most of them this block's 32 predicated
+  // loads with 64-bit addresses.  A tile that lies inside the map (every tile but the last of a ragged M) now takes raw buffer
+  // loads: one 32-bit lane offset, the 16 row offsets in SGPRs, one lane predicate (the column) around the lot.
+  const bool full_tile = !a.partial && m0 + BT <= M;        // uniform
+  const unsigned ybytes = (unsigned)(M * a.Cout * 4);         // (host: M * Cout < 2^30)
+  if (PRE && full_tile && kg == 0) {
+    const int n = n0 + wn * (BT / 2) + (lane & 31);
+    const unsigned base = ((unsigned)(m0 + wm * (BT / 2) + 4 * (lane >> 5)) * (unsigned)a.Cout + (unsigned)n) * 4u;
+#pragma unroll
+    for (int e = 0; e < 16; e++) pre0[e] = pre1[e] = 0.f;
+    if (n < a.Cout) {
+      if (p0) {
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)p0, 0, ybytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          pre0[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  r0, base, (unsigned)(((e & 3) + 8 * (e >> 2)) * a.Cout * 4), 0));
+      }
+      if (p1) {
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)p1, 0, ybytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          pre1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                  r1, base, (unsigned)(((e & 3) + 8 * (e >> 2)) * a.Cout * 4), 0));
+      }
+    }
+  } else if (PRE && !a.partial && kg == 0) {
     const long mrow = m0 + wm * (BT / 2) + 4 * (lane >> 5);
     const int n = n0 + wn * (BT / 2) + (lane & 31);
 #pragma unroll
@@ -227,13 +268,31 @@ void conv_bn_kernel(CbArgs a) {
         fa[i] = *reinterpret_cast<const v4f*>(sb + fa_off[qq] + i * 32 * BK * 4);
         fb[i] = *reinterpret_cast<const v4f*>(sb + fb_off[qq] + i * 32 * BK * 4);
       }
+      if constexpr (DUAL) {
+        // one 32 x 32 tile per wave = ONE chain of dependent MFMAs: the even / odd 2-deep slices go to two accumulators
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++)
+        for (int kk = 0; kk < 4; kk += 2) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk], fb[0][kk], acc[0][0], 0, 0, 0);
+          acc_b = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][kk + 1], fb[0][kk + 1], acc_b, 0, 0, 0);
+        }
+      } else {
 #pragma unroll
-        for (int i = 0; i < T; i++)
+        for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-          for (int j = 0; j < T; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < T; i++)
+#pragma unroll
+            for (int j = 0; j < T; j++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+  auto fake_step = [&](int buf) {       // ablation: the LDS reads of a step without its MFMAs
+    const char* sb = s_raw + buf * 2 * TILE;
+#pragma unroll
+    for (int qq = 0; qq < QN; qq++) {
+      const v4f fa = *reinterpret_cast<const v4f*>(sb + fa_off[qq]);
+      const v4f fb = *reinterpret_cast<const v4f*>(sb + fb_off[qq]);
+      acc[0][0][qq & 15] += fa[0] + fb[1] + fa[2] + fb[3];
     }
   };
   if constexpr (DEPTH == 1) {
@@ -259,25 +318,37 @@ void conv_bn_kernel(CbArgs a) {
     // formulation with a switch over the last turns spilled: 128 VGPRs + 76 B of scratch at depth 2, 208 B at depth 3).
     static_assert(DEPTH == 2, "two register sets");
     using Set1 = std::integral_constant<int, 1>;
+    if constexpr (SCHED & 16) stamp_x[0] = wall_clock64();          // index arithmetic done
     load_set(Set0{}, tap, c);
     if (nsteps > 1) {
       advance();
       load_set(Set1{}, tap, c);
     }
+    if constexpr (SCHED & 16) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // (set 0 = the four oldest of eight loads)
+      asm volatile("" : "+v"(ra[0][0]), "+v"(rb[0][0]));
+      stamp_x[1] = wall_clock64();                                 // first tile in registers
+    }
     store_set(Set0{}, 0);
     __syncthreads();
+    if constexpr (SCHED & 16) stamp[1] = wall_clock64();
     int step = 0;
+    // SCHED = ablation builds of the steady-state turns (JDET_CONV_BN_ABL, timing only, wrong results): bit 0 = no operand
+    // requests and no LDS stores (the loop runs on whatever LDS holds), bit 1 = no MFMAs (the LDS reads feed one add each),
+    // bit 2 = no barriers.  Round 6, measured and removed from the product instantiations: a scheduling fence behind the
+    // requests (hipcc sinks the four buffer loads below twelve of the step's sixteen MFMAs; with the fence it serialises
+    // the LDS reads instead: + 2 % per layer) and s_setprio 1 around the MFMAs (+ 2 %): profiles/r06_conv_prefetch.md.
     for (; step + 3 < nsteps; step += 2) {
       advance();
-      load_set(Set0{}, tap, c);        // step + 2
-      mfma_step(0);
-      store_set(Set1{}, 1);            // step + 1
-      __syncthreads();
+      if constexpr (!(SCHED & 1)) load_set(Set0{}, tap, c);        // step + 2
+      if constexpr (SCHED & 2) fake_step(0); else mfma_step(0);
+      if constexpr (!(SCHED & 1)) store_set(Set1{}, 1);            // step + 1
+      if constexpr (!(SCHED & 4)) __syncthreads();
       advance();
-      load_set(Set1{}, tap, c);        // step + 3
-      mfma_step(1);
-      store_set(Set0{}, 0);            // step + 2
-      __syncthreads();
+      if constexpr (!(SCHED & 1)) load_set(Set1{}, tap, c);        // step + 3
+      if constexpr (SCHED & 2) fake_step(1); else mfma_step(1);
+      if constexpr (!(SCHED & 1)) store_set(Set0{}, 0);            // step + 2
+      if constexpr (!(SCHED & 4)) __syncthreads();
     }
     while (step < nsteps) {            // the last one to three steps
       if (step + 2 < nsteps) {
@@ -299,6 +370,11 @@ void conv_bn_kernel(CbArgs a) {
     }
   }
 
+  if constexpr (DUAL) acc[0][0] += acc_b;
+  if constexpr (SCHED & 16) {
+    asm volatile("" : "+v"(acc[0][0]));          // (the stamp stays behind the last MFMA's result)
+    stamp[2] = wall_clock64();
+  }
   if (KG == 2) {
     float* red = reinterpret_cast<float*>(s_raw);
     static_assert(KG == 1 || 4 * T * T * 16 * 64 * 4 <= 4 * TILE, "reduction buffer");
@@ -320,6 +396,77 @@ void conv_bn_kernel(CbArgs a) {
   float cs1[T], cs2[T];
 #pragma unroll
   for (int j = 0; j < T; j++) cs1[j] = cs2[j] = 0.f;
+  bool stored = false;
+  if constexpr (T == 1) {
+    if (a.partial && m0 + BT <= M) {          // K split over workgroups: the plain sums to this part's plane, same store form
+      stored = true;
+      const int n = n0 + wn * (BT / 2) + (lane & 31);
+      if (n < a.Cout) {
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.partial + (size_t)blockIdx.y * M * a.Cout), 0, ybytes, 0x00020000);
+        const unsigned base = ((unsigned)(m0 + wm * (BT / 2) + 4 * (lane >> 5)) * (unsigned)a.Cout + (unsigned)n) * 4u;
+        const float* red = reinterpret_cast<const float*>(s_raw) + (size_t)(wave & 3) * 16 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+          float v = acc[0][0][e];
+          if (KG == 2) v += red[e * 64];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rp, base,
+                                                (unsigned)(((e & 3) + 8 * (e >> 2)) * a.Cout * 4), 0);
+        }
+      }
+    }
+    // a tile inside the map (round 6): the 16 rows leave by raw buffer stores -- one 32-bit lane offset, the row offsets in
+    // SGPRs, the mode decided once -- instead of 16 predicated stores with 64-bit addresses.  Same operations on the same
+    // values in the same order as the general path below.
+    if (full_tile) {
+      stored = true;
+      const int n = n0 + wn * (BT / 2) + (lane & 31);
+      const bool nok = n < a.Cout;
+      float sa = 1.f, sh = 0.f, beta = 0.f;
+      if (nok && (mode != JDET_EPI_ADD)) {
+        bn_affine(ep.bn, n, sa, sh);
+        beta = ep.bn.bias ? ep.bn.bias[n] : 0.f;
+      }
+      if constexpr (SCHED & 16) {
+        asm volatile("" : "+v"(sa), "+v"(sh));
+        stamp_x[2] = wall_clock64();                               // the column's BatchNorm parameters read and folded
+      }
+      if (nok) {
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, ybytes, 0x00020000);
+        const unsigned base = ((unsigned)(m0 + wm * (BT / 2) + 4 * (lane >> 5)) * (unsigned)a.Cout + (unsigned)n) * 4u;
+        const float* red = reinterpret_cast<const float*>(s_raw) + (size_t)(wave & 3) * 16 * 64 + lane;
+        auto rows = [&](auto modec) {
+          constexpr int MODE = decltype(modec)::value;
+          float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            float v = acc[0][0][e];
+            if (KG == 2) v += red[e * 64];
+            if constexpr (MODE == JDET_EPI_FORWARD) {
+              if (ep.affine) v = v * sa + sh;
+              v += pre0[e];                          // residual (0 without one)
+              if (ep.relu) v = fmaxf(v, 0.f);
+            } else if constexpr (MODE == JDET_EPI_ADD) {
+              v += pre1[e] > 0.f ? pre0[e] : 0.f;
+            } else {
+              v = pre0[e] > 0.f ? v : 0.f;
+              c1 += v;
+              c2 += v * (pre0[e] - beta);
+              v *= sa;
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, base,
+                                                  (unsigned)(((e & 3) + 8 * (e >> 2)) * a.Cout * 4), 0);
+          }
+          cs1[0] = c1;
+          cs2[0] = c2;
+        };
+        if (mode == JDET_EPI_FORWARD) rows(std::integral_constant<int, JDET_EPI_FORWARD>{});
+        else if (mode == JDET_EPI_ADD) rows(std::integral_constant<int, JDET_EPI_ADD>{});
+        else rows(std::integral_constant<int, JDET_EPI_MASK>{});
+      }
+    }
+  }
+  if (!stored)
 #pragma unroll
   for (int i = 0; i < T; i++) {
     const long mrow = m0 + wm * (BT / 2) + i * 32 + 4 * (lane >> 5);
@@ -331,6 +478,10 @@ void conv_bn_kernel(CbArgs a) {
       if (nok && !a.partial && (mode != JDET_EPI_ADD)) {
         bn_affine(ep.bn, n, sa, sh);
         beta = ep.bn.bias ? ep.bn.bias[n] : 0.f;
+      }
+      if constexpr (SCHED & 16) {
+        asm volatile("" : "+v"(sa), "+v"(sh));
+        stamp_x[2] = wall_clock64();                               // the column's BatchNorm parameters read and folded
       }
 #pragma unroll
       for (int h = 0; h < 2; h++) {          // 8 rows at a time: their neighbour loads are in flight together
@@ -393,6 +544,26 @@ void conv_bn_kernel(CbArgs a) {
         row[n] = s1;
         row[a.Cout + n] = s2;
       }
+    }
+  }
+  if constexpr (SCHED & 16) {
+    __syncthreads();
+    if (threadIdx.x == 0 && !a.partial && m0 < M && n0 + 16 <= a.Cout) {
+      stamp[3] = wall_clock64();
+      int* d = reinterpret_cast<int*>(a.y + (size_t)m0 * a.Cout + n0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        d[2 * k] = (int)(stamp[k] & 0xffffffff);
+        d[2 * k + 1] = (int)(stamp[k] >> 32);
+      }
+      d[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+      d[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+      d[10] = (int)blockIdx.x;
+      d[11] = 0x5741;
+      d[12] = (int)(stamp_x[0] - stamp[0]);
+      d[13] = (int)(stamp_x[1] - stamp[0]);
+      d[14] = (int)(stamp_x[2] - stamp[2]);
+      d[15] = 0;
     }
   }
 }
@@ -478,6 +649,22 @@ int launch(const CbArgs& a, hipStream_t st) {
   if constexpr (BT == 64) {
     static const int deep = cb_env_int("JDET_CONV_BN_DEEP", 1);     // operand tiles TWO K steps ahead (0: one; A/B switch)
     if (deep) {
+      if constexpr (KG == 1) {
+        static const int abl = cb_env_int("JDET_CONV_BN_ABL", 0);     // ablation builds (timing only): see the kernel
+        switch (BK == 32 ? abl : 0) {
+          case 1: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 1>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 2: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 3: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 3>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 4: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 4>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 5: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 5>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 6: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 6>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 16: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 16>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 8: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 8>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          case 13: hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2, 13>), dim3((unsigned)tiles, a.ksplit), dim3(256), 0, st, a); break;
+          default: break;
+        }
+        if (BK == 32 && ((abl >= 1 && abl <= 6) || abl == 8 || abl == 13 || abl == 16)) return jdet_launch_status();
+      }
       hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
       return jdet_launch_status();
     }

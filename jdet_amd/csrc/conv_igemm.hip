@@ -88,8 +88,10 @@ void conv3x3_igemm_kernel(ConvArgs a) {
   const int total = gridDim.x;
   int logical = blockIdx.x;
   if ((total & 7) == 0) logical = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-  const long m0 = (long)(logical / NT) * BT;
-  const int n0 = (logical % NT) * BT;
+  // (32-bit unsigned index arithmetic in the prologue -- the host refuses positions * channels >= 2^30; see conv_bn.hip)
+  const int mtile = (int)((unsigned)logical / (unsigned)NT);
+  const long m0 = (long)mtile * BT;
+  const int n0 = (logical - mtile * NT) * BT;
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)(M * a.Cin * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw =
@@ -107,18 +109,19 @@ void conv3x3_igemm_kernel(ConvArgs a) {
     m_ok[p] = lm < M;
     img[p] = py[p] = px[p] = 0;
     if (m_ok[p]) {
-      img[p] = (int)(lm / ((long)a.H * a.W));
-      const int rem = (int)(lm - (long)img[p] * a.H * a.W);
-      py[p] = rem / a.W;
-      px[p] = rem - py[p] * a.W;
+      const unsigned hw = (unsigned)(a.H * a.W), ulm = (unsigned)lm;
+      const unsigned im = ulm / hw, rem = ulm - im * hw, yy = rem / (unsigned)a.W;
+      img[p] = (int)im;
+      py[p] = (int)yy;
+      px[p] = (int)(rem - yy * (unsigned)a.W);
     }
     wv[p] = n0 + row < a.Cout ? ((unsigned)((n0 + row) * 9 * a.Cin + lchunk * 4)) * 4u : kOob;
     st_off[p] = swz_bytes<BK>(row, lchunk);
   }
   const int all_steps = 9 * (a.Cin / BK);   // (host: BK = 32 only when Cin % 32 == 0)
   // cross-workgroup K split: blockIdx.y takes the K steps [step0, step0 + nsteps) and leaves a partial tile
-  const int step0 = (int)((long)all_steps * blockIdx.y / a.ksplit);
-  const int nsteps = (int)((long)all_steps * (blockIdx.y + 1) / a.ksplit) - step0;
+  const int step0 = (int)((unsigned)all_steps * blockIdx.y / (unsigned)a.ksplit);
+  const int nsteps = (int)((unsigned)all_steps * (blockIdx.y + 1u) / (unsigned)a.ksplit) - step0;
   const int spt = a.Cin / BK;
 
   unsigned av[PASSES][NC];               // byte offsets of the tap's source pixel(s), or kOob
@@ -313,6 +316,49 @@ void conv3x3_igemm_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  // A tile inside the map (round 6, conv_bn.hip's finding): raw buffer loads / stores with one 32-bit lane offset and the 16
+  // row offsets in SGPRs instead of 16 predicated accesses with 64-bit addresses per 32 x 32 tile; same values, same order.
+  // (the 64 x 64 tile only: on the 128 x 128 tile the extra live values cost the 127-VGPR kernel two spills, and its
+  //  epilogue is 2 % of a 275 us launch)
+  if (T == 1 && m0 + BT <= M) {
+    const unsigned ybytes = (unsigned)(M * a.Cout * 4);
+    float* const dst = a.partial ? a.partial + (size_t)blockIdx.y * M * a.Cout : a.y;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.rowmask ? a.rowmask : a.x), 0, (unsigned)(M * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < T; i++) {
+      const unsigned mrow = (unsigned)(m0 + wm * (BT / 2) + i * 32 + 4 * (lane >> 5));
+      float mk[16];
+#pragma unroll
+      for (int e = 0; e < 16; e++)
+        mk[e] = (a.rowmask && !a.partial)
+                    ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, mrow * 4u, (unsigned)(((e & 3) + 8 * (e >> 2)) * 4), 0))
+                    : 1.f;
+#pragma unroll
+      for (int j = 0; j < T; j++) {
+        const int n = n0 + wn * (BT / 2) + j * 32 + (lane & 31);
+        if (n < a.Cout) {
+          const float b = a.bias ? a.bias[n] : 0.f;
+          const unsigned base = (mrow * (unsigned)a.Cout + (unsigned)n) * 4u;
+#pragma unroll
+          for (int e = 0; e < 16; e++) {
+            float v = acc[i][j][e];
+            if (KG == 2)
+              v += reinterpret_cast<const float*>(s_raw)[(((wave & 3) * T * T + i * T + j) * 16 + e) * 64 + lane];
+            if (!a.partial) {
+              v += b;
+              if (a.relu) v = fmaxf(v, 0.f);
+              if (a.rowmask) v *= mk[e];
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, base,
+                                                  (unsigned)(((e & 3) + 8 * (e >> 2)) * a.Cout * 4), 0);
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < T; i++) {
     float mk[16];

@@ -75,11 +75,14 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
   const int tiles = mt * nt * taps;
   // grid = tiles * (ksplit rounded up to whole rounds over the 8 XCDs); the surplus workgroups of the last round leave
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int chunk = xcd + 8 * (j / tiles), tile = j % tiles;
+  const int jq = (int)((unsigned)j / (unsigned)tiles);
+  const int chunk = xcd + 8 * jq, tile = j - jq * tiles;
   if (chunk >= a.ksplit) return;
-  const int tap = tile % taps, rest = tile / taps;
-  const int n0 = (rest % nt) * BN, m0 = (rest / nt) * BM;
-  const int dy = tap / a.R - pad, dx = tap % a.R - pad;
+  const int rest = (int)((unsigned)tile / (unsigned)taps), tap = tile - rest * taps;
+  const int mq = (int)((unsigned)rest / (unsigned)nt);
+  const int n0 = (rest - mq * nt) * BN, m0 = mq * BM;
+  const int tr = (int)((unsigned)tap / (unsigned)a.R);
+  const int dy = tr - pad, dx = tap - tr * a.R - pad;
   const long p_begin = (long)chunk * a.steps_per_chunk * BK;
   if (p_begin >= M) return;
   long left = (M - p_begin + BK - 1) / BK;
@@ -158,10 +161,14 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
     const int row = p * (256 / CB) + b_row;
     const long pp = p_begin + row;
     bp[p] = (int)pp;
-    bi[p] = (int)(pp / ((long)a.Ho * a.Wo));
-    const int rem = (int)(pp - (long)bi[p] * a.Ho * a.Wo);
-    by[p] = rem / a.Wo;
-    bx[p] = rem - by[p] * a.Wo;
+    {   // 32-bit unsigned: the host refuses (M + BK) * channels >= 2^30 (a 64-bit division is ~200 VALU instructions, and
+        // these workgroups live for a few microseconds: profiles/r06_conv_prefetch.md, the stamps of conv_bn)
+      const unsigned hw = (unsigned)(a.Ho * a.Wo), upp = (unsigned)pp;
+      const unsigned im = upp / hw, rem = upp - im * hw, yy = rem / (unsigned)a.Wo;
+      bi[p] = (int)im;
+      by[p] = (int)yy;
+      bx[p] = (int)(rem - yy * (unsigned)a.Wo);
+    }
     b_lin[p] = (unsigned)(((pp + dy * a.W + dx) * a.Cin + n0 + b_chunk * 4) * 4);
     b_st[p] = TILE_A + (row * SB + b_chunk * 4) * 4;
     o_h[p] = o_w[p] = 0.f;

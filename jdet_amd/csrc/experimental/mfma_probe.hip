@@ -79,6 +79,71 @@ void mfma_probe_kernel(const float* __restrict__ src, int steps, long long* __re
   if (lane == 0) cycles[blockIdx.x * 4 + wave] = t1 - t0;
   if (s == 12345.f) sink[0] = s;
 }
+// Round 6: the 64 x 64-tile kernels' inner structure (one 32 x 32 tile per wave, conv_bn.hip) against the 128-tile one, MFMAs and
+// LDS reads only (16 MFMAs per step either way):
+//   4  one accumulator, 8 ds_read_b128 per step (4 A + 4 B, each feeding 4 MFMAs)      -- the 64-tile step
+//   5  four accumulators (2 x 2 tiles), 4 ds_read_b128 per step (2 A + 2 B)              -- the 128-tile step
+//   6  one accumulator, operands in registers (the bare dependent chain)
+//   7  two accumulators (even / odd slices), 8 ds_read_b128 per step
+template <int VARIANT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+void mfma_probe2_kernel(const float* __restrict__ src, int steps, long long* __restrict__ cycles, float* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) char s_raw[32768];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // operands from `src` (random data: the matrix pipe's power, hence the clock under the power cap, depends on the bits it toggles)
+  for (int i = tid; i < 32768 / 4; i += 256) reinterpret_cast<float*>(s_raw)[i] = src[(i + blockIdx.x * 64) & 16383];
+  __syncthreads();
+  // conv_bn's XOR-swizzled 16-byte chunks: row = lane & 31 (+ 32 * wave half), chunk = 2 * q + (lane >> 5)
+  auto off = [&](int row, int chunk) { return (row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2)) * 4; };
+  int fa_off[4], fb_off[4];
+  for (int q = 0; q < 4; q++) {
+    fa_off[q] = off((wave >> 1) * 32 + (lane & 31), 2 * q + (lane >> 5));
+    fb_off[q] = 8192 + off((wave & 1) * 32 + (lane & 31), 2 * q + (lane >> 5));
+  }
+  v16f acc[4];
+  for (int i = 0; i < 4; i++)
+    for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+  const long long t0 = __builtin_amdgcn_s_memtime();
+  for (int step = 0; step < steps; step++) {
+    const char* sb = s_raw + (step & 1) * 16384;
+    if constexpr (VARIANT == 4 || VARIANT == 7) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const v4f fa = *reinterpret_cast<const v4f*>(sb + fa_off[q]);
+        const v4f fb = *reinterpret_cast<const v4f*>(sb + fb_off[q]);
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const int a = VARIANT == 7 ? (kk & 1) : 0;
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc[a], 0, 0, 0);
+        }
+      }
+    } else if constexpr (VARIANT == 5) {
+      v4f fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        fa[i] = *reinterpret_cast<const v4f*>(sb + fa_off[i]);
+        fb[i] = *reinterpret_cast<const v4f*>(sb + fb_off[i]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i * 2 + j], 0, 0, 0);
+    } else {
+      const float fa = src[lane], fb = src[64 + lane] + step;
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[0], 0, 0, 0);
+    }
+  }
+  const long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 4; i++)
+    for (int e = 0; e < 16; e++) s += acc[i][e];
+  if (lane == 0) cycles[blockIdx.x * 4 + wave] = t1 - t0;
+  if (s == 12345.f) sink[0] = s;
+}
 }  // namespace
 
 // cycles: n_blocks * 4 entries (one per wave); src: at least 64 KiB of floats
@@ -91,6 +156,10 @@ JDET_API int jdet_debug_mfma_probe(int variant, const float* src, int n_blocks, 
     case 1: hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
     case 2: hipLaunchKernelGGL(mfma_probe_kernel<2>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
     case 3: hipLaunchKernelGGL(mfma_probe_kernel<3>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
+    case 4: hipLaunchKernelGGL(mfma_probe2_kernel<4>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
+    case 5: hipLaunchKernelGGL(mfma_probe2_kernel<5>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
+    case 6: hipLaunchKernelGGL(mfma_probe2_kernel<6>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
+    case 7: hipLaunchKernelGGL(mfma_probe2_kernel<7>, dim3(n_blocks), dim3(256), 0, st, src, steps, cycles, sink); break;
     default: return JDET_E_BADARG;
   }
   return jdet_launch_status();

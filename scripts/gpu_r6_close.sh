@@ -57,4 +57,7 @@ timeout 900 python -m pytest tests/test_gpu_conv_igemm.py -q -x 2>&1 | tail -3
 bash scripts/ab_step.sh -n 3 "JDET_CONV_WGRAD=0" "JDET_CONV_WGRAD=1" "JDET_CONV_WGRAD=1 JDET_CONV_IGEMM_DGRAD=1" "JDET_CONV_WGRAD=0 JDET_CONV_IGEMM_DGRAD=1" 2>&1 | tee $R/gpurun_out/r6_ab_dgrad_bank.txt
 JDET_CONV_WGRAD=1 JDET_CONV_IGEMM_DGRAD=1 bash scripts/gpu_prof_s2anet.sh > /dev/null 2>&1; cp gpurun_out/prof_s2anet/steady_state.txt gpurun_out/r6_steady_own_grads.txt; head -3 gpurun_out/r6_steady_own_grads.txt | cut -c1-150; rm -rf gpurun_out/prof_s2anet/trace
 }
+run_abl() {   # ablation builds of the conv_bn 64-tile K loop (timing only): 1 no requests / LDS stores, 2 no MFMAs, 4 no barriers
+for k in ${ABLS:-0 1 2 3 4 5 6}; do echo "== JDET_CONV_BN_ABL=$k"; JDET_CONV_BN_ABL=$k timeout 600 python scripts/conv_bn_timing.py layers 2>&1 | grep -v Warn | cut -c1-42; done | tee $R/gpurun_out/r6_conv_bn_abl_layers.txt | grep "==\|sum\|l3.conv2\|l2.conv2\|l1.conv2\|l3.conv1"
+}
 for s in "$@"; do run_$s; done
