@@ -144,14 +144,15 @@ void conv_bn_kernel(CbArgs a) {
 
   unsigned av[PASSES];
   auto set_tap = [&](int tap) {
-    const int r = tap / a.R, s = tap - r * a.R;
+    // branch-free (round 6: the predicated form was eight exec-mask branches per call, inside the K loop at every tap change;
+    // R is 1 or 3: tap / R = (tap * 11) >> 5 for tap < 9)
+    const int r = a.R == 1 ? tap : (tap * 11) >> 5, s = tap - r * a.R;
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
-      av[p] = kOob;
-      if (!m_ok[p]) continue;
       const int yy = py[p] + r - pad, xx = px[p] + s - pad;
-      if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-        av[p] = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;
+      const bool in = m_ok[p] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const unsigned off = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;
+      av[p] = in ? off : kOob;
     }
   };
   constexpr int SETS = DEPTH;
@@ -424,12 +425,14 @@ void conv_bn_kernel(CbArgs a) {
       const bool nok = n < a.Cout;
       float sa = 1.f, sh = 0.f, beta = 0.f;
       if (nok && (mode != JDET_EPI_ADD)) {
+        // (measured: read and folded ahead of the K loop instead, riding in pre1 -- 1.3-2.2 us leave the epilogue, 0.6-1.8 us
+        //  join the prologue: no gain)
         bn_affine(ep.bn, n, sa, sh);
         beta = ep.bn.bias ? ep.bn.bias[n] : 0.f;
       }
       if constexpr (SCHED & 16) {
         asm volatile("" : "+v"(sa), "+v"(sh));
-        stamp_x[2] = wall_clock64();                               // the column's BatchNorm parameters read and folded
+        stamp_x[2] = wall_clock64();
       }
       if (nok) {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, ybytes, 0x00020000);

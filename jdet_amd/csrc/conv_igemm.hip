@@ -127,7 +127,7 @@ void conv3x3_igemm_kernel(ConvArgs a) {
   unsigned av[PASSES][NC];               // byte offsets of the tap's source pixel(s), or kOob
   float aw[PASSES][NC];                  // deformable: bilinear weights
   auto set_tap = [&](int tap) {
-    const int r = tap / 3, s = tap - r * 3;
+    const int r = (tap * 11) >> 5, s = tap - r * 3;      // tap / 3 for tap < 9
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
 #pragma unroll
@@ -135,12 +135,15 @@ void conv3x3_igemm_kernel(ConvArgs a) {
         av[p][k] = kOob;
         aw[p][k] = 0.f;
       }
-      if (!m_ok[p]) continue;
-      if (!DEFORM) {
+      if (!DEFORM) {      // branch-free (round 6, as conv_bn.hip's)
         const int yy = py[p] + r - 1, xx = px[p] + s - 1;
-        if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W)
-          av[p][0] = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;   // element index < 2^30: the byte offset is formed unsigned
-      } else {
+        const bool in = m_ok[p] && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const unsigned off = ((unsigned)(((img[p] * a.H + yy) * a.W + xx) * a.Cin + lchunk * 4)) * 4u;   // element index < 2^30: the byte offset is formed unsigned
+        av[p][0] = in ? off : kOob;
+        continue;
+      }
+      if (!m_ok[p]) continue;
+      {
         // dcn_v1.py:L132-166 (deformable_im2col): h_im = h_in + i*dil + offset_h, zero outside (-1, H) x (-1, W),
         // corners outside the image contribute 0 (dmcn_im2col_bilinear L25-56)
         const size_t ob = (((size_t)img[p] * 18 + 2 * tap) * a.H + py[p]) * a.W + px[p];

@@ -328,6 +328,27 @@ void conv3x3_wgrad_kernel(WgradArgs a) {
   }
   // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
   // a register's 32 lanes add to 128 contiguous bytes of gW[co, tap, :] ----
+  // A tile inside the weight tensor (round 6, conv_bn.hip's stamps: these workgroups live a few microseconds, and 16 x TM x TN
+  // predicated atomics with 64-bit addresses were a large part of that): raw buffer atomics, one 32-bit lane offset per
+  // 32 x 32 tile, the 16 row offsets in SGPRs.
+  const long gw_bytes = (long)a.Cout * taps * a.Cin * 4;
+  if (m0 + BM <= a.Cout && n0 + BN <= a.Cin && gw_bytes < (1L << 32)) {
+    const __amdgpu_buffer_rsrc_t rgw = __builtin_amdgcn_make_buffer_rsrc((void*)a.gw, 0, (unsigned)gw_bytes, 0x00020000);
+    const unsigned row_bytes = (unsigned)(taps * a.Cin * 4);
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const unsigned ci = (unsigned)(n0 + wn * 32 * TN + j * 32 + (lane & 31));
+        const unsigned co = (unsigned)(m0 + wm * 32 * TM + i * 32 + 4 * (lane >> 5));
+        const unsigned base = ((co * (unsigned)taps + (unsigned)tap) * (unsigned)a.Cin + ci) * 4u;
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[i][j][e], rgw, (int)base,
+                                                          (int)(((e & 3) + 8 * (e >> 2)) * row_bytes), 0);
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -405,6 +426,8 @@ int run_wgrad(const float* x_nhwc, const float* gy_nhwc, const float* offset, in
     // 32 K steps per chunk, in whole rounds over the 8 XCDs (chunk c runs on XCD c % 8: fewer than 8 chunks leave XCDs
     // idle -- 4 chunks of 32 steps ran 82 us where 8 chunks of 16 ran 48, 512 -> 2048 1x1 at 2 x 32^2) -- best or within
     // 2 % of the best forced split at all 17 layer shapes; halved while that makes more than ~9000 workgroups
+    // (round 6, re-measured with the rows four steps ahead and the raw-buffer epilogue: still the best forced split at the
+    //  layer1-3 shapes -- 64-step chunks ran 7-15 % slower at layer2; profiles/r06_conv_prefetch.md)
     ks = ((steps / 32 + 7) / 8) * 8;
     if (ks < 8) ks = 8;
     while (ks > 8 && tiles * ks > 9216) ks -= 8;

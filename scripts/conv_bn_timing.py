@@ -35,7 +35,9 @@ LAYERS = [
 
 
 def timeit(fn, n=30):
-    for _ in range(5):
+    # (25 warm-up launches: with 5, the first variant timed for a layer ran 5-9 % slow -- clocks and caches still settling --
+    #  which read as a win for whatever came later in a sweep: profiles/r06_conv_prefetch.md)
+    for _ in range(25):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
