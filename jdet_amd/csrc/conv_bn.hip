@@ -668,7 +668,13 @@ int launch(const CbArgs& a, hipStream_t st) {
         }
         if (BK == 32 && ((abl >= 1 && abl <= 6) || abl == 8 || abl == 13 || abl == 16)) return jdet_launch_status();
       }
-      hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), 0, st, a);
+      // JDET_CONV_BN_DYN_LDS (measurement switch): unused dynamic LDS per workgroup = fewer workgroups per CU (40960: two
+      // instead of four) -- a one-round launch then runs in two rounds whose prologues / epilogues overlap the other
+      // resident workgroup's K loop
+      static const int dyn = cb_env_int("JDET_CONV_BN_DYN_LDS", 0);
+      static const int dyn_min = cb_env_int("JDET_CONV_BN_DYN_MIN_TILES", 0), dyn_max = cb_env_int("JDET_CONV_BN_DYN_MAX_TILES", 1 << 30);
+      const unsigned lds = (dyn > 0 && tiles * a.ksplit >= dyn_min && tiles * a.ksplit <= dyn_max) ? (unsigned)dyn : 0u;
+      hipLaunchKernelGGL((conv_bn_kernel<BT, BK, KG, 2>), dim3((unsigned)tiles, a.ksplit), dim3(256 * KG), lds, st, a);
       return jdet_launch_status();
     }
   }
