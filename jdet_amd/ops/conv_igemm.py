@@ -116,14 +116,19 @@ def conv3x3_wgrad(x, gy, offset=None, ksplit=0):
     return gw.permute(0, 3, 1, 2)
 
 
-# Weight gradient of the igemm layers by csrc/conv_wgrad.hip (JDET_CONV_WGRAD=1; default: the library's).  Several uses
+# Weight gradient of the igemm layers by csrc/conv_wgrad.hip (default since round 6; JDET_CONV_WGRAD=0: the library's).  Several uses
 # of ONE weight inside one backward pass (a tower shared by the pyramid levels) accumulate into the buffer the first use
 # returned: the kernel adds in place, so the engine neither zero-fills per call nor sums the uses afterwards.
 # Measured (profiles/r04_conv_wgrad.md): the kernel runs 91 % MFMA-busy in cycles and ties the library's in isolation
 # (312 vs 314-326 us at 2 x 128^2 x 256), but inside the autotuned S2ANet step the library's pick is faster than its
 # stand-alone time: 29.28 ms with this switch on against 29.02-29.06 ms off -- so it is off by default.  (Round 5: the same
 # layers through the backbone's 64 x 64-tile entry point tie the library as well: 27.885 vs 27.904 ms, profiles/r05_conv_bn.md.)
-WGRAD = os.environ.get("JDET_CONV_WGRAD", "0") == "1"
+# Round 6: ON by default.  With 128 x 64 tiles for the tower shape (310 us against 360 on 128 x 128 and the library's 326 incl.
+# its zero fill), raw buffer atomics with SGPR row offsets in the epilogue and 32-bit prologue arithmetic the own kernel first
+# tied the library in the step (26.48 vs 26.48-26.52 ms) and then beat it: 26.075 vs 26.173 ms (three same-box pairs, all three in
+# its favour), 744 -> 727 launches (18 library zero fills and 8 accumulation adds fewer): profiles/r06_conv_prefetch.md.
+# JDET_CONV_WGRAD=0: the library's.
+WGRAD = os.environ.get("JDET_CONV_WGRAD", "1") == "1"
 def _wgrad_call(x_nhwc, gy_nhwc, offset, N, H, W, Cin, Cout, out_ptr, ksplit):
     return L.lib().jdet_conv3x3_wgrad(L.ptr(x_nhwc), L.ptr(gy_nhwc), L.ptr(L.f32c(offset)) if offset is not None else None,
                                       N, H, W, Cin, Cout, out_ptr, int(ksplit), L.stream_ptr(x_nhwc))
