@@ -76,7 +76,7 @@ __device__ __forceinline__ void bn_affine(const jdet_bn_params_t& p, int n, floa
 // DEPTH (round 6; BT = 64, one wave group): the operand tiles of a K step are requested DEPTH steps ahead into DEPTH
 // register sets instead of one step ahead into one -- a 64 x 64 tile's K step is 16 MFMAs per wave (0.43 us), less than a
 // global round trip under load, so with one step of cover every step ended in a wait for its successor's tiles.
-template <int BT, int BK, int KG, int DEPTH = 1, int SCHED = 0>
+template <int BT, int BK, int KG, int DEPTH = 1, int ABL = 0>
 __global__ __launch_bounds__(256 * KG)
 __attribute__((amdgpu_waves_per_eu(BT == 128 ? (KG == 2 ? 4 : (BK == 32 ? 2 : 4)) : 4)))
 void conv_bn_kernel(CbArgs a) {
@@ -90,10 +90,10 @@ void conv_bn_kernel(CbArgs a) {
   static_assert(PASSES >= 1 && QN >= 1, "tile shape");
   __shared__ __attribute__((aligned(16))) char s_raw[4 * TILE];     // [buffer][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // SCHED & 16: workgroup time stamps (scripts/r6_conv_stamps.py): start, K loop entered / left, end, placement -- written
+  // ABL & 16: workgroup time stamps (scripts/r6_conv_stamps.py): start, K loop entered / left, end, placement -- written
   // over the first words of the tile's first output row (a profiling build: that row is garbage afterwards)
   long long stamp[4] = {0, 0, 0, 0}, stamp_x[3] = {0, 0, 0};     // _x: requests issued | first tile landed | epilogue operands read
-  if constexpr (SCHED & 16) stamp[0] = wall_clock64();
+  if constexpr (ABL & 16) stamp[0] = wall_clock64();
   const long M = (long)a.N * a.Ho * a.Wo;
   const long Min = (long)a.N * a.H * a.W;
   const int taps = a.R * a.R, pad = a.R >> 1;
@@ -195,7 +195,7 @@ void conv_bn_kernel(CbArgs a) {
     for (int j = 0; j < T; j++)
 #pragma unroll
       for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-  constexpr bool DUAL = T == 1 && (SCHED & 8) != 0;
+  constexpr bool DUAL = T == 1 && (ABL & 8) != 0;
   v16f acc_b;
 #pragma unroll
   for (int e = 0; e < 16; e++) acc_b[e] = 0.f;
@@ -319,37 +319,37 @@ void conv_bn_kernel(CbArgs a) {
     // formulation with a switch over the last turns spilled: 128 VGPRs + 76 B of scratch at depth 2, 208 B at depth 3).
     static_assert(DEPTH == 2, "two register sets");
     using Set1 = std::integral_constant<int, 1>;
-    if constexpr (SCHED & 16) stamp_x[0] = wall_clock64();          // index arithmetic done
+    if constexpr (ABL & 16) stamp_x[0] = wall_clock64();          // index arithmetic done
     load_set(Set0{}, tap, c);
     if (nsteps > 1) {
       advance();
       load_set(Set1{}, tap, c);
     }
-    if constexpr (SCHED & 16) {
+    if constexpr (ABL & 16) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // (set 0 = the four oldest of eight loads)
       asm volatile("" : "+v"(ra[0][0]), "+v"(rb[0][0]));
       stamp_x[1] = wall_clock64();                                 // first tile in registers
     }
     store_set(Set0{}, 0);
     __syncthreads();
-    if constexpr (SCHED & 16) stamp[1] = wall_clock64();
+    if constexpr (ABL & 16) stamp[1] = wall_clock64();
     int step = 0;
-    // SCHED = ablation builds of the steady-state turns (JDET_CONV_BN_ABL, timing only, wrong results): bit 0 = no operand
+    // ABL = ablation builds of the steady-state turns (JDET_CONV_BN_ABL, timing only, wrong results): bit 0 = no operand
     // requests and no LDS stores (the loop runs on whatever LDS holds), bit 1 = no MFMAs (the LDS reads feed one add each),
     // bit 2 = no barriers.  Round 6, measured and removed from the product instantiations: a scheduling fence behind the
     // requests (hipcc sinks the four buffer loads below twelve of the step's sixteen MFMAs; with the fence it serialises
     // the LDS reads instead: + 2 % per layer) and s_setprio 1 around the MFMAs (+ 2 %): profiles/r06_conv_prefetch.md.
     for (; step + 3 < nsteps; step += 2) {
       advance();
-      if constexpr (!(SCHED & 1)) load_set(Set0{}, tap, c);        // step + 2
-      if constexpr (SCHED & 2) fake_step(0); else mfma_step(0);
-      if constexpr (!(SCHED & 1)) store_set(Set1{}, 1);            // step + 1
-      if constexpr (!(SCHED & 4)) __syncthreads();
+      if constexpr (!(ABL & 1)) load_set(Set0{}, tap, c);        // step + 2
+      if constexpr (ABL & 2) fake_step(0); else mfma_step(0);
+      if constexpr (!(ABL & 1)) store_set(Set1{}, 1);            // step + 1
+      if constexpr (!(ABL & 4)) __syncthreads();
       advance();
-      if constexpr (!(SCHED & 1)) load_set(Set1{}, tap, c);        // step + 3
-      if constexpr (SCHED & 2) fake_step(1); else mfma_step(1);
-      if constexpr (!(SCHED & 1)) store_set(Set0{}, 0);            // step + 2
-      if constexpr (!(SCHED & 4)) __syncthreads();
+      if constexpr (!(ABL & 1)) load_set(Set1{}, tap, c);        // step + 3
+      if constexpr (ABL & 2) fake_step(1); else mfma_step(1);
+      if constexpr (!(ABL & 1)) store_set(Set0{}, 0);            // step + 2
+      if constexpr (!(ABL & 4)) __syncthreads();
     }
     while (step < nsteps) {            // the last one to three steps
       if (step + 2 < nsteps) {
@@ -372,7 +372,7 @@ void conv_bn_kernel(CbArgs a) {
   }
 
   if constexpr (DUAL) acc[0][0] += acc_b;
-  if constexpr (SCHED & 16) {
+  if constexpr (ABL & 16) {
     asm volatile("" : "+v"(acc[0][0]));          // (the stamp stays behind the last MFMA's result)
     stamp[2] = wall_clock64();
   }
@@ -430,7 +430,7 @@ void conv_bn_kernel(CbArgs a) {
         bn_affine(ep.bn, n, sa, sh);
         beta = ep.bn.bias ? ep.bn.bias[n] : 0.f;
       }
-      if constexpr (SCHED & 16) {
+      if constexpr (ABL & 16) {
         asm volatile("" : "+v"(sa), "+v"(sh));
         stamp_x[2] = wall_clock64();
       }
@@ -482,7 +482,7 @@ void conv_bn_kernel(CbArgs a) {
         bn_affine(ep.bn, n, sa, sh);
         beta = ep.bn.bias ? ep.bn.bias[n] : 0.f;
       }
-      if constexpr (SCHED & 16) {
+      if constexpr (ABL & 16) {
         asm volatile("" : "+v"(sa), "+v"(sh));
         stamp_x[2] = wall_clock64();                               // the column's BatchNorm parameters read and folded
       }
@@ -549,7 +549,7 @@ void conv_bn_kernel(CbArgs a) {
       }
     }
   }
-  if constexpr (SCHED & 16) {
+  if constexpr (ABL & 16) {
     __syncthreads();
     if (threadIdx.x == 0 && !a.partial && m0 < M && n0 + 16 <= a.Cout) {
       stamp[3] = wall_clock64();
